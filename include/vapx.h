@@ -1,0 +1,153 @@
+/*
+ * vapx.h — C ABI of libvapx.so: MI355X-native many-stream engine for the Realtime-VAP
+ * streaming forward pass (CPC encoder -> LSTM -> downsample -> per-stream context ring ->
+ * 1 self + 3 self/cross GPT layers -> VAP head -> p_now / p_future / VAD).
+ *
+ * The reference (inokoj/VAP-Realtime) has NO FFI / plugin interface for this path: it is plain
+ * Python attribute calls.  Each entry point below therefore cites the reference
+ * Python call it stands in for; the ctypes binding a maintainer would add on the reference side is
+ * shown in INTEGRATION.md and implemented in vap-realtime_amd/engine.py.
+ *
+ * Conventions
+ *   - plain C types only; no torch / HIP types in signatures (hipStream_t travels as void*).
+ *   - every function returns 0 on success or a negative VAPX_E_* code; no exceptions cross the
+ *     ABI; vapx_last_error() returns a human-readable message for the last failure on a handle
+ *     (or for a failed vapx_create when called with NULL).
+ *   - ownership: the caller owns audio / output / blob memory (the blob is copied at create);
+ *     the library owns device weights, per-stream state and scratch.
+ *   - threading: calls on one handle must be serialised by the caller (the reference runs
+ *     inference on a single thread, rvap/vap_main/vap_main.py:520-521).  Work is ordered on the
+ *     HIP stream passed in; device outputs are valid after that stream is synchronised, host
+ *     outputs are valid on return.
+ *   - one handle per GPU; streams (dialogues) are independent, so multi-GPU = one handle per
+ *     device with the stream ids partitioned by the caller (no collective).
+ */
+#ifndef VAPX_H_
+#define VAPX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VAPX_ABI_VERSION 1
+
+/* error codes */
+#define VAPX_OK 0
+#define VAPX_E_INVAL (-1)    /* bad argument */
+#define VAPX_E_HIP (-2)      /* HIP runtime error (see vapx_last_error) */
+#define VAPX_E_NOMEM (-3)
+#define VAPX_E_RANGE (-4)    /* stream id / batch size out of range */
+#define VAPX_E_NODEVICE (-5) /* no gfx950 device visible */
+
+/* model variants: which heads are evaluated (vap_main.py:290-307, vap_bc_main.py:272-277,
+ * vap_nod_main.py:273-279) */
+#define VAPX_MODE_VAP 0
+#define VAPX_MODE_BC 1
+#define VAPX_MODE_NOD 2
+
+/* memory-space flags for vapx_step */
+#define VAPX_AUDIO_HOST 0
+#define VAPX_AUDIO_DEVICE 1
+#define VAPX_OUT_HOST 0
+#define VAPX_OUT_DEVICE 2
+#define VAPX_IDS_DEVICE 4 /* stream_ids points to device memory (default: host) */
+
+/* Layout of one output row (floats).  Row stride is VAPX_OUT_STRIDE. */
+#define VAPX_OUT_P_NOW 0     /* [2]  result_p_now        vap_main.py:316 */
+#define VAPX_OUT_P_FUTURE 2  /* [2]  result_p_future     vap_main.py:317 */
+#define VAPX_OUT_VAD 4       /* [2]  result_vad          vap_main.py:313-320 */
+#define VAPX_OUT_AUX 6       /* [4]  bc: {-, p_bc_react, p_bc_emo, -}; nod: {-, short, long, long_p} */
+#define VAPX_OUT_NVALID 10   /* [1]  n = rows in the context window this frame (as float) */
+#define VAPX_OUT_LOGITS 16   /* [256] vap_head logits of the newest row  vap_main.py:290 */
+#define VAPX_OUT_E 272       /* [2*256] this frame's embeddings e1,e2   vap_main.py:272 */
+#define VAPX_OUT_STRIDE 784
+
+typedef struct vapx_engine* vapx_handle;
+
+typedef struct vapx_config {
+  int32_t struct_size;  /* sizeof(vapx_config), for ABI evolution */
+  int32_t device_id;    /* HIP device ordinal */
+  int32_t frame_hz;     /* 5, 10, 20 or 50: VAPRealTime frame_rate   vap_main.py:192,219 */
+  int32_t ctx_frames;   /* T = int(context_len_sec*frame_rate)        vap_main.py:221 */
+  int32_t max_streams;  /* stream slots whose state lives in HBM */
+  int32_t max_batch;    /* max streams per vapx_step call (sizes scratch) */
+  int32_t mode;         /* VAPX_MODE_* */
+  int32_t flags;        /* reserved, 0 */
+} vapx_config;
+
+/* Number of floats the weight blob must have for a frame rate (layout:
+ * vap-realtime_amd/weights.py:blob_layout).  Returns 0 for an unsupported rate. */
+size_t vapx_blob_floats(int32_t frame_hz);
+
+/* Stands in for VAPRealTime.__init__ (vap_main.py:192-247): builds device weights from the packed
+ * blob (host memory, fp32), allocates per-stream state (context ring, LSTM h/c, 320-sample
+ * carry) zero-initialised, and scratch for max_batch streams. */
+int vapx_create(const vapx_config* cfg, const float* weights_blob, size_t n_floats, vapx_handle* out);
+
+void vapx_destroy(vapx_handle h);
+
+/* Stands in for VAPRealTime.process_vap (vap_main.py:249-335) for n streams at once.
+ *   stream_ids : n ids in [0,max_streams), all distinct; NULL means 0..n-1.
+ *   audio      : fp32 [n][2][samples_per_ch].  samples_per_ch == hop (=16000/frame_hz): new
+ *                samples only, the engine prepends its own 320-sample carry like proc_serv_in
+ *                (vap_main.py:397-409).  samples_per_ch == hop+320: a complete frame exactly as
+ *                process_vap receives x1/x2 (carry supplied by the caller, vap_offline.py:51-61);
+ *                the engine's carry is then set to the frame's last 320 samples.
+ *   out        : fp32 [n][VAPX_OUT_STRIDE].
+ *   flags      : VAPX_AUDIO_* | VAPX_OUT_* | VAPX_IDS_DEVICE
+ *   hip_stream : hipStream_t to order the work on (NULL = default stream). */
+int vapx_step(vapx_handle h, int32_t n, const int32_t* stream_ids, const float* audio,
+              int32_t samples_per_ch, float* out, int32_t flags, void* hip_stream);
+
+/* Zero one stream's state (context ring fill, LSTM h/c, carry).  The reference never resets
+ * model state on reconnect (vap_main.py:368-369 re-zeroes only the carry); this is the explicit
+ * equivalent of constructing a fresh VAPRealTime for that stream. */
+int vapx_reset_stream(vapx_handle h, int32_t stream_id);
+
+/* State export / import for one stream (tests, migration between GPUs).  Host pointers, any may
+ * be NULL to skip.  ring: [2][T][256] oldest->newest, rows >= n_frames undefined;
+ * lstm: [2 ch][2 (h,c)][256]; carry: [2][320]. */
+int vapx_get_state(vapx_handle h, int32_t stream_id, float* ring, int32_t* n_frames, float* lstm, float* carry);
+int vapx_set_state(vapx_handle h, int32_t stream_id, const float* ring, int32_t n_frames, const float* lstm,
+                   const float* carry);
+
+/* Stage-level entry points: the model-attribute surface process_vap calls (SURVEY.md §8b level 1).
+ * All pointers are DEVICE memory, fp32, contiguous.  They use the handle's weights and scratch
+ * but touch no stream state except vapx_encode_audio (LSTM h/c of the given stream ids). */
+
+/* VapGPT.encode_audio (vap_main.py:175-180): frames [n][2][hop+320] -> e [n][2][256].
+ * Stateful: advances the LSTM state of stream_ids (host pointer, NULL = 0..n-1). */
+int vapx_encode_audio(vapx_handle h, int32_t n, const int32_t* stream_ids, const float* frames, float* e,
+                      void* hip_stream);
+
+/* GPT.forward (ar_channel, vap_main.py:285-286) then GPTStereo.forward (ar, :287) on explicit
+ * context tensors x [n][2][rows][256] (rows <= ctx_frames).  Any output pointer may be NULL.
+ *   o    [n][2][rows][256]  ar_channel(x_c)["x"]
+ *   x12  [n][2][rows][256]  ar(...)["x1"], ["x2"]
+ *   comb [n][rows][256]     ar(...)["x"]  (Combinator output, all rows) */
+int vapx_transformer(vapx_handle h, int32_t n, int32_t rows, const float* x, float* o, float* x12, float* comb,
+                     void* hip_stream);
+
+/* Copy an internal scratch buffer of the LAST vapx_step to the host (per-layer parity tests).
+ * name: "h0".."h3","z","lstm_out","e","x0","o","stereo0".."stereo2"; returns the number of
+ * floats written (<= max_floats) or a negative error. */
+int64_t vapx_peek(vapx_handle h, const char* name, float* dst, size_t max_floats);
+
+/* Standalone fp32-MFMA GEMM used by every dense contraction of the path (kernel unit tests):
+ * C[M][N] = epilogue(A[M][K] . W[N][K]^T); device pointers.  epi: 0 store(+bias) 1 gelu
+ * 2 +resid 3 +resid & LN copy -> C2  4 bias+ChannelNorm+ReLU  5 bias+LN+GELU.  N must be a
+ * multiple of 256, K a multiple of 32; epilogues 3,4,5 need N == 256. */
+int vapx_gemm(void* hip_stream, int32_t M, int32_t N, int32_t K, const float* A, const float* W, float* C,
+              int32_t epi, const float* bias, const float* gamma, const float* beta, const float* resid,
+              float* C2, int32_t tile_rows);
+
+const char* vapx_last_error(vapx_handle h);
+int32_t vapx_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAPX_H_ */

@@ -1,0 +1,78 @@
+"""Pin the oracle (oracle/vap_oracle.py) against golden vectors produced by the imported,
+unmodified reference (tools/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from golden_util import Case
+from oracle.vap_oracle import ServerFramer, VapOracle
+
+TOL = 2e-5          # logits / embeddings: fp32 summation-order noise between two CPU formulations
+TOL_P = 2e-6        # probabilities
+TOL_RESID = 1e-3    # raw residual-stream tensors (magnitudes ~1e2)
+
+
+def run_oracle(case, collect_frames=()):
+    o = VapOracle(case.cpc_sd, case.vap_sd, case.frame_hz, case.ctx_sec, case.mode)
+    S = len(case.streams)
+    st = o.new_state(S)
+    fr = ServerFramer(S, case.hop)
+    outs, cols = [], {}
+    for f in range(case.n_frames):
+        col = {} if f in collect_frames else None
+        buf = fr.frame(case.new_samples(f)) if case.framing == "server" else case.window(f)
+        outs.append(o.step(buf, st, col))
+        if col is not None:
+            cols[f] = col
+    return outs, cols
+
+
+@pytest.mark.parametrize("name", ["vap20", "vap10", "offline20", "multi3", "vap50"])
+def test_oracle_matches_reference_outputs(name):
+    c = Case(name)
+    z = c.z
+    es = int(z["meta.e_stride"]) if "meta.e_stride" in z.files else 1
+    inter_frames = sorted({int(k.split(".")[1][1:]) for k in z.files if k.startswith("inter.f")})
+    outs, cols = run_oracle(c, inter_frames)
+    for f, out in enumerate(outs):
+        np.testing.assert_allclose(out["p_now"], z["p_now"][f], rtol=0, atol=TOL_P)
+        np.testing.assert_allclose(out["p_future"], z["p_future"][f], rtol=0, atol=TOL_P)
+        np.testing.assert_allclose(out["vad"], z["vad"][f], rtol=0, atol=TOL_P)
+        np.testing.assert_allclose(out["logits"], z["logits"][f], rtol=0, atol=TOL)
+        if f % es == 0:
+            np.testing.assert_allclose(out["e"], z["e"][f // es], rtol=0, atol=TOL)
+    for f in inter_frames:
+        col = cols[f]
+        rows = z[f"inter.f{f}.rows"]
+        np.testing.assert_allclose(col["cnn4"][0].numpy(), z[f"inter.f{f}.cnn4"], rtol=0, atol=TOL)
+        np.testing.assert_allclose(col["lstm_out"][0].numpy(), z[f"inter.f{f}.lstm_out"], rtol=0, atol=TOL)
+        np.testing.assert_allclose(col["o"][0].numpy()[:, rows], z[f"inter.f{f}.o"], rtol=0, atol=TOL_RESID)
+        for l in range(3):
+            np.testing.assert_allclose(col[f"stereo{l}"][0].numpy()[:, rows], z[f"inter.f{f}.stereo{l}"],
+                                       rtol=2e-5, atol=TOL_RESID)
+        np.testing.assert_allclose(col["comb"][0].numpy()[rows], z[f"inter.f{f}.comb"], rtol=0, atol=TOL)
+
+
+def test_oracle_bc_heads():
+    c = Case("bc20")
+    outs, _ = run_oracle(c)
+    for f, out in enumerate(outs):
+        np.testing.assert_allclose(out["p_bc_react"], c.z["p_bc_react"][f].reshape(-1), rtol=0, atol=TOL_P)
+        np.testing.assert_allclose(out["p_bc_emo"], c.z["p_bc_emo"][f].reshape(-1), rtol=0, atol=TOL_P)
+
+
+def test_oracle_nod_heads():
+    c = Case("nod20")
+    outs, _ = run_oracle(c)
+    for f, out in enumerate(outs):
+        for k in ("p_nod_short", "p_nod_long", "p_nod_long_p"):
+            np.testing.assert_allclose(out[k], c.z[k][f].reshape(-1), rtol=0, atol=TOL_P)
+        n = min(f + 1, c.T)
+        np.testing.assert_allclose(out["p_bc"][:, :n], c.z["p_bc"][f][:, :n], rtol=0, atol=TOL_P)
+
+
+def test_batched_oracle_equals_independent_runs():
+    """multi3 golden = three independent reference processes; the oracle runs them as one batch."""
+    c = Case("multi3")
+    outs, _ = run_oracle(c)
+    # different streams must actually differ (guards against a broadcast bug)
+    assert np.abs(outs[-1]["logits"][0] - outs[-1]["logits"][1]).max() > 1e-2

@@ -1,0 +1,349 @@
+"""Weight handling for the VAP streaming forward pass.
+
+Two jobs:
+
+1. ``synthetic_weights(seed, frame_hz, mode)`` — deterministic, numpy-seeded stand-ins for the
+   reference checkpoints (every ``asset/**.pt`` is absent from the reference checkout, see
+   ``/root/reference/.MISSING_LARGE_BLOBS``).  The tensors carry exactly the names and shapes of
+   the reference state dicts: the CPC checkpoint's ``["weights"]`` dict
+   (``rvap/vap_main/encoder_components.py:73-159``) and the VAP state dict consumed by
+   ``VAPRealTime.__init__`` (``rvap/vap_main/vap_main.py:199-212``), including the four
+   ``encoder.downsample.*`` keys that are copied over by hand there.  Scales are chosen
+   "sensitive" (logits span several units) so numerical errors are not hidden behind a
+   near-constant output.
+2. ``pack_blob(cpc_sd, vap_sd, ...)`` — re-lays those tensors into the single contiguous fp32
+   blob that ``vapx_create`` (include/vapx.h) uploads to HBM.  Layout is described by
+   ``blob_layout``; the same table is compiled into the C side (csrc/vapx_layout.h is generated
+   from it by ``write_layout_header``) so both sides agree by construction.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+DIM = 256
+FFN = 768
+HEADS = 4
+N_CLASSES = 256
+LSTM_GATES = 4 * DIM
+
+MODES = ("vap", "bc", "nod")
+
+
+def cpc_frames_for_rate(frame_hz: int) -> int:
+    """K = int(100 / frame_hz): CPC frames per VAP frame == downsample kernel size
+    (train/encoder.py:33-42)."""
+    hop = 16000 // frame_hz
+    L = hop + 320
+    p = L // 5
+    for s in (4, 2, 2, 2):
+        p //= s
+    return p - 2
+
+
+# ----------------------------------------------------------------------------------------------
+# synthetic state dicts
+# ----------------------------------------------------------------------------------------------
+
+def _cpc_spec() -> List[Tuple[str, Tuple[int, ...], str]]:
+    spec = []
+    ks = [10, 8, 4, 4, 4]
+    for i, k in enumerate(ks):
+        cin = 1 if i == 0 else DIM
+        spec.append((f"gEncoder.conv{i}.weight", (DIM, cin, k), "conv"))
+        spec.append((f"gEncoder.conv{i}.bias", (DIM,), "bias"))
+        spec.append((f"gEncoder.batchNorm{i}.weight", (1, DIM, 1), "gamma"))
+        spec.append((f"gEncoder.batchNorm{i}.bias", (1, DIM, 1), "beta"))
+    spec.append(("gAR.baseNet.weight_ih_l0", (LSTM_GATES, DIM), "lstm"))
+    spec.append(("gAR.baseNet.weight_hh_l0", (LSTM_GATES, DIM), "lstm"))
+    spec.append(("gAR.baseNet.bias_ih_l0", (LSTM_GATES,), "bias"))
+    spec.append(("gAR.baseNet.bias_hh_l0", (LSTM_GATES,), "bias"))
+    return spec
+
+
+def _layer_spec(prefix: str, cross: bool) -> List[Tuple[str, Tuple[int, ...], str]]:
+    spec = [
+        (f"{prefix}.ln_self_attn.weight", (DIM,), "gamma"),
+        (f"{prefix}.ln_self_attn.bias", (DIM,), "beta"),
+        (f"{prefix}.ln_ffnetwork.weight", (DIM,), "gamma"),
+        (f"{prefix}.ln_ffnetwork.bias", (DIM,), "beta"),
+        (f"{prefix}.mha.m", (HEADS,), "alibi"),
+        (f"{prefix}.mha.key.weight", (DIM, DIM), "linear"),
+        (f"{prefix}.mha.query.weight", (DIM, DIM), "linear"),
+        (f"{prefix}.mha.value.weight", (DIM, DIM), "linear"),
+        (f"{prefix}.mha.proj.weight", (DIM, DIM), "linear"),
+        (f"{prefix}.ffnetwork.0.weight", (FFN, DIM), "linear"),
+        (f"{prefix}.ffnetwork.3.weight", (DIM, FFN), "linear"),
+    ]
+    if cross:
+        spec += [
+            (f"{prefix}.ln_src_attn.weight", (DIM,), "gamma"),
+            (f"{prefix}.ln_src_attn.bias", (DIM,), "beta"),
+            (f"{prefix}.mha_cross.m", (HEADS,), "alibi"),
+            (f"{prefix}.mha_cross.key.weight", (DIM, DIM), "linear"),
+            (f"{prefix}.mha_cross.query.weight", (DIM, DIM), "linear"),
+            (f"{prefix}.mha_cross.value.weight", (DIM, DIM), "linear"),
+            (f"{prefix}.mha_cross.proj.weight", (DIM, DIM), "linear"),
+        ]
+    return spec
+
+
+def _vap_spec(K: int, mode: str) -> List[Tuple[str, Tuple[int, ...], str]]:
+    spec = _layer_spec("ar_channel.layers.0", cross=False)
+    for l in range(3):
+        spec += _layer_spec(f"ar.layers.{l}", cross=True)
+    spec += [
+        ("ar.combinator.h0_a.weight", (DIM, DIM), "linear"),
+        ("ar.combinator.h0_b.weight", (DIM, DIM), "linear"),
+        ("ar.combinator.ln.weight", (DIM,), "gamma"),
+        ("ar.combinator.ln.bias", (DIM,), "beta"),
+        ("objective.codebook.emb.weight", (N_CLASSES, 8), "codebook"),
+        ("va_classifier.weight", (1, DIM), "linear"),
+        ("va_classifier.bias", (1,), "bias"),
+        ("vap_head.weight", (N_CLASSES, DIM), "linear"),
+        ("vap_head.bias", (N_CLASSES,), "bias"),
+    ]
+    if mode == "bc":  # rvap/vap_bc/vap_bc_main.py:137
+        spec += [("bc_head.weight", (3, DIM), "linear"), ("bc_head.bias", (3,), "bias")]
+    elif mode == "nod":  # rvap/vap_nod/vap_nod_main.py:137-138
+        spec += [
+            ("nod_head.weight", (4, DIM), "linear"),
+            ("nod_head.bias", (4,), "bias"),
+            ("bc_head.weight", (1, DIM), "linear"),
+            ("bc_head.bias", (1,), "bias"),
+        ]
+    spec += [
+        ("encoder.downsample.1.weight", (DIM, DIM, K), "down"),
+        ("encoder.downsample.1.bias", (DIM,), "bias"),
+        ("encoder.downsample.2.ln.weight", (DIM,), "gamma"),
+        ("encoder.downsample.2.ln.bias", (DIM,), "beta"),
+    ]
+    return spec
+
+
+def alibi_slopes(n: int = HEADS) -> np.ndarray:
+    """m_h = 2^(-8(h+1)/n) (modules.py:125-160) — [1/4, 1/16, 1/64, 1/256] for 4 heads."""
+    start = 2.0 ** (-(2.0 ** -(math.log2(n) - 3)))
+    return np.array([start * start ** i for i in range(n)], dtype=np.float32)
+
+
+def codebook_vectors() -> np.ndarray:
+    """emb[i, k] = bit k of i (objective.py:93-110)."""
+    idx = np.arange(N_CLASSES)[:, None]
+    return ((idx >> np.arange(8)[None, :]) & 1).astype(np.float32)
+
+
+def _draw(rng: np.random.Generator, shape, kind: str) -> np.ndarray:
+    if kind == "alibi":
+        return alibi_slopes()
+    if kind == "codebook":
+        return codebook_vectors()
+    if kind == "gamma":
+        return (1.0 + 0.2 * rng.standard_normal(shape)).astype(np.float32)
+    if kind == "beta":
+        return (0.2 * rng.standard_normal(shape)).astype(np.float32)
+    if kind == "bias":
+        return (0.1 * rng.standard_normal(shape)).astype(np.float32)
+    if kind == "linear":
+        fan_in = shape[-1]
+        return (1.5 / math.sqrt(fan_in) * rng.standard_normal(shape)).astype(np.float32)
+    if kind == "conv":
+        fan_in = shape[1] * shape[2]
+        return (1.5 / math.sqrt(fan_in) * rng.standard_normal(shape)).astype(np.float32)
+    if kind == "down":
+        fan_in = shape[1] * shape[2]
+        return (1.0 / math.sqrt(fan_in) * rng.standard_normal(shape)).astype(np.float32)
+    if kind == "lstm":
+        return (1.0 / math.sqrt(shape[-1]) * rng.standard_normal(shape)).astype(np.float32)
+    raise ValueError(kind)
+
+
+def synthetic_weights(seed: int = 0, frame_hz: int = 20, mode: str = "vap"):
+    """Return ``(cpc_sd, vap_sd)`` as OrderedDicts of float32 numpy arrays with the reference's
+    state-dict names.  Deterministic in (seed, frame_hz, mode); the draw order is the order of
+    the spec lists above and never changes."""
+    assert mode in MODES
+    K = cpc_frames_for_rate(frame_hz)
+    rng = np.random.default_rng(seed)
+    cpc = OrderedDict((n, _draw(rng, s, k)) for n, s, k in _cpc_spec())
+    vap = OrderedDict((n, _draw(rng, s, k)) for n, s, k in _vap_spec(K, mode))
+    return cpc, vap
+
+
+def weights_fingerprint(cpc_sd, vap_sd) -> np.ndarray:
+    """Small vector (sum, abs-sum per dict) stored in golden fixtures so a test can prove the
+    GPU box regenerated bit-identical weights from the seed."""
+    out = []
+    for sd in (cpc_sd, vap_sd):
+        s = np.float64(0.0)
+        a = np.float64(0.0)
+        for v in sd.values():
+            s += np.asarray(v, dtype=np.float64).sum()
+            a += np.abs(np.asarray(v, dtype=np.float64)).sum()
+        out += [s, a]
+    return np.array(out, dtype=np.float64)
+
+
+# ----------------------------------------------------------------------------------------------
+# device blob
+# ----------------------------------------------------------------------------------------------
+# Every GEMM weight is kept [N, K] row-major with K contiguous (the nn.Linear layout), which is
+# what the fp32 MFMA GEMM kernel stages (csrc/gemm_f32.hip).  Conv weights [cout, cin, k] become
+# [cout, k*cin] (tap-major) so that an implicit-GEMM row is one contiguous window of the
+# channels-last activation.  LSTM gate rows are interleaved so that one 256-wide N tile holds all
+# four gates of 64 hidden units (csrc/lstm.hip).
+
+def _lstm_perm() -> np.ndarray:
+    """new row index r' = w*256 + g*64 + jj  <-  old row g*256 + w*64 + jj."""
+    perm = np.empty(LSTM_GATES, dtype=np.int64)
+    for w in range(4):
+        for g in range(4):
+            for jj in range(64):
+                perm[w * 256 + g * 64 + jj] = g * 256 + w * 64 + jj
+    return perm
+
+
+def blob_entries(K: int, mode: str) -> List[Tuple[str, int]]:
+    """Ordered (name, n_floats) table of the device blob.  Offsets are multiples of 64 floats."""
+    e: List[Tuple[str, int]] = []
+    e.append(("conv0.w", DIM * 10))          # [tap][cout]  (vector kernel, cout contiguous)
+    e.append(("conv0.b", DIM))
+    e.append(("cn0.g", DIM)); e.append(("cn0.b", DIM))
+    for i, k in zip((1, 2, 3, 4), (8, 4, 4, 4)):
+        e.append((f"conv{i}.w", DIM * k * DIM))  # [cout][tap*256+cin]
+        e.append((f"conv{i}.b", DIM))
+        e.append((f"cn{i}.g", DIM)); e.append((f"cn{i}.b", DIM))
+    e.append(("lstm.w", LSTM_GATES * 2 * DIM))   # [perm row][ Wih(256) | Whh(256) ]
+    e.append(("lstm.b", LSTM_GATES))             # b_ih + b_hh, permuted
+    e.append(("down.w", DIM * K * DIM))          # [cout][k*256+cin]
+    e.append(("down.b", DIM)); e.append(("down.g", DIM)); e.append(("down.beta", DIM))
+    for l in range(4):
+        p = f"L{l}"
+        e.append((f"{p}.ln_self.g", DIM)); e.append((f"{p}.ln_self.b", DIM))
+        e.append((f"{p}.wqkv", 3 * DIM * DIM))     # [Wq;Wk;Wv]  [768][256]
+        e.append((f"{p}.wproj", DIM * DIM))
+        if l > 0:
+            e.append((f"{p}.ln_src.g", DIM)); e.append((f"{p}.ln_src.b", DIM))
+            e.append((f"{p}.wq_x", DIM * DIM))
+            e.append((f"{p}.wkv_x", 2 * DIM * DIM))  # [Wk;Wv] [512][256]
+            e.append((f"{p}.wproj_x", DIM * DIM))
+        e.append((f"{p}.ln_ffn.g", DIM)); e.append((f"{p}.ln_ffn.b", DIM))
+        e.append((f"{p}.w0", FFN * DIM))
+        e.append((f"{p}.w3", DIM * FFN))
+    e.append(("comb.wa", DIM * DIM)); e.append(("comb.wb", DIM * DIM))
+    e.append(("comb.g", DIM)); e.append(("comb.b", DIM))
+    e.append(("head.w", N_CLASSES * DIM)); e.append(("head.b", N_CLASSES))
+    e.append(("vad.w", DIM)); e.append(("vad.b", 64))
+    # auxiliary heads (bc: 3 rows, nod: 4 rows + 1 row); always present, zero when unused
+    e.append(("aux.w", 8 * DIM)); e.append(("aux.b", 64))
+    return e
+
+
+def blob_layout(K: int, mode: str = "vap") -> "OrderedDict[str, Tuple[int, int]]":
+    off = 0
+    lay: "OrderedDict[str, Tuple[int, int]]" = OrderedDict()
+    for name, n in blob_entries(K, mode):
+        lay[name] = (off, n)
+        off += (n + 63) // 64 * 64
+    lay["__total__"] = (off, 0)
+    return lay
+
+
+def pack_blob(cpc_sd: Dict[str, np.ndarray], vap_sd: Dict[str, np.ndarray], mode: str = "vap") -> np.ndarray:
+    """Re-lay reference-named tensors into the device blob (float32, 1-D)."""
+    def A(x):
+        return np.asarray(x.detach().cpu().numpy() if hasattr(x, "detach") else x, dtype=np.float32)
+
+    K = A(vap_sd["encoder.downsample.1.weight"]).shape[2]
+    lay = blob_layout(K, mode)
+    blob = np.zeros(lay["__total__"][0], dtype=np.float32)
+
+    def put(name, arr):
+        off, n = lay[name]
+        arr = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)
+        assert arr.size <= n, (name, arr.size, n)
+        blob[off:off + arr.size] = arr
+
+    w0 = A(cpc_sd["gEncoder.conv0.weight"])            # [256,1,10]
+    put("conv0.w", w0[:, 0, :].T)                       # [10][256]
+    put("conv0.b", A(cpc_sd["gEncoder.conv0.bias"]))
+    put("cn0.g", A(cpc_sd["gEncoder.batchNorm0.weight"]))
+    put("cn0.b", A(cpc_sd["gEncoder.batchNorm0.bias"]))
+    for i in (1, 2, 3, 4):
+        w = A(cpc_sd[f"gEncoder.conv{i}.weight"])       # [cout, cin, k]
+        put(f"conv{i}.w", w.transpose(0, 2, 1))          # [cout][k][cin]
+        put(f"conv{i}.b", A(cpc_sd[f"gEncoder.conv{i}.bias"]))
+        put(f"cn{i}.g", A(cpc_sd[f"gEncoder.batchNorm{i}.weight"]))
+        put(f"cn{i}.b", A(cpc_sd[f"gEncoder.batchNorm{i}.bias"]))
+    perm = _lstm_perm()
+    wih = A(cpc_sd["gAR.baseNet.weight_ih_l0"])[perm]
+    whh = A(cpc_sd["gAR.baseNet.weight_hh_l0"])[perm]
+    put("lstm.w", np.concatenate([wih, whh], axis=1))    # [1024][512]
+    put("lstm.b", (A(cpc_sd["gAR.baseNet.bias_ih_l0"]) + A(cpc_sd["gAR.baseNet.bias_hh_l0"]))[perm])
+    wd = A(vap_sd["encoder.downsample.1.weight"])        # [cout, cin, K]
+    put("down.w", wd.transpose(0, 2, 1))
+    put("down.b", A(vap_sd["encoder.downsample.1.bias"]))
+    put("down.g", A(vap_sd["encoder.downsample.2.ln.weight"]))
+    put("down.beta", A(vap_sd["encoder.downsample.2.ln.bias"]))
+    for l in range(4):
+        src = "ar_channel.layers.0" if l == 0 else f"ar.layers.{l - 1}"
+        p = f"L{l}"
+        put(f"{p}.ln_self.g", A(vap_sd[f"{src}.ln_self_attn.weight"]))
+        put(f"{p}.ln_self.b", A(vap_sd[f"{src}.ln_self_attn.bias"]))
+        put(f"{p}.wqkv", np.concatenate([A(vap_sd[f"{src}.mha.query.weight"]),
+                                          A(vap_sd[f"{src}.mha.key.weight"]),
+                                          A(vap_sd[f"{src}.mha.value.weight"])], axis=0))
+        put(f"{p}.wproj", A(vap_sd[f"{src}.mha.proj.weight"]))
+        if l > 0:
+            put(f"{p}.ln_src.g", A(vap_sd[f"{src}.ln_src_attn.weight"]))
+            put(f"{p}.ln_src.b", A(vap_sd[f"{src}.ln_src_attn.bias"]))
+            put(f"{p}.wq_x", A(vap_sd[f"{src}.mha_cross.query.weight"]))
+            put(f"{p}.wkv_x", np.concatenate([A(vap_sd[f"{src}.mha_cross.key.weight"]),
+                                               A(vap_sd[f"{src}.mha_cross.value.weight"])], axis=0))
+            put(f"{p}.wproj_x", A(vap_sd[f"{src}.mha_cross.proj.weight"]))
+        put(f"{p}.ln_ffn.g", A(vap_sd[f"{src}.ln_ffnetwork.weight"]))
+        put(f"{p}.ln_ffn.b", A(vap_sd[f"{src}.ln_ffnetwork.bias"]))
+        put(f"{p}.w0", A(vap_sd[f"{src}.ffnetwork.0.weight"]))
+        put(f"{p}.w3", A(vap_sd[f"{src}.ffnetwork.3.weight"]))
+    put("comb.wa", A(vap_sd["ar.combinator.h0_a.weight"]))
+    put("comb.wb", A(vap_sd["ar.combinator.h0_b.weight"]))
+    put("comb.g", A(vap_sd["ar.combinator.ln.weight"]))
+    put("comb.b", A(vap_sd["ar.combinator.ln.bias"]))
+    if "vap_head.weight" in vap_sd:
+        put("head.w", A(vap_sd["vap_head.weight"]))
+        put("head.b", A(vap_sd["vap_head.bias"]))
+    put("vad.w", A(vap_sd["va_classifier.weight"]))
+    put("vad.b", A(vap_sd["va_classifier.bias"]))
+    if mode == "bc":
+        put("aux.w", A(vap_sd["bc_head.weight"]))                       # rows 0..2
+        put("aux.b", A(vap_sd["bc_head.bias"]))
+    elif mode == "nod":
+        aw = np.zeros((8, DIM), np.float32)
+        ab = np.zeros(64, np.float32)
+        aw[0:4] = A(vap_sd["nod_head.weight"]); ab[0:4] = A(vap_sd["nod_head.bias"])
+        aw[4:5] = A(vap_sd["bc_head.weight"]); ab[4:5] = A(vap_sd["bc_head.bias"])
+        put("aux.w", aw); put("aux.b", ab)
+    return blob
+
+
+def write_layout_header(path: str, K_values=(2, 5, 10, 20)) -> None:
+    """Generate csrc/vapx_layout.h: blob offsets as functions of K (only down.w depends on K)."""
+    lines = ["// GENERATED by vap-realtime_amd/weights.py:write_layout_header — do not edit.",
+             "#pragma once", "#include <stddef.h>", "namespace vapx_layout {",
+             "struct Entry { const char* name; size_t off; size_t n; };"]
+    for K in K_values:
+        lay = blob_layout(K)
+        lines.append(f"static const Entry kLayoutK{K}[] = {{")
+        for name, (off, n) in lay.items():
+            lines.append(f'  {{"{name}", {off}u, {n}u}},')
+        lines.append("};")
+    lines.append("inline const Entry* layout_for_K(int K, size_t* count) {")
+    for K in K_values:
+        lines.append(f"  if (K == {K}) {{ *count = sizeof(kLayoutK{K})/sizeof(Entry); return kLayoutK{K}; }}")
+    lines.append("  *count = 0; return nullptr; }")
+    lines.append("}  // namespace vapx_layout")
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
