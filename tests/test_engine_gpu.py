@@ -1,0 +1,128 @@
+"""Parity of the HIP path (through the C ABI) against the golden vectors of the imported reference
+and against the oracle, on the GPU.  Tolerance: 1e-4 abs on p_now / p_future / VAD / logits
+(BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from golden_util import Case
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def make_engine(case, max_streams=None, **kw):
+    from vap_realtime_amd import engine, weights as W
+    blob = W.pack_blob(case.cpc_sd, case.vap_sd, case.mode)
+    S = max_streams or len(case.streams)
+    return engine.Engine(blob, case.frame_hz, case.ctx_sec, max_streams=S, mode=case.mode, **kw)
+
+
+def run_engine(case, eng, ids=None):
+    from vap_realtime_amd.engine import split_outputs
+    outs = []
+    for f in range(case.n_frames):
+        audio = case.new_samples(f) if case.framing == "server" else case.window(f)
+        outs.append(split_outputs(eng.step(audio, ids)))
+    return outs
+
+
+@pytest.mark.parametrize("name", ["vap20", "offline20", "vap10", "multi3", "vap50"])
+def test_step_matches_reference_golden(name):
+    c = Case(name)
+    eng = make_engine(c)
+    outs = run_engine(c, eng)
+    z = c.z
+    es = int(z["meta.e_stride"]) if "meta.e_stride" in z.files else 1
+    worst = {}
+    for f, o in enumerate(outs):
+        assert np.all(o["n"] == min(f + 1, c.T))
+        for k in ("p_now", "p_future", "vad", "logits"):
+            d = float(np.abs(o[k] - z[k][f]).max())
+            worst[k] = max(worst.get(k, 0.0), d)
+        if f % es == 0:
+            worst["e"] = max(worst.get("e", 0.0), float(np.abs(o["e"] - z["e"][f // es]).max()))
+    print(name, worst)
+    for k, v in worst.items():
+        assert v <= TOL, (name, k, v)
+    eng.close()
+
+
+def test_intermediates_match_reference():
+    """Per-stage buffers of selected frames (CNN, LSTM, each transformer layer) vs hooks on the
+    reference modules."""
+    c = Case("vap20")
+    eng = make_engine(c)
+    z = c.z
+    inter_frames = sorted({int(k.split(".")[1][1:]) for k in z.files if k.startswith("inter.f")})
+    for f in range(max(inter_frames) + 1):
+        eng.step(c.new_samples(f))
+        if f not in inter_frames:
+            continue
+        ncpc = 5
+        zbuf = eng.peek("z", (2, ncpc, 256))
+        cnn4 = z[f"inter.f{f}.cnn4"]                       # [256, 7] channel-1
+        np.testing.assert_allclose(zbuf[0], cnn4[:, 1:-1].T, rtol=0, atol=2e-5)
+        lo = eng.peek("lstm_out", (2, ncpc, 256))
+        np.testing.assert_allclose(lo, z[f"inter.f{f}.lstm_out"], rtol=0, atol=2e-5)
+        rows = z[f"inter.f{f}.rows"]
+        for key, buf in (("o", "o"), ("stereo0", "stereo0"), ("stereo1", "stereo1"), ("stereo2", "stereo2")):
+            got = eng.peek(buf, (2, c.T, 256))[:, rows]
+            want = z[f"inter.f{f}.{key}"]
+            np.testing.assert_allclose(got, want, rtol=3e-5, atol=1e-3, err_msg=f"frame {f} {key}")
+    eng.close()
+
+
+def test_engine_equals_oracle_on_fresh_inputs():
+    """Seeded inputs that are NOT in the golden set: HIP path vs oracle, 3 streams, ragged ids."""
+    from oracle.vap_oracle import ServerFramer, VapOracle
+    from vap_realtime_amd import engine, synth, weights as W
+    cpc, vap = W.synthetic_weights(21, 20, "vap")
+    o = VapOracle(cpc, vap, 20, 2.5)
+    S, F_ = 3, 54
+    audio = synth.dialogue_batch([40, 41, 42], 800 * F_)
+    st, fr = o.new_state(S), ServerFramer(S, 800)
+    eng = engine.Engine(W.pack_blob(cpc, vap), 20, 2.5, max_streams=8, max_batch=4)
+    ids = [5, 0, 7]
+    for f in range(F_):
+        new = audio[:, :, f * 800:(f + 1) * 800]
+        want = o.step(fr.frame(new), st)
+        got = engine.split_outputs(eng.step(new, ids))
+        for k in ("p_now", "p_future", "vad", "logits"):
+            np.testing.assert_allclose(got[k], want[k], rtol=0, atol=TOL, err_msg=f"frame {f} {k}")
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["bc20", "nod20"])
+def test_aux_heads(name):
+    c = Case(name)
+    eng = make_engine(c)
+    outs = run_engine(c, eng)
+    for f, o in enumerate(outs):
+        if name == "bc20":
+            np.testing.assert_allclose(o["aux"][:, 1], c.z["p_bc_react"][f].reshape(-1), rtol=0, atol=TOL)
+            np.testing.assert_allclose(o["aux"][:, 2], c.z["p_bc_emo"][f].reshape(-1), rtol=0, atol=TOL)
+        else:
+            np.testing.assert_allclose(o["aux"][:, 1], c.z["p_nod_short"][f].reshape(-1), rtol=0, atol=TOL)
+            np.testing.assert_allclose(o["aux"][:, 2], c.z["p_nod_long"][f].reshape(-1), rtol=0, atol=TOL)
+            np.testing.assert_allclose(o["aux"][:, 3], c.z["p_nod_long_p"][f].reshape(-1), rtol=0, atol=TOL)
+    eng.close()
+
+
+def test_state_roundtrip_and_reset():
+    """get_state -> set_state into another slot reproduces the stream; reset == fresh stream."""
+    from vap_realtime_amd.engine import split_outputs
+    c = Case("vap20")
+    eng = make_engine(c, max_streams=3)
+    for f in range(53):
+        eng.step(c.new_samples(f), [0])
+    st = eng.get_state(0)
+    assert st["n_frames"] == c.T
+    eng.set_state(2, st)
+    a = split_outputs(eng.step(c.new_samples(53), [0]))
+    b = split_outputs(eng.step(c.new_samples(53), [2]))
+    np.testing.assert_allclose(a["logits"], b["logits"], rtol=0, atol=1e-5)
+    eng.reset_stream(0)
+    fresh = split_outputs(eng.step(c.new_samples(0), [0]))
+    np.testing.assert_allclose(fresh["logits"], c.z["logits"][0], rtol=0, atol=TOL)
+    eng.close()

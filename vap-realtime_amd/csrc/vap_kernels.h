@@ -1,0 +1,79 @@
+// Argument blocks + launchers of the non-GEMM kernels (see vap_kernels.hip).
+#pragma once
+#include "common.h"
+
+struct Conv0Args {
+  const float* audio;   // [B][2][spc]
+  const int* ids;       // [B] stream ids (device) or null = identity
+  float* carry;         // [S][2][320] or null (stage API: frames carry their own context)
+  float* h0;            // [B*2][P0+4][256] channels-last, 2 zero guard rows each side
+  const float* w;       // [10][256]
+  const float* bias;    // [256]
+  const float* gamma;   // [256]
+  const float* beta;    // [256]
+  int* frames_seen;     // [S] or null
+  int* bn;              // [B] out: rows in the window this frame
+  int* bhead;           // [B] out: ring slot the new embedding goes to
+  int L, spc, T;
+};
+
+struct LstmArgs {
+  const float* z;       // [M][ncpc][256]
+  const int* ids;       // [M/2] or null
+  float* h_state;       // [S*2][256]
+  float* c_state;       // [S*2][256]
+  const float* wfrag;   // fragment-major [4 w][64 kc][8 ns][64 lane][4]
+  const float* bias;    // [1024] permuted, b_ih + b_hh
+  float* out;           // [M][ncpc][256]
+  int M, ncpc;
+};
+
+struct GatherArgs {
+  float* ring;          // [S*2][T][256] or null (then xin is used)
+  const float* e;       // [B*2][256] this frame's embeddings
+  const float* xin;     // [B*2][rows_in][256] explicit context (stage API)
+  const int* ids;
+  const int* bn;
+  const int* bhead;
+  float* x0;            // [B*2][T][256] chronological, zero beyond n
+  float* xn;            // LayerNorm(x0; gamma, beta)
+  const float* gamma;
+  const float* beta;
+  int B, T, rows_in;
+};
+
+struct AttnArgs {
+  const float* q;       // row (bc*T + i), stride ldq, head h at column h*64
+  const float* k;
+  const float* v;       // rows of channel (bc ^ swap_kv), stride ldkv
+  float* out;           // [B*2*T][256]
+  const int* bn;
+  int T, ldq, ldkv, swap_kv;
+};
+
+struct HeadArgs {
+  const float* x;       // [B*2][T][256] stereo tower outputs (a = ch 0, b = ch 1)
+  const float* o;       // [B*2][T][256] ar_channel outputs
+  const float* e;       // [B*2][256]
+  const int* bn;
+  const int* ids;
+  int* frames_seen;     // incremented when non-null
+  const float* waT;     // [256 k][256 j]
+  const float* wbT;
+  const float* cg;
+  const float* cb;
+  const float* hwT;     // [256 k][256 j]
+  const float* hb;
+  const float* vw;      // [256]
+  const float* vb;      // [1]
+  const float* aw;      // [8][256]
+  const float* ab;      // [8]
+  float* out;           // [B][out_stride]
+  int B, T, mode, out_stride;
+};
+
+hipError_t launch_conv0(const Conv0Args& a, int B, hipStream_t st);
+hipError_t launch_lstm(const LstmArgs& a, hipStream_t st);
+hipError_t launch_gather_ln(const GatherArgs& a, hipStream_t st);
+hipError_t launch_attention(const AttnArgs& a, int B, hipStream_t st);
+hipError_t launch_head(const HeadArgs& a, hipStream_t st);

@@ -1,0 +1,193 @@
+"""ctypes binding of libvapx.so (include/vapx.h) — the only way Python reaches the HIP path.
+
+There is deliberately NO fallback: if the shared library is missing, was built for another
+architecture, or no gfx950 device is visible, construction raises.  PyTorch is used only as the
+owner of device buffers / HIP streams whose raw pointers are handed to the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvapx.so")
+
+OUT_STRIDE = 784
+OUT_P_NOW, OUT_P_FUTURE, OUT_VAD, OUT_AUX, OUT_NVALID, OUT_LOGITS, OUT_E = 0, 2, 4, 6, 10, 16, 272
+AUDIO_DEVICE, OUT_DEVICE, IDS_DEVICE = 1, 2, 4
+MODE = {"vap": 0, "bc": 1, "nod": 2}
+
+EXPORTS = ("vapx_abi_version", "vapx_blob_floats", "vapx_create", "vapx_destroy", "vapx_step",
+           "vapx_reset_stream", "vapx_get_state", "vapx_set_state", "vapx_encode_audio",
+           "vapx_transformer", "vapx_peek", "vapx_gemm", "vapx_last_error")
+
+
+class VapxError(RuntimeError):
+    pass
+
+
+class _Config(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("device_id", C.c_int32), ("frame_hz", C.c_int32),
+                ("ctx_frames", C.c_int32), ("max_streams", C.c_int32), ("max_batch", C.c_int32),
+                ("mode", C.c_int32), ("flags", C.c_int32)]
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen libvapx.so and declare prototypes.  Import torch first when it is going to be used in
+    the same process so both share one HIP runtime (same SONAME libamdhip64.so.7)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise VapxError(f"{p} not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        f"(or `make -C vap-realtime_amd/csrc`). There is no CPU fallback.")
+    try:
+        import torch  # noqa: F401  (loads torch's bundled libamdhip64 first when torch is installed)
+    except Exception:  # pragma: no cover
+        pass
+    lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    vp, i32, f32p, i32p = C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p
+    lib.vapx_abi_version.restype = i32
+    lib.vapx_blob_floats.restype = C.c_size_t
+    lib.vapx_blob_floats.argtypes = [i32]
+    lib.vapx_create.restype = i32
+    lib.vapx_create.argtypes = [C.POINTER(_Config), f32p, C.c_size_t, C.POINTER(vp)]
+    lib.vapx_destroy.restype = None
+    lib.vapx_destroy.argtypes = [vp]
+    lib.vapx_step.restype = i32
+    lib.vapx_step.argtypes = [vp, i32, i32p, f32p, i32, f32p, i32, vp]
+    lib.vapx_reset_stream.restype = i32
+    lib.vapx_reset_stream.argtypes = [vp, i32]
+    lib.vapx_get_state.restype = i32
+    lib.vapx_get_state.argtypes = [vp, i32, f32p, C.POINTER(i32), f32p, f32p]
+    lib.vapx_set_state.restype = i32
+    lib.vapx_set_state.argtypes = [vp, i32, f32p, i32, f32p, f32p]
+    lib.vapx_encode_audio.restype = i32
+    lib.vapx_encode_audio.argtypes = [vp, i32, i32p, f32p, f32p, vp]
+    lib.vapx_transformer.restype = i32
+    lib.vapx_transformer.argtypes = [vp, i32, i32, f32p, f32p, f32p, f32p, vp]
+    lib.vapx_peek.restype = C.c_int64
+    lib.vapx_peek.argtypes = [vp, C.c_char_p, f32p, C.c_size_t]
+    lib.vapx_gemm.restype = i32
+    lib.vapx_gemm.argtypes = [vp, i32, i32, i32, f32p, f32p, f32p, i32, f32p, f32p, f32p, f32p, f32p, i32]
+    lib.vapx_last_error.restype = C.c_char_p
+    lib.vapx_last_error.argtypes = [vp]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _np_ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One engine = one GPU: device weights + state of ``max_streams`` dialogue streams.
+
+    Mirrors ``VAPRealTime(vap_model, cpc_model, device, frame_rate, context_len_sec)``
+    (rvap/vap_main/vap_main.py:192-247) with the weights given as a packed blob
+    (``weights.pack_blob``)."""
+
+    def __init__(self, blob: np.ndarray, frame_hz: int = 20, context_len_sec: float = 2.5,
+                 max_streams: int = 1, max_batch: Optional[int] = None, mode: str = "vap", device_id: int = 0):
+        self.lib = load_library()
+        self.frame_hz = frame_hz
+        self.T = int(context_len_sec * frame_hz)           # vap_main.py:221
+        self.hop = 16000 // frame_hz
+        self.L = self.hop + 320                             # vap_main.py:230
+        self.max_streams = max_streams
+        self.max_batch = max_batch or max_streams
+        self.mode = mode
+        self.device_id = device_id
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        cfg = _Config(C.sizeof(_Config), device_id, frame_hz, self.T, max_streams, self.max_batch, MODE[mode], 0)
+        h = C.c_void_p()
+        rc = self.lib.vapx_create(C.byref(cfg), _np_ptr(blob), blob.size, C.byref(h))
+        if rc != 0:
+            raise VapxError(f"vapx_create failed ({rc}): {self.lib.vapx_last_error(None).decode()}")
+        self._h = h
+
+    # -- lifecycle -------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.vapx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc < 0:
+            raise VapxError(f"{what} failed ({rc}): {self.lib.vapx_last_error(self._h).decode()}")
+        return rc
+
+    # -- the step --------------------------------------------------------------------------------
+    def step(self, audio: np.ndarray, stream_ids: Optional[Sequence[int]] = None) -> np.ndarray:
+        """Host path.  audio: float [n,2,hop] (new samples; engine keeps the carry) or [n,2,hop+320]
+        (complete frames as ``process_vap`` receives them).  Returns float32 [n, OUT_STRIDE]."""
+        audio = np.ascontiguousarray(audio, dtype=np.float32)
+        n, two, spc = audio.shape
+        assert two == 2
+        ids = None if stream_ids is None else np.ascontiguousarray(stream_ids, dtype=np.int32)
+        if ids is not None:
+            assert ids.shape == (n,)
+        out = np.empty((n, OUT_STRIDE), dtype=np.float32)
+        self._check(self.lib.vapx_step(self._h, n, _np_ptr(ids), _np_ptr(audio), spc, _np_ptr(out), 0, None), "vapx_step")
+        return out
+
+    def step_device(self, n: int, audio_ptr: int, spc: int, out_ptr: int, ids_ptr: int = 0, stream: int = 0):
+        """Device path: raw device pointers (e.g. ``tensor.data_ptr()``), work enqueued on ``stream``
+        (a hipStream_t as int, 0 = default); returns immediately."""
+        flags = AUDIO_DEVICE | OUT_DEVICE | (IDS_DEVICE if ids_ptr else 0)
+        self._check(self.lib.vapx_step(self._h, n, ids_ptr or None, audio_ptr, spc, out_ptr, flags, stream or None), "vapx_step")
+
+    def reset_stream(self, sid: int):
+        self._check(self.lib.vapx_reset_stream(self._h, sid), "vapx_reset_stream")
+
+    def get_state(self, sid: int):
+        ring = np.zeros((2, self.T, 256), np.float32)
+        lstm = np.zeros((2, 2, 256), np.float32)
+        carry = np.zeros((2, 320), np.float32)
+        n = C.c_int32(0)
+        self._check(self.lib.vapx_get_state(self._h, sid, _np_ptr(ring), C.byref(n), _np_ptr(lstm), _np_ptr(carry)), "vapx_get_state")
+        return {"ring": ring, "n_frames": n.value, "lstm": lstm, "carry": carry}
+
+    def set_state(self, sid: int, state: dict):
+        ring = np.ascontiguousarray(state["ring"], np.float32)
+        lstm = np.ascontiguousarray(state["lstm"], np.float32)
+        carry = np.ascontiguousarray(state["carry"], np.float32)
+        self._check(self.lib.vapx_set_state(self._h, sid, _np_ptr(ring), int(state["n_frames"]), _np_ptr(lstm), _np_ptr(carry)), "vapx_set_state")
+
+    def peek(self, name: str, shape) -> np.ndarray:
+        buf = np.empty(int(np.prod(shape)), np.float32)
+        got = self._check(self.lib.vapx_peek(self._h, name.encode(), _np_ptr(buf), buf.size), "vapx_peek")
+        assert got == buf.size, (name, got, buf.size)
+        return buf.reshape(shape)
+
+    # -- stage-level (device pointers) -------------------------------------------------------------
+    def encode_audio_device(self, n: int, frames_ptr: int, e_ptr: int, stream_ids=None, stream: int = 0):
+        ids = None if stream_ids is None else np.ascontiguousarray(stream_ids, dtype=np.int32)
+        self._check(self.lib.vapx_encode_audio(self._h, n, _np_ptr(ids), frames_ptr, e_ptr, stream or None), "vapx_encode_audio")
+
+    def transformer_device(self, n: int, rows: int, x_ptr: int, o_ptr: int = 0, x12_ptr: int = 0, comb_ptr: int = 0, stream: int = 0):
+        self._check(self.lib.vapx_transformer(self._h, n, rows, x_ptr, o_ptr or None, x12_ptr or None, comb_ptr or None, stream or None), "vapx_transformer")
+
+
+def split_outputs(out: np.ndarray) -> dict:
+    """Name the columns of a vapx_step output block."""
+    return {
+        "p_now": out[:, OUT_P_NOW:OUT_P_NOW + 2], "p_future": out[:, OUT_P_FUTURE:OUT_P_FUTURE + 2],
+        "vad": out[:, OUT_VAD:OUT_VAD + 2], "aux": out[:, OUT_AUX:OUT_AUX + 4],
+        "n": out[:, OUT_NVALID].astype(np.int32), "logits": out[:, OUT_LOGITS:OUT_LOGITS + 256],
+        "e": out[:, OUT_E:OUT_E + 512].reshape(-1, 2, 256),
+    }

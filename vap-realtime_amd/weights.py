@@ -216,7 +216,7 @@ def blob_entries(K: int, mode: str) -> List[Tuple[str, int]]:
         e.append((f"conv{i}.w", DIM * k * DIM))  # [cout][tap*256+cin]
         e.append((f"conv{i}.b", DIM))
         e.append((f"cn{i}.g", DIM)); e.append((f"cn{i}.b", DIM))
-    e.append(("lstm.w", LSTM_GATES * 2 * DIM))   # [perm row][ Wih(256) | Whh(256) ]
+    e.append(("lstm.w", LSTM_GATES * 2 * DIM))   # MFMA-fragment-major [4 w][64 kc][8 ns][64 lane][4]
     e.append(("lstm.b", LSTM_GATES))             # b_ih + b_hh, permuted
     e.append(("down.w", DIM * K * DIM))          # [cout][k*256+cin]
     e.append(("down.b", DIM)); e.append(("down.g", DIM)); e.append(("down.beta", DIM))
@@ -233,9 +233,10 @@ def blob_entries(K: int, mode: str) -> List[Tuple[str, int]]:
         e.append((f"{p}.ln_ffn.g", DIM)); e.append((f"{p}.ln_ffn.b", DIM))
         e.append((f"{p}.w0", FFN * DIM))
         e.append((f"{p}.w3", DIM * FFN))
-    e.append(("comb.wa", DIM * DIM)); e.append(("comb.wb", DIM * DIM))
+    e.append(("comb.wa", DIM * DIM)); e.append(("comb.wb", DIM * DIM))      # [N][K] (GEMM path)
+    e.append(("comb.waT", DIM * DIM)); e.append(("comb.wbT", DIM * DIM))    # [K][N] (head kernel)
     e.append(("comb.g", DIM)); e.append(("comb.b", DIM))
-    e.append(("head.w", N_CLASSES * DIM)); e.append(("head.b", N_CLASSES))
+    e.append(("head.wT", N_CLASSES * DIM)); e.append(("head.b", N_CLASSES))  # [K][N]
     e.append(("vad.w", DIM)); e.append(("vad.b", 64))
     # auxiliary heads (bc: 3 rows, nod: 4 rows + 1 row); always present, zero when unused
     e.append(("aux.w", 8 * DIM)); e.append(("aux.b", 64))
@@ -281,7 +282,9 @@ def pack_blob(cpc_sd: Dict[str, np.ndarray], vap_sd: Dict[str, np.ndarray], mode
     perm = _lstm_perm()
     wih = A(cpc_sd["gAR.baseNet.weight_ih_l0"])[perm]
     whh = A(cpc_sd["gAR.baseNet.weight_hh_l0"])[perm]
-    put("lstm.w", np.concatenate([wih, whh], axis=1))    # [1024][512]
+    wcat = np.concatenate([wih, whh], axis=1)            # [1024 permuted rows][512]
+    # row = w*256 + ns*32 + l31 ; k = kc*8 + kh*4 + u  ->  [w][kc][ns][lane = kh*32 + l31][u]
+    put("lstm.w", wcat.reshape(4, 8, 32, 64, 2, 4).transpose(0, 3, 1, 4, 2, 5))
     put("lstm.b", (A(cpc_sd["gAR.baseNet.bias_ih_l0"]) + A(cpc_sd["gAR.baseNet.bias_hh_l0"]))[perm])
     wd = A(vap_sd["encoder.downsample.1.weight"])        # [cout, cin, K]
     put("down.w", wd.transpose(0, 2, 1))
@@ -291,6 +294,9 @@ def pack_blob(cpc_sd: Dict[str, np.ndarray], vap_sd: Dict[str, np.ndarray], mode
     for l in range(4):
         src = "ar_channel.layers.0" if l == 0 else f"ar.layers.{l - 1}"
         p = f"L{l}"
+        for mk in (f"{src}.mha.m", f"{src}.mha_cross.m"):
+            if mk in vap_sd and not np.allclose(A(vap_sd[mk]), alibi_slopes(), rtol=1e-6):
+                raise ValueError(f"{mk}: ALiBi slopes differ from the 4-head constants the kernel hard-codes")
         put(f"{p}.ln_self.g", A(vap_sd[f"{src}.ln_self_attn.weight"]))
         put(f"{p}.ln_self.b", A(vap_sd[f"{src}.ln_self_attn.bias"]))
         put(f"{p}.wqkv", np.concatenate([A(vap_sd[f"{src}.mha.query.weight"]),
@@ -310,10 +316,12 @@ def pack_blob(cpc_sd: Dict[str, np.ndarray], vap_sd: Dict[str, np.ndarray], mode
         put(f"{p}.w3", A(vap_sd[f"{src}.ffnetwork.3.weight"]))
     put("comb.wa", A(vap_sd["ar.combinator.h0_a.weight"]))
     put("comb.wb", A(vap_sd["ar.combinator.h0_b.weight"]))
+    put("comb.waT", A(vap_sd["ar.combinator.h0_a.weight"]).T)
+    put("comb.wbT", A(vap_sd["ar.combinator.h0_b.weight"]).T)
     put("comb.g", A(vap_sd["ar.combinator.ln.weight"]))
     put("comb.b", A(vap_sd["ar.combinator.ln.bias"]))
     if "vap_head.weight" in vap_sd:
-        put("head.w", A(vap_sd["vap_head.weight"]))
+        put("head.wT", A(vap_sd["vap_head.weight"]).T)
         put("head.b", A(vap_sd["vap_head.bias"]))
     put("vad.w", A(vap_sd["va_classifier.weight"]))
     put("vad.b", A(vap_sd["va_classifier.bias"]))
