@@ -144,6 +144,15 @@ int vapx_gemm(void* hip_stream, int32_t M, int32_t N, int32_t K, const float* A,
               int32_t epi, const float* bias, const float* gamma, const float* beta, const float* resid,
               float* C2, int32_t tile_rows);
 
+/* Per-kernel-class timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+ * class ids: 0..5 = the GEMM by epilogue (same numbering as vapx_gemm's epi), 8 conv0, 9 lstm,
+ * 10 ring gather+LN, 11 attention, 12 heads.  enable(mask) selects classes (0 = off);
+ * read() synchronises the device, sums the elapsed time and launch count per class since the
+ * last read into total_ms[n_classes] / launches[n_classes], and recycles the events. */
+#define VAPX_PROF_CLASSES 13
+int vapx_profile_enable(vapx_handle h, uint32_t class_mask);
+int vapx_profile_read(vapx_handle h, double* total_ms, int64_t* launches, int32_t n_classes);
+
 const char* vapx_last_error(vapx_handle h);
 int32_t vapx_abi_version(void);
 

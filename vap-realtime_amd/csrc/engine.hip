@@ -54,6 +54,13 @@ struct vapx_engine {
   hipEvent_t ids_evt = nullptr;
   int last_B = 0;
 
+  // optional per-kernel-class HIP-event timing (vapx_profile_*): events are recorded on the launch
+  // stream around the launches whose class bit is set in prof_mask
+  uint32_t prof_mask = 0;
+  struct ProfRec { hipEvent_t a, b; int cls; };
+  std::vector<ProfRec> prof_recs;
+  std::vector<hipEvent_t> prof_pool;
+
   const float* W(const char* name) const {
     for (size_t i = 0; i < lay_n; ++i)
       if (!strcmp(lay[i].name, name)) return w + lay[i].off;
@@ -100,6 +107,34 @@ void geometry(int hz, int* hop, int* L, int P[5], int* ncpc) {
   *ncpc = P[4] - 2;
 }
 
+// kernel classes for profiling: 0..5 = GEMM by epilogue, then the rest
+enum { CLS_CONV0 = 8, CLS_LSTM = 9, CLS_GATHER = 10, CLS_ATTN = 11, CLS_HEAD = 12, CLS_COUNT = 13 };
+
+struct ProfScope {
+  vapx_engine* h; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; int cls;
+  ProfScope(vapx_engine* h_, int cls_, hipStream_t st_) : h(h_), st(st_), cls(cls_) {
+    if (!(h->prof_mask & (1u << cls))) return;
+    auto get = [&]() {
+      hipEvent_t e = nullptr;
+      if (!h->prof_pool.empty()) { e = h->prof_pool.back(); h->prof_pool.pop_back(); }
+      else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+      return e;
+    };
+    a = get(); b = get();
+    if (a) (void)hipEventRecord(a, st);
+  }
+  ~ProfScope() {
+    if (!a || !b) return;
+    (void)hipEventRecord(b, st);
+    h->prof_recs.push_back({a, b, cls});
+  }
+};
+
+hipError_t gemm(vapx_engine* h, const GemmArgs& g, int epi, hipStream_t st) {
+  ProfScope ps(h, epi, st);
+  return launch_gemm_f32(g, epi, 0, st);
+}
+
 GemmArgs gemm_args(const float* A, RowMap am, const float* W, int M, int N, int K, float* C, RowMap cm) {
   GemmArgs g;
   memset(&g, 0, sizeof g);
@@ -117,7 +152,7 @@ int run_encoder(vapx_engine* h, int B, const int* ids_dev, const float* audio, i
   c0.h0 = h->h0; c0.w = h->W("conv0.w"); c0.bias = h->W("conv0.b"); c0.gamma = h->W("cn0.g"); c0.beta = h->W("cn0.b");
   c0.frames_seen = use_state_meta ? h->frames_seen : nullptr; c0.bn = h->bn; c0.bhead = h->bhead;
   c0.L = h->L; c0.spc = spc; c0.T = h->T;
-  HIPCHK(h, launch_conv0(c0, B, st));
+  { ProfScope ps(h, CLS_CONV0, st); HIPCHK(h, launch_conv0(c0, B, st)); }
 
   struct ConvSpec { const float* in; int Pin, guard_in, k, s; float* out; int Pout, guard_out; const char* idx; };
   const ConvSpec cs[3] = {
@@ -135,23 +170,23 @@ int run_encoder(vapx_engine* h, int B, const int* ids_dev, const float* audio, i
     snprintf(nm, sizeof nm, "conv%s.b", c.idx); g.bias = h->W(nm);
     snprintf(nm, sizeof nm, "cn%s.g", c.idx); g.gamma = h->W(nm);
     snprintf(nm, sizeof nm, "cn%s.b", c.idx); g.beta = h->W(nm);
-    HIPCHK(h, launch_gemm_f32(g, EPI_CN_RELU, 0, st));
+    HIPCHK(h, gemm(h, g, EPI_CN_RELU, st));
   }
   {  // conv4: only positions 1..P4-2 survive z[:, 1:-1] (encoder.py:76)
     RowMap am{(long)(P[3] + 2) * 256, 2 * 256, h->ncpc};
     GemmArgs g = gemm_args(h->h3 + 2 * 256, am, h->W("conv4.w"), B * 2 * h->ncpc, 256, 4 * 256, h->z, contiguous_rows(256));
     g.bias = h->W("conv4.b"); g.gamma = h->W("cn4.g"); g.beta = h->W("cn4.b");
-    HIPCHK(h, launch_gemm_f32(g, EPI_CN_RELU, 0, st));
+    HIPCHK(h, gemm(h, g, EPI_CN_RELU, st));
   }
   LstmArgs la;
   la.z = h->z; la.ids = ids_dev; la.h_state = h->h_state; la.c_state = h->c_state;
   la.wfrag = h->W("lstm.w"); la.bias = h->W("lstm.b"); la.out = h->lstm_out; la.M = B * 2; la.ncpc = h->ncpc;
-  HIPCHK(h, launch_lstm(la, st));
+  { ProfScope ps(h, CLS_LSTM, st); HIPCHK(h, launch_lstm(la, st)); }
   {  // downsample: single-output Conv1d == dense [ncpc*256 -> 256] + LN + GELU
     GemmArgs g = gemm_args(h->lstm_out, contiguous_rows((long)h->ncpc * 256), h->W("down.w"), B * 2, 256, h->ncpc * 256,
                            h->e, contiguous_rows(256));
     g.bias = h->W("down.b"); g.gamma = h->W("down.g"); g.beta = h->W("down.beta");
-    HIPCHK(h, launch_gemm_f32(g, EPI_BIAS_LN_GELU, 0, st));
+    HIPCHK(h, gemm(h, g, EPI_BIAS_LN_GELU, st));
   }
   return VAPX_OK;
 }
@@ -167,36 +202,36 @@ int run_layers(vapx_engine* h, int B, hipStream_t st) {
     float* xout = h->xl[l + 1];
     // self attention
     GemmArgs g = gemm_args(h->xn, r256, Lw.wqkv, M, 768, 256, h->qkv, r768);
-    HIPCHK(h, launch_gemm_f32(g, EPI_STORE, 0, st));
+    HIPCHK(h, gemm(h, g, EPI_STORE, st));
     AttnArgs aa{h->qkv, h->qkv + 256, h->qkv + 512, h->att, h->bn, T, 768, 768, 0};
-    HIPCHK(h, launch_attention(aa, B, st));
+    { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attention(aa, B, st)); }
     g = gemm_args(h->att, r256, Lw.wproj, M, 256, 256, h->xmid, r256);
     g.resid = xin; g.C2 = h->xn;
     if (l == 0) { g.gamma = Lw.ln_ffn_g; g.beta = Lw.ln_ffn_b; }
     else { g.gamma = Lw.ln_src_g; g.beta = Lw.ln_src_b; }
-    HIPCHK(h, launch_gemm_f32(g, EPI_RESID_LN, 0, st));
+    HIPCHK(h, gemm(h, g, EPI_RESID_LN, st));
     if (l > 0) {
       // cross attention: Q from LN_src(x), K/V from the OTHER channel's raw layer input
       g = gemm_args(h->xn, r256, Lw.wq_x, M, 256, 256, h->qx, r256);
-      HIPCHK(h, launch_gemm_f32(g, EPI_STORE, 0, st));
+      HIPCHK(h, gemm(h, g, EPI_STORE, st));
       g = gemm_args(xin, r256, Lw.wkv_x, M, 512, 256, h->kvx, r512);
-      HIPCHK(h, launch_gemm_f32(g, EPI_STORE, 0, st));
+      HIPCHK(h, gemm(h, g, EPI_STORE, st));
       AttnArgs ax{h->qx, h->kvx, h->kvx + 256, h->att, h->bn, T, 256, 512, 1};
-      HIPCHK(h, launch_attention(ax, B, st));
+      { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attention(ax, B, st)); }
       g = gemm_args(h->att, r256, Lw.wproj_x, M, 256, 256, h->xmid, r256);
       g.resid = h->xmid; g.C2 = h->xn; g.gamma = Lw.ln_ffn_g; g.beta = Lw.ln_ffn_b;
-      HIPCHK(h, launch_gemm_f32(g, EPI_RESID_LN, 0, st));
+      HIPCHK(h, gemm(h, g, EPI_RESID_LN, st));
     }
     // feed-forward
     g = gemm_args(h->xn, r256, Lw.w0, M, 768, 256, h->ffn, r768);
-    HIPCHK(h, launch_gemm_f32(g, EPI_GELU, 0, st));
+    HIPCHK(h, gemm(h, g, EPI_GELU, st));
     g = gemm_args(h->ffn, r768, Lw.w3, M, 256, 768, xout, r256);
     g.resid = h->xmid;
     if (l < 3) {
       g.C2 = h->xn; g.gamma = h->layer[l + 1].ln_self_g; g.beta = h->layer[l + 1].ln_self_b;
-      HIPCHK(h, launch_gemm_f32(g, EPI_RESID_LN, 0, st));
+      HIPCHK(h, gemm(h, g, EPI_RESID_LN, st));
     } else {
-      HIPCHK(h, launch_gemm_f32(g, EPI_RESID, 0, st));
+      HIPCHK(h, gemm(h, g, EPI_RESID, st));
     }
   }
   return VAPX_OK;
@@ -267,6 +302,8 @@ void vapx_destroy(vapx_handle h) {
   if (h->out_pinned) (void)hipHostFree(h->out_pinned);
   if (h->ids_pinned) (void)hipHostFree(h->ids_pinned);
   if (h->ids_evt) (void)hipEventDestroy(h->ids_evt);
+  for (auto& r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (auto e : h->prof_pool) (void)hipEventDestroy(e);
   delete h;
 }
 
@@ -380,7 +417,7 @@ int vapx_step(vapx_handle h, int32_t n, const int32_t* stream_ids, const float* 
   ga.ring = h->ring; ga.e = h->e; ga.xin = nullptr; ga.ids = ids; ga.bn = h->bn; ga.bhead = h->bhead;
   ga.x0 = h->xl[0]; ga.xn = h->xn; ga.gamma = h->layer[0].ln_self_g; ga.beta = h->layer[0].ln_self_b;
   ga.B = n; ga.T = h->T; ga.rows_in = 0;
-  HIPCHK(h, launch_gather_ln(ga, st));
+  { ProfScope ps(h, CLS_GATHER, st); HIPCHK(h, launch_gather_ln(ga, st)); }
   rc = run_layers(h, n, st);
   if (rc) return rc;
   float* od = (flags & VAPX_OUT_DEVICE) ? out : h->out_dev;
@@ -390,7 +427,7 @@ int vapx_step(vapx_handle h, int32_t n, const int32_t* stream_ids, const float* 
   ha.hwT = h->W("head.wT"); ha.hb = h->W("head.b"); ha.vw = h->W("vad.w"); ha.vb = h->W("vad.b");
   ha.aw = h->W("aux.w"); ha.ab = h->W("aux.b"); ha.out = od; ha.B = n; ha.T = h->T; ha.mode = h->cfg.mode;
   ha.out_stride = VAPX_OUT_STRIDE;
-  HIPCHK(h, launch_head(ha, st));
+  { ProfScope ps(h, CLS_HEAD, st); HIPCHK(h, launch_head(ha, st)); }
   h->last_B = n;
   if (!(flags & VAPX_OUT_DEVICE)) {
     HIPCHK(h, hipMemcpyAsync(h->out_pinned, h->out_dev, (size_t)n * VAPX_OUT_STRIDE * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -492,7 +529,7 @@ int vapx_transformer(vapx_handle h, int32_t n, int32_t rows, const float* x, flo
   ga.ring = nullptr; ga.e = nullptr; ga.xin = x; ga.ids = nullptr; ga.bn = h->bn; ga.bhead = h->bhead;
   ga.x0 = h->xl[0]; ga.xn = h->xn; ga.gamma = h->layer[0].ln_self_g; ga.beta = h->layer[0].ln_self_b;
   ga.B = n; ga.T = T; ga.rows_in = rows;
-  HIPCHK(h, launch_gather_ln(ga, st));
+  { ProfScope ps(h, CLS_GATHER, st); HIPCHK(h, launch_gather_ln(ga, st)); }
   int rc = run_layers(h, n, st);
   if (rc) return rc;
   const long nro = (long)n * 2 * rows;
@@ -508,7 +545,7 @@ int vapx_transformer(vapx_handle h, int32_t n, int32_t rows, const float* x, flo
       GemmArgs g = gemm_args(h->xl[4] + (long)c * T * 256, am, h->W(c ? "comb.wb" : "comb.wa"), M, 256, 256,
                              c ? h->qx : h->att, contiguous_rows(256));
       g.gamma = h->W("comb.g"); g.beta = h->W("comb.b");
-      HIPCHK(h, launch_gemm_f32(g, EPI_BIAS_LN_GELU, 0, st));
+      HIPCHK(h, gemm(h, g, EPI_BIAS_LN_GELU, st));
     }
     const long tot = (long)M * 256;
     hipLaunchKernelGGL(add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->xmid, h->att, h->qx, tot);
@@ -545,6 +582,27 @@ int64_t vapx_peek(vapx_handle h, const char* name, float* dst, size_t max_floats
   if (n > max_floats) n = max_floats;
   HIPCHK(h, hipMemcpy(dst, src, n * sizeof(float), hipMemcpyDeviceToHost));
   return (int64_t)n;
+}
+
+int vapx_profile_enable(vapx_handle h, uint32_t class_mask) {
+  if (!h) return VAPX_E_INVAL;
+  h->prof_mask = class_mask;
+  return VAPX_OK;
+}
+
+int vapx_profile_read(vapx_handle h, double* total_ms, int64_t* launches, int32_t n_classes) {
+  if (!h || !total_ms || !launches) return VAPX_E_INVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipDeviceSynchronize());
+  for (int i = 0; i < n_classes; ++i) { total_ms[i] = 0.0; launches[i] = 0; }
+  for (auto& r : h->prof_recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.cls < n_classes) { total_ms[r.cls] += ms; launches[r.cls] += 1; }
+    h->prof_pool.push_back(r.a);
+    h->prof_pool.push_back(r.b);
+  }
+  h->prof_recs.clear();
+  return VAPX_OK;
 }
 
 int vapx_gemm(void* hip_stream, int32_t M, int32_t N, int32_t K, const float* A, const float* W, float* C, int32_t epi,

@@ -22,7 +22,10 @@ MODE = {"vap": 0, "bc": 1, "nod": 2}
 
 EXPORTS = ("vapx_abi_version", "vapx_blob_floats", "vapx_create", "vapx_destroy", "vapx_step",
            "vapx_reset_stream", "vapx_get_state", "vapx_set_state", "vapx_encode_audio",
-           "vapx_transformer", "vapx_peek", "vapx_gemm", "vapx_last_error")
+           "vapx_transformer", "vapx_peek", "vapx_gemm", "vapx_last_error", "vapx_profile_enable",
+           "vapx_profile_read")
+PROF_CLASSES = {0: "gemm_store", 1: "gemm_gelu", 2: "gemm_resid", 3: "gemm_resid_ln", 4: "gemm_cn_relu",
+                5: "gemm_bias_ln_gelu", 8: "conv0", 9: "lstm", 10: "gather_ln", 11: "attention", 12: "head"}
 
 
 class VapxError(RuntimeError):
@@ -77,6 +80,10 @@ def load_library(path: Optional[str] = None):
     lib.vapx_peek.argtypes = [vp, C.c_char_p, f32p, C.c_size_t]
     lib.vapx_gemm.restype = i32
     lib.vapx_gemm.argtypes = [vp, i32, i32, i32, f32p, f32p, f32p, i32, f32p, f32p, f32p, f32p, f32p, i32]
+    lib.vapx_profile_enable.restype = i32
+    lib.vapx_profile_enable.argtypes = [vp, C.c_uint32]
+    lib.vapx_profile_read.restype = i32
+    lib.vapx_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
     lib.vapx_last_error.restype = C.c_char_p
     lib.vapx_last_error.argtypes = [vp]
     if path is None:
@@ -167,6 +174,19 @@ class Engine:
         lstm = np.ascontiguousarray(state["lstm"], np.float32)
         carry = np.ascontiguousarray(state["carry"], np.float32)
         self._check(self.lib.vapx_set_state(self._h, sid, _np_ptr(ring), int(state["n_frames"]), _np_ptr(lstm), _np_ptr(carry)), "vapx_set_state")
+
+    def profile_enable(self, classes=()):
+        mask = 0
+        for c in classes:
+            mask |= 1 << int(c)
+        self._check(self.lib.vapx_profile_enable(self._h, mask), "vapx_profile_enable")
+
+    def profile_read(self) -> dict:
+        """{class_name: (total_ms, launches)} since the last read (synchronises the device)."""
+        ms = (C.c_double * 13)()
+        cnt = (C.c_int64 * 13)()
+        self._check(self.lib.vapx_profile_read(self._h, ms, cnt, 13), "vapx_profile_read")
+        return {PROF_CLASSES[i]: (ms[i], cnt[i]) for i in PROF_CLASSES if cnt[i]}
 
     def peek(self, name: str, shape) -> np.ndarray:
         buf = np.empty(int(np.prod(shape)), np.float32)
