@@ -239,10 +239,13 @@ hipError_t launch_gemm_f32(const GemmArgs& g, int epi, int tile_rows, hipStream_
   if ((g.N & 255) || (g.K & 31) || g.K <= 0) return hipErrorInvalidValue;
   if ((epi == EPI_RESID_LN || epi == EPI_CN_RELU || epi == EPI_BIAS_LN_GELU) && g.N != 256) return hipErrorInvalidValue;
   if (tile_rows == 0) {
-    const long ntn = g.N >> 8;
-    if (((g.M + 127) / 128) * ntn >= 512) tile_rows = 128;
-    else if (((g.M + 63) / 64) * ntn >= 384) tile_rows = 64;
-    else tile_rows = 32;
+    // measured on MI355X (tools/gemm_sweep.py, profiles/r01_gemm_sweep.txt): 64-row tiles win for
+    // N = 256 (more workgroups -> less tile quantisation, 3 waves/SIMD), 128-row tiles for the
+    // plain-store wide GEMMs, 32-row tiles when M is too small to fill 256 CUs otherwise.
+    if (g.N >= 512 && epi == EPI_STORE) tile_rows = 128;
+    else if (g.M < 12000) tile_rows = 32;
+    else if (g.K >= 2048 && g.M >= 200000) tile_rows = 128;
+    else tile_rows = 64;
   }
   switch (tile_rows) {
     case 128: return launch_wm<4, 1>(g, epi, stream);
