@@ -48,7 +48,7 @@ struct vapx_engine {
   float *h0 = nullptr, *h1 = nullptr, *h2 = nullptr, *h3 = nullptr, *z = nullptr, *lstm_out = nullptr, *e = nullptr;
   float* xl[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // layer inputs/outputs: x0, o, stereo0..2
   float *xn = nullptr, *xmid = nullptr, *att = nullptr, *qkv = nullptr, *qx = nullptr, *kvx = nullptr, *ffn = nullptr;
-  float *tmpa = nullptr, *tmpb = nullptr;
+  float *gx = nullptr;
   float* out_pinned = nullptr;
   int* ids_pinned = nullptr;
   hipEvent_t ids_evt = nullptr;
@@ -178,9 +178,14 @@ int run_encoder(vapx_engine* h, int B, const int* ids_dev, const float* audio, i
     g.bias = h->W("conv4.b"); g.gamma = h->W("cn4.g"); g.beta = h->W("cn4.b");
     HIPCHK(h, gemm(h, g, EPI_CN_RELU, st));
   }
+  {  // LSTM input projection for all n_cpc steps at once: gx = z.W_ih^T + (b_ih + b_hh)
+    GemmArgs g = gemm_args(h->z, contiguous_rows(256), h->W("lstm.wih"), B * 2 * h->ncpc, 1024, 256, h->gx, contiguous_rows(1024));
+    g.bias = h->W("lstm.b");
+    HIPCHK(h, gemm(h, g, EPI_STORE, st));
+  }
   LstmArgs la;
-  la.z = h->z; la.ids = ids_dev; la.h_state = h->h_state; la.c_state = h->c_state;
-  la.wfrag = h->W("lstm.w"); la.bias = h->W("lstm.b"); la.out = h->lstm_out; la.M = B * 2; la.ncpc = h->ncpc;
+  la.gx = h->gx; la.ids = ids_dev; la.h_state = h->h_state; la.c_state = h->c_state;
+  la.wfrag = h->W("lstm.whh"); la.out = h->lstm_out; la.M = B * 2; la.ncpc = h->ncpc;
   { ProfScope ps(h, CLS_LSTM, st); HIPCHK(h, launch_lstm(la, st)); }
   {  // downsample: single-output Conv1d == dense [ncpc*256 -> 256] + LN + GELU
     GemmArgs g = gemm_args(h->lstm_out, contiguous_rows((long)h->ncpc * 256), h->W("down.w"), B * 2, 256, h->ncpc * 256,
@@ -293,7 +298,7 @@ void vapx_destroy(vapx_handle h) {
   (void)hipDeviceSynchronize();
   float* fp[] = {h->w, h->ring, h->h_state, h->c_state, h->carry, h->audio_dev, h->out_dev, h->h0, h->h1, h->h2, h->h3,
                  h->z, h->lstm_out, h->e, h->xl[0], h->xl[1], h->xl[2], h->xl[3], h->xl[4], h->xn, h->xmid, h->att,
-                 h->qkv, h->qx, h->kvx, h->ffn, h->tmpa, h->tmpb};
+                 h->qkv, h->qx, h->kvx, h->ffn, h->gx};
   for (float* p : fp)
     if (p) (void)hipFree(p);
   int* ip[] = {h->frames_seen, h->ids_dev, h->bn, h->bhead};
@@ -374,6 +379,7 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
   CR(dalloc(&h->h3, B * 2 * (P[3] + 2) * 256));
   CR(dalloc(&h->z, B * 2 * h->ncpc * 256));
   CR(dalloc(&h->lstm_out, B * 2 * h->ncpc * 256));
+  CR(dalloc(&h->gx, B * 2 * h->ncpc * 1024));
   CR(dalloc(&h->e, B * 2 * 256));
   const size_t rows = B * 2 * T;
   for (int i = 0; i < 5; ++i) CR(dalloc(&h->xl[i], rows * 256));

@@ -18,12 +18,11 @@ struct Conv0Args {
 };
 
 struct LstmArgs {
-  const float* z;       // [M][ncpc][256]
+  const float* gx;      // [M][ncpc][1024] input projection + both biases, permuted gate columns
   const int* ids;       // [M/2] or null
   float* h_state;       // [S*2][256]
   float* c_state;       // [S*2][256]
-  const float* wfrag;   // fragment-major [4 w][64 kc][8 ns][64 lane][4]
-  const float* bias;    // [1024] permuted, b_ih + b_hh
+  const float* wfrag;   // W_hh, fragment-major [4 w][16 kc][16 ns][64 lane][4]
   float* out;           // [M][ncpc][256]
   int M, ncpc;
 };

@@ -68,106 +68,95 @@ __global__ __launch_bounds__(256) void conv0_kernel(Conv0Args a) {
 // 2. LSTM (256 -> 256, 1 layer), n_cpc sequential steps, (h, c) persistent per (stream, channel)
 //    reference: CPCAR.forward encoder_components.py:140-159 (nn.LSTM, gate order i,f,g,o, both
 //    biases), keepHidden=True (encoder.py:27).
-//    One workgroup = 32 (stream,channel) rows x all 1024 gate columns; wave w owns hidden units
-//    64w..64w+63 for all four gates (weight rows pre-permuted so its 256 columns are
-//    [i|f|g|o] x 64), i.e. 8 MFMA accumulators of 32x32 — the cell update is then lane-local.
-//    Per step the contraction is [z_t | h_{t-1}] (K = 512) . [W_ih | W_hh]^T; the A operand sits
-//    in LDS, the weight fragments stream from L2 in a fragment-major layout (one coalesced
-//    1 KiB load per wave per 4 MFMAs).  c stays in registers across steps, h in LDS.
+//    The input projection z.W_ih^T + b_ih + b_hh for all n_cpc steps is a plain batched GEMM
+//    (engine: gx = gemm(z, lstm.wih) + bias); only the K = 256 recurrence h_{t-1}.W_hh^T is
+//    sequential.  One workgroup = 16 (stream,channel) rows (v_mfma_f32_16x16x4_f32, so a small
+//    batch still spreads over many CUs); wave w owns hidden units 64w..64w+63 for all four gates
+//    (weight rows pre-permuted: its 256 columns are [i|f|g|o] x 64 -> the cell update is
+//    lane-local).  h lives in LDS between steps, c in registers, W_hh fragments stream from L2 in
+//    fragment-major order (one coalesced 1 KiB load per wave per 4 MFMAs).
 // ------------------------------------------------------------------------------------------------
-constexpr int ZH_LD = 516;  // 512 + 4 pad floats
+constexpr int H_LD = 260;  // 256 + 4 pad floats
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void lstm_kernel(LstmArgs a) {
-  __shared__ __attribute__((aligned(16))) float zh[32 * ZH_LD];
+  __shared__ __attribute__((aligned(16))) float hbuf[16 * H_LD];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int l31 = lane & 31, hi = lane >> 5, kh = hi * 4;
-  const int m0 = blockIdx.x * 32;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.x * 16;
 
-  // state row of a local row
   auto state_row = [&](int m) {
     m = m < a.M ? m : a.M - 1;
     int b = m >> 1;
     int sid = a.ids ? a.ids[b] : b;
     return (long)sid * 2 + (m & 1);
   };
-  // h_{-1} -> zh[:, 256:512]
-  for (int i = tid; i < 32 * 64; i += 256) {
+  for (int i = tid; i < 16 * 64; i += 256) {
     int row = i >> 6, q = (i & 63) * 4;
-    *(f32x4*)&zh[row * ZH_LD + 256 + q] = *(const f32x4*)(a.h_state + state_row(m0 + row) * 256 + q);
+    *(f32x4*)&hbuf[row * H_LD + q] = *(const f32x4*)(a.h_state + state_row(m0 + row) * 256 + q);
   }
-  // c in registers: element (hh, r) <-> row lr(r), hidden unit j = 64w + 32hh + l31
-  float creg[2][16];
+  // accumulator (ns, reg): row = 4*kq + reg, column ns*16 + l15 of this wave's 256 = gate ns/4,
+  // hidden unit j = 64w + 16*(ns%4) + l15.  c for (q = ns%4, reg) stays in registers.
+  float creg[4][4];
+  long srow[4];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-    long sr = state_row(m0 + row);
+  for (int reg = 0; reg < 4; ++reg) {
+    srow[reg] = state_row(m0 + kq * 4 + reg);
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) creg[hh][r] = a.c_state[sr * 256 + w * 64 + hh * 32 + l31];
+    for (int q = 0; q < 4; ++q) creg[q][reg] = a.c_state[srow[reg] * 256 + w * 64 + q * 16 + l15];
   }
-  float bias[8];
-#pragma unroll
-  for (int ns = 0; ns < 8; ++ns) bias[ns] = a.bias[w * 256 + ns * 32 + l31];
-
-  const f32x4* wf = (const f32x4*)a.wfrag + (long)w * 64 * 8 * 64 + lane;
+  const f32x4* wf = (const f32x4*)a.wfrag + (long)w * 16 * 16 * 64 + lane;
+  const float* pa = &hbuf[l15 * H_LD + kq * 4];
   for (int t = 0; t < a.ncpc; ++t) {
-    for (int i = tid; i < 32 * 64; i += 256) {
-      int row = i >> 6, q = (i & 63) * 4;
-      int m = m0 + row;
-      m = m < a.M ? m : a.M - 1;
-      *(f32x4*)&zh[row * ZH_LD + q] = *(const f32x4*)(a.z + ((long)m * a.ncpc + t) * 256 + q);
-    }
-    __syncthreads();
-    f32x16 acc[8];
+    __syncthreads();  // hbuf holds h_{t-1}
+    f32x4v acc[16];
 #pragma unroll
-    for (int ns = 0; ns < 8; ++ns)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ns][r] = bias[ns];
-    const float* pa = &zh[l31 * ZH_LD + kh];
+    for (int ns = 0; ns < 16; ++ns) acc[ns] = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
-    for (int kc = 0; kc < 64; ++kc) {
-      f32x4 av = *(const f32x4*)(pa + kc * 8);
-      f32x4 bv[8];
+    for (int kc = 0; kc < 16; ++kc) {
+      f32x4 av = *(const f32x4*)(pa + kc * 16);
+      f32x4 bv[16];
 #pragma unroll
-      for (int ns = 0; ns < 8; ++ns) bv[ns] = wf[((long)kc * 8 + ns) * 64];
+      for (int ns = 0; ns < 16; ++ns) bv[ns] = wf[((long)kc * 16 + ns) * 64];
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int ns = 0; ns < 8; ++ns)
-          acc[ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[ns][s], acc[ns], 0, 0, 0);
+        for (int ns = 0; ns < 16; ++ns)
+          acc[ns] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[ns][s], acc[ns], 0, 0, 0);
     }
-    __syncthreads();  // every wave has finished reading zh for this step
+    __syncthreads();  // every wave has finished reading hbuf for this step
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = kq * 4 + reg;
       int m = m0 + row;
+      const bool live = m < a.M;
+      m = live ? m : a.M - 1;
+      const float* gx = a.gx + ((long)m * a.ncpc + t) * 1024 + w * 256 + l15;
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        float ig = sigmoidf_(acc[0 + hh][r]);
-        float fg = sigmoidf_(acc[2 + hh][r]);
-        float gg = tanhf(acc[4 + hh][r]);
-        float og = sigmoidf_(acc[6 + hh][r]);
-        float cn = fg * creg[hh][r] + ig * gg;
-        creg[hh][r] = cn;
+      for (int q = 0; q < 4; ++q) {
+        float ig = sigmoidf_(acc[0 + q][reg] + gx[0 * 64 + q * 16]);
+        float fg = sigmoidf_(acc[4 + q][reg] + gx[1 * 64 + q * 16]);
+        float gg = tanhf(acc[8 + q][reg] + gx[2 * 64 + q * 16]);
+        float og = sigmoidf_(acc[12 + q][reg] + gx[3 * 64 + q * 16]);
+        float cn = fg * creg[q][reg] + ig * gg;
+        creg[q][reg] = cn;
         float hn = og * tanhf(cn);
-        int j = w * 64 + hh * 32 + l31;
-        zh[row * ZH_LD + 256 + j] = hn;
-        if (m < a.M) a.out[((long)m * a.ncpc + t) * 256 + j] = hn;
+        const int j = w * 64 + q * 16 + l15;
+        hbuf[row * H_LD + j] = hn;
+        if (live) a.out[((long)m * a.ncpc + t) * 256 + j] = hn;
       }
     }
-    // the z-load + barrier of the next step (or the barrier below) orders these LDS writes
   }
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-    int m = m0 + row;
-    if (m < a.M) {
-      long sr = state_row(m);
+  for (int reg = 0; reg < 4; ++reg) {
+    const int row = kq * 4 + reg;
+    if (m0 + row < a.M) {
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        int j = w * 64 + hh * 32 + l31;
-        a.c_state[sr * 256 + j] = creg[hh][r];
-        a.h_state[sr * 256 + j] = zh[row * ZH_LD + 256 + j];
+      for (int q = 0; q < 4; ++q) {
+        const int j = w * 64 + q * 16 + l15;
+        a.c_state[srow[reg] * 256 + j] = creg[q][reg];
+        a.h_state[srow[reg] * 256 + j] = hbuf[row * H_LD + j];
       }
     }
   }
@@ -212,69 +201,154 @@ __global__ __launch_bounds__(256) void gather_ln_kernel(GatherArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// 4. causal multi-head attention with ALiBi key bias
+// 4. causal multi-head attention with ALiBi key bias, fp32 MFMA
 //    reference: MultiHeadAttention.forward modules.py:82-110 (scale 1/sqrt(dim)=1/16, :52),
 //    MultiHeadAttentionAlibi.get_alibi_mask 162-188 (bias m_h * j on the KEY index).
-//    One workgroup per (stream, channel, head); K and V tiles [n][64] staged in LDS, one query
-//    row per lane (64 q values in registers), online softmax; fp32 vector FMAs (4 % of the step's
-//    MACs at T = 50, not worth reshaping for MFMA).
+//    One workgroup per (stream, channel, head); K and V tiles [n][64] staged in LDS (zero rows
+//    beyond n).  Each wave owns 32-query tiles `it` and computes the TRANSPOSED score tile
+//        S^T[j][i] = sum_d K[j][d] Q[i][d]          (A = K from LDS, B = Q from global)
+//    for the causal key tiles jt <= it.  In the 32x32 accumulator layout a query column i then
+//    lives in ONE lane pair (l, l+32): the softmax row max / sum are lane-local plus one
+//    cross-half shuffle, and — the point of transposing — accumulator register r of S^T is
+//    exactly the B operand of MFMA step r of   O^T[d][i] = sum_j V[j][d] P^T[j][i]
+//    (lane half h holds key j0(r)+4h, which is the k-slot that half supplies), so P never moves.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float kv[];  // K [T][64] then V [T][64]
+constexpr int KV_LD = 68;  // 64 + 4 pad floats: ds_read_b128 rows and ds_read_b32 columns conflict-free
+
+// one 32-query tile against NJT = it+1 causal key tiles (NJT is compile-time so the accumulator
+// array is statically indexed and never conditionally updated — see the spill note in gemm_f32.hip)
+template <int NJT>
+__device__ __forceinline__ void attn_tile(const AttnArgs& a, const float* Ks, const float* Vs, int bc, int h, int n,
+                                          int it, int l31, int hi, float slope) {
   const int T = a.T;
+  const int i = it * 32 + l31;
+  float* op = a.out + ((long)bc * T + i) * 256 + h * 64;
+  // Q fragments (B operand): row i, k-slots kc*8 + 4*hi .. +3, pre-scaled by 1/16
+  const int iq = i < n ? i : n - 1;
+  const float* qp = a.q + ((long)bc * T + iq) * a.ldq + h * 64 + hi * 4;
+  f32x4 qf[8];
+#pragma unroll
+  for (int kc = 0; kc < 8; ++kc) qf[kc] = *(const f32x4*)(qp + kc * 8) * 0.0625f;
+
+  f32x16 acc[NJT];
+#pragma unroll
+  for (int jt = 0; jt < NJT; ++jt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
+    const float* ka = &Ks[(jt * 32 + l31) * KV_LD + hi * 4];
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) {
+      f32x4 av = *(const f32x4*)(ka + kc * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], qf[kc][s], acc[jt], 0, 0, 0);
+    }
+  }
+  // softmax over keys j for query column i (lane-local + one cross-half exchange)
+  float mx = -1e30f;
+#pragma unroll
+  for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      float sc = acc[jt][r] + slope * (float)j;
+      sc = ((j <= i) && (j < n)) ? sc : -1e30f;
+      acc[jt][r] = sc;
+      mx = fmaxf(mx, sc);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float sc = acc[jt][r];
+      float pv = sc > -1e29f ? expf(sc - mx) : 0.f;
+      acc[jt][r] = pv;
+      sum += pv;
+    }
+  sum += __shfl_xor(sum, 32);
+  const float inv = 1.0f / sum;
+  // O^T[d][i] = sum_j V[j][d] * P^T[j][i]
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+#pragma unroll
+  for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float* va = &Vs[(jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * KV_LD + l31];
+      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[0], acc[jt][r], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32], acc[jt][r], o1, 0, 0, 0);
+    }
+  if (i < T) {
+    const float sc = i < n ? inv : 0.f;   // rows beyond the valid window: deterministic zeros
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      f32x4 v0 = {o0[rr * 4 + 0], o0[rr * 4 + 1], o0[rr * 4 + 2], o0[rr * 4 + 3]};
+      f32x4 v1 = {o1[rr * 4 + 0], o1[rr * 4 + 1], o1[rr * 4 + 2], o1[rr * 4 + 3]};
+      *(f32x4*)(op + rr * 8 + hi * 4) = v0 * sc;
+      *(f32x4*)(op + 32 + rr * 8 + hi * 4) = v1 * sc;
+    }
+  }
+}
+
+template <int MAXJT>
+__global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float kv[];
+  const int T = a.T;
+  const int n_tiles = (T + 31) >> 5;
   float* Ks = kv;
-  float* Vs = kv + (long)T * 64;
+  float* Vs = kv + (long)n_tiles * 32 * KV_LD;
   const int h = blockIdx.x & 3, bc = blockIdx.x >> 2, b = bc >> 1;
   const int n = a.bn[b];
   const int kvbc = a.swap_kv ? (bc ^ 1) : bc;
-  const int tid = threadIdx.x, lane = tid & 63, qb = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, NW = blockDim.x >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
   const float* kp = a.k + (long)kvbc * T * a.ldkv + h * 64;
   const float* vp = a.v + (long)kvbc * T * a.ldkv + h * 64;
-  for (int i = tid; i < n * 16; i += blockDim.x) {
+  const int nt_valid = (n + 31) >> 5;          // key/query tiles that contain valid rows
+  for (int i = tid; i < nt_valid * 32 * 16; i += blockDim.x) {
     int j = i >> 4, q = (i & 15) * 4;
-    *(f32x4*)&Ks[j * 64 + q] = *(const f32x4*)(kp + (long)j * a.ldkv + q);
-    *(f32x4*)&Vs[j * 64 + q] = *(const f32x4*)(vp + (long)j * a.ldkv + q);
+    f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = kk;
+    if (j < n) {
+      kk = *(const f32x4*)(kp + (long)j * a.ldkv + q);
+      vv = *(const f32x4*)(vp + (long)j * a.ldkv + q);
+    }
+    *(f32x4*)&Ks[j * KV_LD + q] = kk;
+    *(f32x4*)&Vs[j * KV_LD + q] = vv;
   }
   __syncthreads();
-  const int i = qb * 64 + lane;
-  if (i >= T) return;
-  float* op = a.out + ((long)bc * T + i) * 256 + h * 64;
-  if (i >= n) {
-#pragma unroll
-    for (int d = 0; d < 16; ++d) *(f32x4*)(op + d * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-    return;
-  }
-  f32x4 q[16];
-  const float* qp = a.q + ((long)bc * T + i) * a.ldq + h * 64;
-#pragma unroll
-  for (int d = 0; d < 16; ++d) q[d] = *(const f32x4*)(qp + d * 4) * 0.0625f;
   const float slope = exp2f(-2.0f * (float)(h + 1));  // [1/4, 1/16, 1/64, 1/256]
-  f32x4 o[16];
+
+  for (int pass = 0; pass * NW < n_tiles; ++pass) {
+    // boustrophedon tile order balances the triangular work across waves
+    const int it = pass * NW + ((pass & 1) ? (NW - 1 - w) : w);
+    if (it >= n_tiles) continue;
+    if (it >= nt_valid) {  // whole tile beyond the valid rows: deterministic zeros
+      const int i = it * 32 + l31;
+      if (i < T) {
+        float* op = a.out + ((long)bc * T + i) * 256 + h * 64;
 #pragma unroll
-  for (int d = 0; d < 16; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float mx = -1e30f, l = 0.f;
-  int jend = (qb + 1) * 64;
-  jend = jend < n ? jend : n;
-  for (int j = 0; j < jend; ++j) {
-    const f32x4* kr = (const f32x4*)&Ks[j * 64];
-    f32x4 sv = q[0] * kr[0];
-#pragma unroll
-    for (int d = 1; d < 16; ++d) sv += q[d] * kr[d];
-    float s = (sv[0] + sv[1]) + (sv[2] + sv[3]) + slope * (float)j;
-    if (j <= i) {
-      float mn = fmaxf(mx, s);
-      float corr = expf(mx - mn);
-      float p = expf(s - mn);
-      l = l * corr + p;
-      mx = mn;
-      const f32x4* vr = (const f32x4*)&Vs[j * 64];
-#pragma unroll
-      for (int d = 0; d < 16; ++d) o[d] = o[d] * corr + vr[d] * p;
+        for (int d = 0; d < 8; ++d) *(f32x4*)(op + hi * 32 + d * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      continue;
+    }
+    switch (it) {
+      case 0: attn_tile<1>(a, Ks, Vs, bc, h, n, it, l31, hi, slope); break;
+      case 1: attn_tile<2>(a, Ks, Vs, bc, h, n, it, l31, hi, slope); break;
+      default:
+        if constexpr (MAXJT > 2) {
+          switch (it) {
+            case 2: attn_tile<3>(a, Ks, Vs, bc, h, n, it, l31, hi, slope); break;
+            case 3: attn_tile<4>(a, Ks, Vs, bc, h, n, it, l31, hi, slope); break;
+            case 4: attn_tile<5>(a, Ks, Vs, bc, h, n, it, l31, hi, slope); break;
+            case 5: attn_tile<6>(a, Ks, Vs, bc, h, n, it, l31, hi, slope); break;
+            case 6: attn_tile<7>(a, Ks, Vs, bc, h, n, it, l31, hi, slope); break;
+            case 7: attn_tile<8>(a, Ks, Vs, bc, h, n, it, l31, hi, slope); break;
+          }
+        }
     }
   }
-  const float inv = 1.0f / l;
-#pragma unroll
-  for (int d = 0; d < 16; ++d) *(f32x4*)(op + d * 4) = o[d] * inv;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -470,7 +544,7 @@ hipError_t launch_conv0(const Conv0Args& a, int B, hipStream_t st) {
   return hipGetLastError();
 }
 hipError_t launch_lstm(const LstmArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(lstm_kernel, dim3((a.M + 31) / 32), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(lstm_kernel, dim3((a.M + 15) / 16), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_gather_ln(const GatherArgs& a, hipStream_t st) {
@@ -479,14 +553,18 @@ hipError_t launch_gather_ln(const GatherArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 hipError_t launch_attention(const AttnArgs& a, int B, hipStream_t st) {
-  int nqb = (a.T + 63) / 64;
-  size_t lds = (size_t)a.T * 64 * 2 * sizeof(float);
+  const int n_tiles = (a.T + 31) / 32;
+  const int nw = n_tiles < 4 ? n_tiles : 4;
+  const size_t lds = (size_t)n_tiles * 32 * KV_LD * 2 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)attention_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)attention_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(attention_kernel, dim3(B * 2 * 4), dim3(64 * nqb), lds, st, a);
+  if (n_tiles <= 2) hipLaunchKernelGGL(attention_mfma_kernel<2>, dim3(B * 2 * 4), dim3(64 * nw), lds, st, a);
+  else if (n_tiles <= 8) hipLaunchKernelGGL(attention_mfma_kernel<8>, dim3(B * 2 * 4), dim3(64 * nw), lds, st, a);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 hipError_t launch_head(const HeadArgs& a, hipStream_t st) {

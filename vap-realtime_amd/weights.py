@@ -216,7 +216,8 @@ def blob_entries(K: int, mode: str) -> List[Tuple[str, int]]:
         e.append((f"conv{i}.w", DIM * k * DIM))  # [cout][tap*256+cin]
         e.append((f"conv{i}.b", DIM))
         e.append((f"cn{i}.g", DIM)); e.append((f"cn{i}.b", DIM))
-    e.append(("lstm.w", LSTM_GATES * 2 * DIM))   # MFMA-fragment-major [4 w][64 kc][8 ns][64 lane][4]
+    e.append(("lstm.wih", LSTM_GATES * DIM))     # [perm row][256]  (plain GEMM operand)
+    e.append(("lstm.whh", LSTM_GATES * DIM))     # 16x16x4-MFMA fragment-major [4 w][16 kc][16 ns][64 lane][4]
     e.append(("lstm.b", LSTM_GATES))             # b_ih + b_hh, permuted
     e.append(("down.w", DIM * K * DIM))          # [cout][k*256+cin]
     e.append(("down.b", DIM)); e.append(("down.g", DIM)); e.append(("down.beta", DIM))
@@ -282,9 +283,9 @@ def pack_blob(cpc_sd: Dict[str, np.ndarray], vap_sd: Dict[str, np.ndarray], mode
     perm = _lstm_perm()
     wih = A(cpc_sd["gAR.baseNet.weight_ih_l0"])[perm]
     whh = A(cpc_sd["gAR.baseNet.weight_hh_l0"])[perm]
-    wcat = np.concatenate([wih, whh], axis=1)            # [1024 permuted rows][512]
-    # row = w*256 + ns*32 + l31 ; k = kc*8 + kh*4 + u  ->  [w][kc][ns][lane = kh*32 + l31][u]
-    put("lstm.w", wcat.reshape(4, 8, 32, 64, 2, 4).transpose(0, 3, 1, 4, 2, 5))
+    put("lstm.wih", wih)
+    # row = w*256 + ns*16 + l15 ; k = kc*16 + kq*4 + u  ->  [w][kc][ns][lane = kq*16 + l15][u]
+    put("lstm.whh", whh.reshape(4, 16, 16, 16, 4, 4).transpose(0, 3, 1, 4, 2, 5))
     put("lstm.b", (A(cpc_sd["gAR.baseNet.bias_ih_l0"]) + A(cpc_sd["gAR.baseNet.bias_hh_l0"]))[perm])
     wd = A(vap_sd["encoder.downsample.1.weight"])        # [cout, cin, K]
     put("down.w", wd.transpose(0, 2, 1))
