@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--cpu-baseline-sec", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--groups", type=int, default=0, help="intra-tick overlap groups (0 = engine default)")
     args = ap.parse_args()
 
     import torch
@@ -85,7 +86,7 @@ def main():
     hop = 16000 // hz
     my_streams = shard_streams(S * world, world, rank)           # global stream ids of this rank
     cpc, vap = W.synthetic_weights(0, hz, "vap")
-    eng = engine.Engine(W.pack_blob(cpc, vap), hz, args.ctx_sec, max_streams=S, device_id=local_rank)
+    eng = engine.Engine(W.pack_blob(cpc, vap), hz, args.ctx_sec, max_streams=S, device_id=local_rank, groups=args.groups)
 
     NF = 32                                                      # distinct audio frames, cycled
     base = synth.dialogue_batch(my_streams[:min(S, 64)], hop * NF)   # [<=64,2,hop*NF]

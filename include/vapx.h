@@ -75,7 +75,7 @@ typedef struct vapx_config {
   int32_t max_streams;  /* stream slots whose state lives in HBM */
   int32_t max_batch;    /* max streams per vapx_step call (sizes scratch) */
   int32_t mode;         /* VAPX_MODE_* */
-  int32_t flags;        /* reserved, 0 */
+  int32_t flags;        /* bits 0-3: intra-tick overlap groups (0 = default 1 = none, max 8) */
 } vapx_config;
 
 /* Number of floats the weight blob must have for a frame rate (layout:
