@@ -67,19 +67,12 @@ def main():
     args = ap.parse_args()
 
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from vap_realtime_amd import dist_util, engine, synth, weights as W
+    from vap_realtime_amd.sharding import shard_streams
+    rank, local_rank, world = dist_util.env_rank()
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    from vap_realtime_amd import engine, synth, weights as W
-    from vap_realtime_amd.sharding import shard_streams
+    dist = dist_util.init("nccl", torch.device("cuda", local_rank))
 
     hz, S = args.frame_hz, args.streams
     T = int(args.ctx_sec * hz)
@@ -101,10 +94,7 @@ def main():
         eng.step_device(S, d_audio[i % NF].data_ptr(), hop, d_out.data_ptr(), stream=stream)
 
     def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        dist_util.barrier(dist, torch.cuda.synchronize)
 
     # prime the context window (so the timed region is the steady state), then a profiled pass to
     # find the dominant kernel class
@@ -134,10 +124,7 @@ def main():
     dt = time.perf_counter() - t0
     dom_ms, dom_launches = eng.profile_read()[dominant]
     eng.profile_enable([])
-    if dist is not None:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = dist_util.max_over_ranks(dist, dt, "cuda")
     assert torch.isfinite(d_out[:, :6]).all(), "non-finite outputs"
 
     frames = S * world * args.steps

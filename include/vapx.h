@@ -127,9 +127,10 @@ int vapx_encode_audio(vapx_handle h, int32_t n, const int32_t* stream_ids, const
  * context tensors x [n][2][rows][256] (rows <= ctx_frames).  Any output pointer may be NULL.
  *   o    [n][2][rows][256]  ar_channel(x_c)["x"]
  *   x12  [n][2][rows][256]  ar(...)["x1"], ["x2"]
- *   comb [n][rows][256]     ar(...)["x"]  (Combinator output, all rows) */
+ *   comb [n][rows][256]     ar(...)["x"]  (Combinator output, all rows)
+ *   stage 0: both; 1: ar_channel only (x -> o); 2: ar only (x is then o1,o2 -> x12, comb). */
 int vapx_transformer(vapx_handle h, int32_t n, int32_t rows, const float* x, float* o, float* x12, float* comb,
-                     void* hip_stream);
+                     int32_t stage, void* hip_stream);
 
 /* Copy an internal scratch buffer of the LAST vapx_step to the host (per-layer parity tests).
  * name: "h0".."h3","z","lstm_out","e","x0","o","stereo0".."stereo2"; returns the number of

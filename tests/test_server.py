@@ -1,0 +1,111 @@
+"""Host logic of the many-stream TCP front-end, with a test double in place of the GPU model
+(the real model has no CPU path).  Checks routing, frame assembly and packet framing."""
+import socket
+import struct
+import time
+
+import numpy as np
+
+from vap_realtime_amd import wire
+from vap_realtime_amd.server import ManyStreamServer
+
+
+class FakeVap:
+    """Deterministic stand-in: p_now = [mean|x1|, mean|x2|] of the frame, so routing errors show."""
+    mode = "vap"
+
+    def __init__(self, n_streams, hop):
+        self.n_streams, self.hop = n_streams, hop
+        self.calls, self.resets = [], []
+
+    def process(self, frames, ids):
+        self.calls.append((frames.shape, list(ids)))
+        m = np.abs(frames).mean(axis=2)
+        return {"p_now": m, "p_future": m[:, ::-1], "vad": (m > 0.5).astype(np.float32)}
+
+    def reset(self, sid):
+        self.resets.append(sid)
+
+
+def _recv_exact(sock, n):
+    b = b""
+    while len(b) < n:
+        chunk = sock.recv(n - len(b))
+        assert chunk, "socket closed"
+        b += chunk
+    return b
+
+
+def test_two_streams_routed_and_framed():
+    hop = 800
+    vap = FakeVap(4, hop)
+    srv = ManyStreamServer(vap, port_in=0, port_out=0, max_wait_s=0.5).start()
+    try:
+        ins = [socket.create_connection(("127.0.0.1", srv.port_in)) for _ in range(2)]
+        time.sleep(0.1)
+        outs = [socket.create_connection(("127.0.0.1", srv.port_out)) for _ in range(2)]
+        time.sleep(0.1)
+        rng = np.random.default_rng(5)
+        x = rng.standard_normal((2, 2, 2 * hop)) * np.array([0.1, 2.0])[:, None, None]
+        for f in range(2):
+            for p in range(5):
+                for s in range(2):
+                    seg = slice(f * hop + p * 160, f * hop + (p + 1) * 160)
+                    ins[s].sendall(wire.encode_input(x[s, 0, seg], x[s, 1, seg]))
+            for s in range(2):
+                outs[s].settimeout(5)
+                ln = struct.unpack("<I", _recv_exact(outs[s], 4))[0]
+                assert ln == 12876
+                r = wire.decode_result(_recv_exact(outs[s], ln))
+                np.testing.assert_array_equal(r["x1"], x[s, 0, f * hop:(f + 1) * hop])     # float64 echo
+                want = np.abs(x[s, :, f * hop:(f + 1) * hop].astype(np.float32)).mean(axis=1)
+                np.testing.assert_allclose(r["p_now"], want, rtol=1e-6)
+                np.testing.assert_allclose(r["p_future"], want[::-1], rtol=1e-6)
+        assert vap.resets == [0, 1]
+        assert all(ids == [0, 1] for _, ids in vap.calls) and len(vap.calls) == 2
+    finally:
+        srv.stop()
+
+
+def test_ragged_tick_when_one_stream_lags():
+    hop = 320  # 50 Hz
+    vap = FakeVap(2, hop)
+    srv = ManyStreamServer(vap, port_in=0, port_out=0, max_wait_s=0.05).start()
+    try:
+        a = socket.create_connection(("127.0.0.1", srv.port_in))
+        b = socket.create_connection(("127.0.0.1", srv.port_in))
+        time.sleep(0.1)
+        z = np.zeros(160)
+        for _ in range(2):
+            a.sendall(wire.encode_input(z, z))
+        b.sendall(wire.encode_input(z, z))          # b has only half a frame
+        deadline = time.time() + 3
+        while not vap.calls and time.time() < deadline:
+            time.sleep(0.01)
+        assert vap.calls and vap.calls[0][1] == [0]  # only stream 0 was stepped
+        b.sendall(wire.encode_input(z, z))
+        while len(vap.calls) < 2 and time.time() < deadline:
+            time.sleep(0.01)
+        assert vap.calls[1][1] == [1]
+    finally:
+        srv.stop()
+
+
+def test_single_stream_broadcasts_like_reference():
+    vap = FakeVap(1, 800)
+    srv = ManyStreamServer(vap, port_in=0, port_out=0).start()
+    try:
+        i = socket.create_connection(("127.0.0.1", srv.port_in))
+        time.sleep(0.05)
+        outs = [socket.create_connection(("127.0.0.1", srv.port_out)) for _ in range(3)]
+        time.sleep(0.1)
+        z = np.ones(160)
+        for _ in range(5):
+            i.sendall(wire.encode_input(z, z))
+        for o in outs:
+            o.settimeout(5)
+            ln = struct.unpack("<I", _recv_exact(o, 4))[0]
+            r = wire.decode_result(_recv_exact(o, ln))
+            assert r["p_now"] == [1.0, 1.0]
+    finally:
+        srv.stop()

@@ -226,11 +226,11 @@ int run_encoder(vapx_engine* h, const Scratch& sc, const StateView& sv, int B, c
 }
 
 // ---- 1 self + 3 self/cross layers on x0 = xl[0] (LN_self(L0) already in xn) ---------------------
-int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st) {
+int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_begin = 0, int l_end = 4) {
   const int T = h->T;
   const int M = B * 2 * T;
   const RowMap r256 = contiguous_rows(256), r768 = contiguous_rows(768), r512 = contiguous_rows(512);
-  for (int l = 0; l < 4; ++l) {
+  for (int l = l_begin; l < l_end; ++l) {
     const Layer& Lw = h->layer[l];
     const float* xin = sc.xl[l];
     float* xout = sc.xl[l + 1];
@@ -596,21 +596,26 @@ int vapx_encode_audio(vapx_handle h, int32_t n, const int32_t* stream_ids, const
   return VAPX_OK;
 }
 
-int vapx_transformer(vapx_handle h, int32_t n, int32_t rows, const float* x, float* o, float* x12, float* comb, void* hip_stream) {
+int vapx_transformer(vapx_handle h, int32_t n, int32_t rows, const float* x, float* o, float* x12, float* comb,
+                     int32_t stage, void* hip_stream) {
   if (!h) return VAPX_E_INVAL;
   if (n < 1 || n > h->cfg.max_batch) return fail(h, VAPX_E_RANGE, "n=%d outside [1,%d]", n, h->cfg.max_batch);
   if (rows < 1 || rows > h->T) return fail(h, VAPX_E_RANGE, "rows=%d outside [1,%d]", rows, h->T);
   if (!x) return fail(h, VAPX_E_INVAL, "null x");
+  if (stage < 0 || stage > 2) return fail(h, VAPX_E_INVAL, "stage must be 0 (all), 1 (ar_channel) or 2 (ar)");
+  if (stage == 1 && (x12 || comb)) return fail(h, VAPX_E_INVAL, "stage 1 produces only o");
+  if (stage == 2 && o) return fail(h, VAPX_E_INVAL, "stage 2 does not produce o");
   hipStream_t st = (hipStream_t)hip_stream;
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   const int T = h->T;
+  const int l_begin = stage == 2 ? 1 : 0, l_end = stage == 1 ? 1 : 4;
   hipLaunchKernelGGL(fill_int_kernel, dim3((n + 255) / 256), dim3(256), 0, st, h->sc.bn, rows, n);
   GatherArgs ga;
   ga.ring = nullptr; ga.e = nullptr; ga.xin = x; ga.ids = nullptr; ga.bn = h->sc.bn; ga.bhead = h->sc.bhead;
-  ga.x0 = h->sc.xl[0]; ga.xn = h->sc.xn; ga.gamma = h->layer[0].ln_self_g; ga.beta = h->layer[0].ln_self_b;
+  ga.x0 = h->sc.xl[l_begin]; ga.xn = h->sc.xn; ga.gamma = h->layer[l_begin].ln_self_g; ga.beta = h->layer[l_begin].ln_self_b;
   ga.B = n; ga.T = T; ga.rows_in = rows;
   { ProfScope ps(h, CLS_GATHER, st); HIPCHK(h, launch_gather_ln(ga, st)); }
-  int rc = run_layers(h, h->sc, n, st);
+  int rc = run_layers(h, h->sc, n, st, l_begin, l_end);
   if (rc) return rc;
   const long nro = (long)n * 2 * rows;
   const unsigned cgrid = (unsigned)((nro * 64 + 255) / 256);

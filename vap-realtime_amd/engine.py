@@ -75,7 +75,7 @@ def load_library(path: Optional[str] = None):
     lib.vapx_encode_audio.restype = i32
     lib.vapx_encode_audio.argtypes = [vp, i32, i32p, f32p, f32p, vp]
     lib.vapx_transformer.restype = i32
-    lib.vapx_transformer.argtypes = [vp, i32, i32, f32p, f32p, f32p, f32p, vp]
+    lib.vapx_transformer.argtypes = [vp, i32, i32, f32p, f32p, f32p, f32p, i32, vp]
     lib.vapx_peek.restype = C.c_int64
     lib.vapx_peek.argtypes = [vp, C.c_char_p, f32p, C.c_size_t]
     lib.vapx_gemm.restype = i32
@@ -199,8 +199,10 @@ class Engine:
         ids = None if stream_ids is None else np.ascontiguousarray(stream_ids, dtype=np.int32)
         self._check(self.lib.vapx_encode_audio(self._h, n, _np_ptr(ids), frames_ptr, e_ptr, stream or None), "vapx_encode_audio")
 
-    def transformer_device(self, n: int, rows: int, x_ptr: int, o_ptr: int = 0, x12_ptr: int = 0, comb_ptr: int = 0, stream: int = 0):
-        self._check(self.lib.vapx_transformer(self._h, n, rows, x_ptr, o_ptr or None, x12_ptr or None, comb_ptr or None, stream or None), "vapx_transformer")
+    def transformer_device(self, n: int, rows: int, x_ptr: int, o_ptr: int = 0, x12_ptr: int = 0, comb_ptr: int = 0,
+                           stage: int = 0, stream: int = 0):
+        self._check(self.lib.vapx_transformer(self._h, n, rows, x_ptr, o_ptr or None, x12_ptr or None, comb_ptr or None,
+                                              stage, stream or None), "vapx_transformer")
 
 
 def split_outputs(out: np.ndarray) -> dict:

@@ -1,0 +1,216 @@
+"""Drop-in host objects mirroring the reference's realtime classes, backed by libvapx.
+
+* ``VAPRealTime``   — same constructor, attributes and ``process_vap(x1, x2)`` as
+  ``rvap/vap_main/vap_main.py:185-335`` (and the bc / nod twins), so the reference's server threads
+  (``proc_serv_in`` :354-414, ``proc_serv_out_dist`` :416-457) run unchanged with this object.
+* ``VapGPT``        — the model-attribute surface ``process_vap`` itself touches
+  (``encode_audio``, ``ar_channel``, ``ar``, ``vap_head``, ``va_classifier``,
+  ``objective.probs_next_speaker_aggregate``; SURVEY.md §8b level 1), torch CUDA tensors in/out.
+* ``ManyStreamVAP`` — the many-stream front object (what the reference lacks: it serves exactly one
+  stream per process, vap_main.py:354-366): S independent dialogue streams per GPU, one
+  ``process(frames)`` call per tick.
+
+No CPU fallback anywhere: constructing any of these without libvapx.so / a gfx950 GPU raises.
+"""
+from __future__ import annotations
+
+import time
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import engine as _engine
+from . import weights as _weights
+
+BINS_P_NOW = [0, 1]       # vap_main.py:187
+BINS_PFUTURE = [2, 3]     # vap_main.py:188
+
+
+def _load_state_dicts(vap_model, cpc_model):
+    """Accept paths (torch.load like vap_main.py:199 / encoder_components.py:372) or ready dicts."""
+    if isinstance(vap_model, (str, bytes)) or hasattr(vap_model, "__fspath__"):
+        import torch
+        vap_sd = torch.load(vap_model, map_location="cpu")
+    else:
+        vap_sd = vap_model
+    if isinstance(cpc_model, (str, bytes)) or hasattr(cpc_model, "__fspath__"):
+        import torch
+        cpc_sd = torch.load(cpc_model, map_location="cpu")
+    else:
+        cpc_sd = cpc_model
+    if "weights" in cpc_sd:                      # load_CPC uses checkpoint["weights"]
+        cpc_sd = cpc_sd["weights"]
+    return cpc_sd, vap_sd
+
+
+class VAPRealTime:
+    """One stream, reference-compatible.  ``mode``: "vap" | "bc" | "nod"."""
+
+    BINS_P_NOW = BINS_P_NOW
+    BINS_PFUTURE = BINS_PFUTURE
+    CALC_PROCESS_TIME_INTERVAL = 100
+
+    def __init__(self, vap_model, cpc_model, device=None, frame_rate: int = 20, context_len_sec: float = 2.5,
+                 mode: str = "vap"):
+        cpc_sd, vap_sd = _load_state_dicts(vap_model, cpc_model)
+        self.mode = mode
+        self.device = device
+        dev_id = 0
+        if device is not None and getattr(device, "index", None) is not None:
+            dev_id = int(device.index)
+        if device is not None and str(device).startswith("cpu"):
+            raise _engine.VapxError("vap-realtime_amd has no CPU path; pass a cuda device (MI355X)")
+        self.engine = _engine.Engine(_weights.pack_blob(cpc_sd, vap_sd, mode), frame_rate, context_len_sec,
+                                     max_streams=1, mode=mode, device_id=dev_id)
+        self.audio_contenxt_lim_sec = context_len_sec
+        self.frame_rate = frame_rate
+        self.audio_context_len = int(context_len_sec * frame_rate)
+        self.sampling_rate = 16000
+        self.frame_contxt_padding = 320
+        self.audio_frame_size = self.sampling_rate // frame_rate + self.frame_contxt_padding
+        self.current_x1_audio: list = []
+        self.current_x2_audio: list = []
+        self.result_p_now = 0.
+        self.result_p_future = 0.
+        self.result_last_time = -1
+        self.result_vad = [0., 0.]
+        self.result_p_bc_react = 0.
+        self.result_p_bc_emo = 0.
+        self.result_p_bc = 0.
+        self.result_p_nod_short = 0.
+        self.result_p_nod_long = 0.
+        self.result_p_nod_long_p = 0.
+        self.result_logits = None
+        self.process_time_abs = -1
+        self.list_process_time_context: List[float] = []
+        self.last_interval_time = time.time()
+
+    def process_vap(self, x1, x2):
+        """x1, x2: list or ndarray of ``audio_frame_size`` samples (carry included), exactly what the
+        reference's proc_serv_in / vap_offline hand over (vap_main.py:402-405, vap_offline.py:51-61)."""
+        time_start = time.time()
+        self.current_x1_audio = x1[self.frame_contxt_padding:]
+        self.current_x2_audio = x2[self.frame_contxt_padding:]
+        frame = np.stack([np.asarray(x1, dtype=np.float32), np.asarray(x2, dtype=np.float32)])[None]
+        if frame.shape[2] != self.audio_frame_size:
+            raise ValueError(f"expected {self.audio_frame_size} samples per channel, got {frame.shape[2]}")
+        o = _engine.split_outputs(self.engine.step(frame))
+        if self.mode == "vap":
+            self.result_p_now = [float(v) for v in o["p_now"][0]]
+            self.result_p_future = [float(v) for v in o["p_future"][0]]
+            self.result_vad = [float(o["vad"][0, 0]), float(o["vad"][0, 1])]
+            self.result_logits = o["logits"][0].copy()
+        elif self.mode == "bc":
+            self.result_p_bc_react = [float(o["aux"][0, 1])]
+            self.result_p_bc_emo = [float(o["aux"][0, 2])]
+        else:
+            self.result_p_nod_short = [float(o["aux"][0, 1])]
+            self.result_p_nod_long = [float(o["aux"][0, 2])]
+            self.result_p_nod_long_p = [float(o["aux"][0, 3])]
+        self.result_last_time = time.time()
+        self.list_process_time_context.append(time.time() - time_start)
+        if len(self.list_process_time_context) > self.CALC_PROCESS_TIME_INTERVAL:
+            ave = float(np.average(self.list_process_time_context))
+            fps = len(self.list_process_time_context) / (time.time() - self.last_interval_time)
+            self.last_interval_time = time.time()
+            print('[VAP] Average processing time: %.5f [sec], #process/sec: %.3f' % (ave, fps))
+            self.list_process_time_context = []
+        self.process_time_abs = time.time()
+
+    def get_result(self) -> Dict:
+        """Library-twin result dict (vap_realtime/model.py:189-194)."""
+        return {"t": self.result_last_time, "x1": self.current_x1_audio, "x2": self.current_x2_audio,
+                "p_now": self.result_p_now, "p_future": self.result_p_future, "vad": self.result_vad}
+
+
+class ManyStreamVAP:
+    """S independent streams on one GPU.  ``process(new_samples[, stream_ids])`` = one tick."""
+
+    def __init__(self, cpc_sd, vap_sd, frame_rate: int = 20, context_len_sec: float = 2.5, n_streams: int = 256,
+                 max_batch: Optional[int] = None, mode: str = "vap", device_id: int = 0):
+        self.engine = _engine.Engine(_weights.pack_blob(cpc_sd, vap_sd, mode), frame_rate, context_len_sec,
+                                     max_streams=n_streams, max_batch=max_batch, mode=mode, device_id=device_id)
+        self.n_streams = n_streams
+        self.hop = 16000 // frame_rate
+        self.mode = mode
+
+    def process(self, new_samples: np.ndarray, stream_ids: Optional[Sequence[int]] = None) -> Dict[str, np.ndarray]:
+        """new_samples float [n,2,hop] (or [n,2,hop+320] complete frames) -> dict of [n,...] arrays."""
+        return _engine.split_outputs(self.engine.step(new_samples, stream_ids))
+
+    def reset(self, stream_id: int):
+        self.engine.reset_stream(stream_id)
+
+
+# ------------------------------------------------------------------------------------------------
+# level-1 surface: what VAPRealTime.process_vap calls on self.vap (vap_main.py:272-307)
+# ------------------------------------------------------------------------------------------------
+class _Objective:
+    def probs_next_speaker_aggregate(self, probs, from_bin: int = 0, to_bin: int = 3, scale_with_bins: bool = False):
+        """objective.py:186-206 on a torch tensor [B,n,256] (device-side, tiny)."""
+        import torch
+        idx = torch.arange(256, device=probs.device)
+        bits = ((idx[:, None] >> torch.arange(8, device=probs.device)[None, :]) & 1).to(probs.dtype).view(256, 2, 4)
+        abp = bits[:, :, from_bin:to_bin + 1].sum(-1)
+        p_all = torch.einsum("bid,dc->bic", probs, abp)
+        return p_all / (p_all.sum(-1, keepdim=True) + 1e-5)
+
+
+class VapGPT:
+    """``self.vap`` replacement: torch CUDA tensors in/out, HIP kernels inside (stage-level C ABI)."""
+
+    def __init__(self, cpc_sd, vap_sd, frame_rate: int = 20, context_len_sec: float = 2.5, max_batch: int = 1,
+                 mode: str = "vap", device_id: int = 0):
+        import torch
+        self._torch = torch
+        self.engine = _engine.Engine(_weights.pack_blob(cpc_sd, vap_sd, mode), frame_rate, context_len_sec,
+                                     max_streams=max_batch, mode=mode, device_id=device_id)
+        self.device = torch.device("cuda", device_id)
+        self.objective = _Objective()
+        f = lambda k: torch.as_tensor(np.asarray(vap_sd[k], dtype=np.float32)).to(self.device)
+        self._head_w, self._head_b = f("vap_head.weight"), f("vap_head.bias")
+        self._va_w, self._va_b = f("va_classifier.weight"), f("va_classifier.bias")
+
+    def to(self, device):
+        return self
+
+    def eval(self):
+        return self
+
+    def _stream(self):
+        return self._torch.cuda.current_stream().cuda_stream
+
+    def encode_audio(self, audio1, audio2):
+        """[B,1,L] x2 -> ([B,1,256], [B,1,256]); stateful LSTM like EncoderCPC (vap_main.py:175-180)."""
+        torch = self._torch
+        B = audio1.shape[0]
+        frames = torch.stack([audio1.reshape(B, -1), audio2.reshape(B, -1)], dim=1).float().contiguous()
+        e = torch.empty(B, 2, 256, device=self.device)
+        self.engine.encode_audio_device(B, frames.data_ptr(), e.data_ptr(), stream=self._stream())
+        return e[:, 0:1].contiguous(), e[:, 1:2].contiguous()
+
+    def ar_channel(self, x, attention: bool = False):
+        """GPT.forward (1 self-attention layer), [B,n,256] -> {"x": [B,n,256]} (vap_main.py:285-286)."""
+        torch = self._torch
+        B, n, _ = x.shape
+        xin = torch.stack([x, x], dim=1).float().contiguous()        # the towers share weights
+        o = torch.empty(B, 2, n, 256, device=self.device)
+        self.engine.transformer_device(B, n, xin.data_ptr(), o_ptr=o.data_ptr(), stage=1, stream=self._stream())
+        return {"x": o[:, 0].contiguous()}
+
+    def ar(self, x1, x2, attention: bool = False):
+        """GPTStereo.forward (3 self+cross layers + Combinator) (vap_main.py:287)."""
+        torch = self._torch
+        B, n, _ = x1.shape
+        xin = torch.stack([x1, x2], dim=1).float().contiguous()
+        x12 = torch.empty(B, 2, n, 256, device=self.device)
+        comb = torch.empty(B, n, 256, device=self.device)
+        self.engine.transformer_device(B, n, xin.data_ptr(), x12_ptr=x12.data_ptr(), comb_ptr=comb.data_ptr(), stage=2,
+                                       stream=self._stream())
+        return {"x": comb, "x1": x12[:, 0].contiguous(), "x2": x12[:, 1].contiguous()}
+
+    def vap_head(self, t):
+        return self._torch.nn.functional.linear(t, self._head_w, self._head_b)
+
+    def va_classifier(self, t):
+        return self._torch.nn.functional.linear(t, self._va_w, self._va_b)
