@@ -55,6 +55,11 @@ extern "C" {
 #define VAPX_OUT_DEVICE 2
 #define VAPX_IDS_DEVICE 4 /* stream_ids points to device memory (default: host) */
 
+/* vapx_config.flags */
+#define VAPX_FLAG_GROUPS_MASK 0xF     /* bits 0-3: intra-tick overlap groups (0 = default 1 = none, max 8) */
+#define VAPX_FLAG_FULL_LAST_LAYER 16  /* compute every row of the last layer (default: only the newest row,
+                                         which is all process_vap consumes; needed to vapx_peek "stereo2") */
+
 /* Layout of one output row (floats).  Row stride is VAPX_OUT_STRIDE. */
 #define VAPX_OUT_P_NOW 0     /* [2]  result_p_now        vap_main.py:316 */
 #define VAPX_OUT_P_FUTURE 2  /* [2]  result_p_future     vap_main.py:317 */
@@ -75,7 +80,7 @@ typedef struct vapx_config {
   int32_t max_streams;  /* stream slots whose state lives in HBM */
   int32_t max_batch;    /* max streams per vapx_step call (sizes scratch) */
   int32_t mode;         /* VAPX_MODE_* */
-  int32_t flags;        /* bits 0-3: intra-tick overlap groups (0 = default 1 = none, max 8) */
+  int32_t flags;        /* VAPX_FLAG_* */
 } vapx_config;
 
 /* Number of floats the weight blob must have for a frame rate (layout:
@@ -146,7 +151,8 @@ int vapx_gemm(void* hip_stream, int32_t M, int32_t N, int32_t K, const float* A,
               float* C2, int32_t tile_rows);
 
 /* Per-kernel-class timing with HIP events recorded on the launch stream (bench.py's roofline leg).
- * class ids: 0..5 = the GEMM by epilogue (same numbering as vapx_gemm's epi), 8 conv0, 9 lstm,
+ * class ids: 0..5 = the GEMM by epilogue (same numbering as vapx_gemm's epi), 6 fused FFN block,
+ * 7 last-row path of the final layer, 8 conv0, 9 lstm,
  * 10 ring gather+LN, 11 attention, 12 heads.  enable(mask) selects classes (0 = off);
  * read() synchronises the device, sums the elapsed time and launch count per class since the
  * last read into total_ms[n_classes] / launches[n_classes], and recycles the events. */

@@ -52,7 +52,7 @@ def test_intermediates_match_reference():
     """Per-stage buffers of selected frames (CNN, LSTM, each transformer layer) vs hooks on the
     reference modules."""
     c = Case("vap20")
-    eng = make_engine(c)
+    eng = make_engine(c, full_last_layer=True)
     z = c.z
     inter_frames = sorted({int(k.split(".")[1][1:]) for k in z.files if k.startswith("inter.f")})
     for f in range(max(inter_frames) + 1):
@@ -71,6 +71,17 @@ def test_intermediates_match_reference():
             want = z[f"inter.f{f}.{key}"]
             np.testing.assert_allclose(got, want, rtol=3e-5, atol=1e-3, err_msg=f"frame {f} {key}")
     eng.close()
+
+
+def test_pruned_last_layer_equals_full_last_layer():
+    """Default path computes only the newest row of the last layer; it must agree with the
+    full-layer path (VAPX_FLAG_FULL_LAST_LAYER) far below the parity tolerance."""
+    c = Case("multi3")
+    a, b = make_engine(c), make_engine(c, full_last_layer=True)
+    for oa, ob in zip(run_engine(c, a), run_engine(c, b)):
+        for k in ("p_now", "p_future", "vad", "logits"):
+            np.testing.assert_allclose(oa[k], ob[k], rtol=0, atol=2e-5)
+    a.close(); b.close()
 
 
 def test_engine_equals_oracle_on_fresh_inputs():

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/vapx.h"
+#include "fused_blocks.h"
 #include "gemm_f32.h"
 #include "vap_kernels.h"
 #include "vapx_layout.h"
@@ -32,6 +33,7 @@ struct Scratch {
   float *h0 = nullptr, *h1 = nullptr, *h2 = nullptr, *h3 = nullptr, *z = nullptr, *gx = nullptr, *lstm_out = nullptr, *e = nullptr;
   float* xl[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // layer inputs/outputs: x0, o, stereo0..2
   float *xn = nullptr, *xmid = nullptr, *att = nullptr, *qkv = nullptr, *qx = nullptr, *kvx = nullptr, *ffn = nullptr;
+  float* last[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [B*2][256] each: x, xn, q, att, xmid, out (last-row path)
   Scratch slice(size_t b0, const int* P, int ncpc, int T) const {
     Scratch s = *this;
     const size_t bc = b0 * 2, rows = bc * T;
@@ -41,6 +43,7 @@ struct Scratch {
     for (int i = 0; i < 5; ++i) s.xl[i] += rows * 256;
     s.xn += rows * 256; s.xmid += rows * 256; s.att += rows * 256; s.qkv += rows * 768; s.qx += rows * 256;
     s.kvx += rows * 512; s.ffn += rows * 768;
+    for (int i = 0; i < 6; ++i) s.last[i] += bc * 256;
     return s;
   }
 };
@@ -137,7 +140,7 @@ void geometry(int hz, int* hop, int* L, int P[5], int* ncpc) {
 }
 
 // kernel classes for profiling: 0..5 = GEMM by epilogue, then the rest
-enum { CLS_CONV0 = 8, CLS_LSTM = 9, CLS_GATHER = 10, CLS_ATTN = 11, CLS_HEAD = 12, CLS_COUNT = 13 };
+enum { CLS_FFN = 6, CLS_LASTROW = 7, CLS_CONV0 = 8, CLS_LSTM = 9, CLS_GATHER = 10, CLS_ATTN = 11, CLS_HEAD = 12, CLS_COUNT = 13 };
 
 struct ProfScope {
   vapx_engine* h; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; int cls;
@@ -225,18 +228,31 @@ int run_encoder(vapx_engine* h, const Scratch& sc, const StateView& sv, int B, c
   return VAPX_OK;
 }
 
-// ---- 1 self + 3 self/cross layers on x0 = xl[0] (LN_self(L0) already in xn) ---------------------
-int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_begin = 0, int l_end = 4) {
+// ---- 1 self + 3 self/cross layers on x0 = xl[l_begin] (LN_self already in xn) ---------------------
+// Per layer: [QKV (+cross KV) projections] -> self-attention -> proj+residual+LN -> (cross: q GEMM,
+// cross-attention, proj+residual+LN) -> fused FFN block, which also emits the NEXT layer's
+// projections so that only the first executed layer needs stand-alone projection GEMMs.
+int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_begin = 0, int l_end = 4,
+               bool prune_last = false) {
   const int T = h->T;
   const int M = B * 2 * T;
   const RowMap r256 = contiguous_rows(256), r768 = contiguous_rows(768), r512 = contiguous_rows(512);
-  for (int l = l_begin; l < l_end; ++l) {
+  if (prune_last && (l_end != 4 || l_begin > 2)) prune_last = false;
+  const int l_full_end = prune_last ? 3 : l_end;
+  for (int l = l_begin; l < l_full_end; ++l) {
     const Layer& Lw = h->layer[l];
     const float* xin = sc.xl[l];
     float* xout = sc.xl[l + 1];
+    GemmArgs g;
+    if (l == l_begin) {
+      g = gemm_args(sc.xn, r256, Lw.wqkv, M, 768, 256, sc.qkv, r768);
+      HIPCHK(h, gemm(h, g, EPI_STORE, st));
+      if (l > 0) {
+        g = gemm_args(xin, r256, Lw.wkv_x, M, 512, 256, sc.kvx, r512);
+        HIPCHK(h, gemm(h, g, EPI_STORE, st));
+      }
+    }
     // self attention
-    GemmArgs g = gemm_args(sc.xn, r256, Lw.wqkv, M, 768, 256, sc.qkv, r768);
-    HIPCHK(h, gemm(h, g, EPI_STORE, st));
     AttnArgs aa{sc.qkv, sc.qkv + 256, sc.qkv + 512, sc.att, sc.bn, T, 768, 768, 0};
     { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attention(aa, B, st)); }
     g = gemm_args(sc.att, r256, Lw.wproj, M, 256, 256, sc.xmid, r256);
@@ -248,25 +264,53 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
       // cross attention: Q from LN_src(x), K/V from the OTHER channel's raw layer input
       g = gemm_args(sc.xn, r256, Lw.wq_x, M, 256, 256, sc.qx, r256);
       HIPCHK(h, gemm(h, g, EPI_STORE, st));
-      g = gemm_args(xin, r256, Lw.wkv_x, M, 512, 256, sc.kvx, r512);
-      HIPCHK(h, gemm(h, g, EPI_STORE, st));
       AttnArgs ax{sc.qx, sc.kvx, sc.kvx + 256, sc.att, sc.bn, T, 256, 512, 1};
       { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attention(ax, B, st)); }
       g = gemm_args(sc.att, r256, Lw.wproj_x, M, 256, 256, sc.xmid, r256);
       g.resid = sc.xmid; g.C2 = sc.xn; g.gamma = Lw.ln_ffn_g; g.beta = Lw.ln_ffn_b;
       HIPCHK(h, gemm(h, g, EPI_RESID_LN, st));
     }
-    // feed-forward
-    g = gemm_args(sc.xn, r256, Lw.w0, M, 768, 256, sc.ffn, r768);
-    HIPCHK(h, gemm(h, g, EPI_GELU, st));
-    g = gemm_args(sc.ffn, r768, Lw.w3, M, 256, 768, xout, r256);
-    g.resid = sc.xmid;
-    if (l < 3) {
-      g.C2 = sc.xn; g.gamma = h->layer[l + 1].ln_self_g; g.beta = h->layer[l + 1].ln_self_b;
-      HIPCHK(h, gemm(h, g, EPI_RESID_LN, st));
-    } else {
-      HIPCHK(h, gemm(h, g, EPI_RESID, st));
+    // feed-forward (+ next layer's projections)
+    FfnArgs fa;
+    memset(&fa, 0, sizeof fa);
+    fa.xn = sc.xn; fa.xmid = sc.xmid; fa.w0 = Lw.w0; fa.w3 = Lw.w3; fa.xout = xout; fa.M = M;
+    if (l + 1 < l_end) {
+      const Layer& Ln = h->layer[l + 1];
+      fa.ln_g = Ln.ln_self_g; fa.ln_b = Ln.ln_self_b; fa.wqkv = Ln.wqkv; fa.qkv = sc.qkv; fa.n_qkv = 768;
+      fa.wkvx = Ln.wkv_x; fa.kvx = sc.kvx;
+      if (prune_last && l + 1 == 3) {   // the pruned layer needs K,V of every row but Q of one row only
+        fa.wqkv = Ln.wqkv + 256 * 256; fa.n_qkv = 512;
+      }
     }
+    { ProfScope ps(h, CLS_FFN, st); HIPCHK(h, launch_ffn_block(fa, st)); }
+  }
+  if (prune_last) {
+    // ---- layer 3 on the newest row of every (stream, channel) only; K/V (all rows) came from the
+    //      previous layer's FFN block: sc.qkv = [K | V] [M][512], sc.kvx = cross [K | V] [M][512] ----
+    const Layer& Lw = h->layer[3];
+    const int Ml = B * 2;
+    float *lx = sc.last[0], *lxn = sc.last[1], *lq = sc.last[2], *latt = sc.last[3], *lxmid = sc.last[4], *lout = sc.last[5];
+    ProfScope ps(h, CLS_LASTROW, st);
+    LastRowArgs lr{sc.xl[3], sc.bn, lx, lxn, Lw.ln_self_g, Lw.ln_self_b, B, T};
+    HIPCHK(h, launch_gather_last_ln(lr, st));
+    GemmArgs g = gemm_args(lxn, r256, Lw.wqkv, Ml, 256, 256, lq, r256);            // Q rows of Wqkv
+    HIPCHK(h, launch_gemm_f32(g, EPI_STORE, 0, st));
+    AttnArgs aa{lq, sc.qkv, sc.qkv + 256, latt, sc.bn, T, 256, 512, 0};
+    HIPCHK(h, launch_attention_last(aa, B, st));
+    g = gemm_args(latt, r256, Lw.wproj, Ml, 256, 256, lxmid, r256);
+    g.resid = lx; g.C2 = lxn; g.gamma = Lw.ln_src_g; g.beta = Lw.ln_src_b;
+    HIPCHK(h, launch_gemm_f32(g, EPI_RESID_LN, 0, st));
+    g = gemm_args(lxn, r256, Lw.wq_x, Ml, 256, 256, lq, r256);
+    HIPCHK(h, launch_gemm_f32(g, EPI_STORE, 0, st));
+    AttnArgs ax{lq, sc.kvx, sc.kvx + 256, latt, sc.bn, T, 256, 512, 1};
+    HIPCHK(h, launch_attention_last(ax, B, st));
+    g = gemm_args(latt, r256, Lw.wproj_x, Ml, 256, 256, lxmid, r256);
+    g.resid = lxmid; g.C2 = lxn; g.gamma = Lw.ln_ffn_g; g.beta = Lw.ln_ffn_b;
+    HIPCHK(h, launch_gemm_f32(g, EPI_RESID_LN, 0, st));
+    FfnArgs fa;
+    memset(&fa, 0, sizeof fa);
+    fa.xn = lxn; fa.xmid = lxmid; fa.w0 = Lw.w0; fa.w3 = Lw.w3; fa.xout = lout; fa.M = Ml;
+    HIPCHK(h, launch_ffn_block(fa, st));
   }
   return VAPX_OK;
 }
@@ -319,10 +363,11 @@ int step_group(vapx_engine* h, const Scratch& sc, int nb, int b0, const int* ids
   ga.x0 = sc.xl[0]; ga.xn = sc.xn; ga.gamma = h->layer[0].ln_self_g; ga.beta = h->layer[0].ln_self_b;
   ga.B = nb; ga.T = h->T; ga.rows_in = 0;
   { ProfScope ps(h, CLS_GATHER, st); HIPCHK(h, launch_gather_ln(ga, st)); }
-  rc = run_layers(h, sc, nb, st);
+  const bool prune = !(h->cfg.flags & VAPX_FLAG_FULL_LAST_LAYER);
+  rc = run_layers(h, sc, nb, st, 0, 4, prune);
   if (rc) return rc;
   HeadArgs ha;
-  ha.x = sc.xl[4]; ha.o = sc.xl[1]; ha.e = sc.e; ha.bn = sc.bn; ha.ids = ids; ha.frames_seen = sv.frames_seen;
+  ha.x = prune ? sc.last[5] : sc.xl[4]; ha.x_last_only = prune ? 1 : 0; ha.o = sc.xl[1]; ha.e = sc.e; ha.bn = sc.bn; ha.ids = ids; ha.frames_seen = sv.frames_seen;
   ha.waT = h->W("comb.waT"); ha.wbT = h->W("comb.wbT"); ha.cg = h->W("comb.g"); ha.cb = h->W("comb.b");
   ha.hwT = h->W("head.wT"); ha.hb = h->W("head.b"); ha.vw = h->W("vad.w"); ha.vb = h->W("vad.b");
   ha.aw = h->W("aux.w"); ha.ab = h->W("aux.b"); ha.out = out; ha.B = nb; ha.T = h->T; ha.mode = h->cfg.mode;
@@ -355,7 +400,8 @@ void vapx_destroy(vapx_handle h) {
   (void)hipDeviceSynchronize();
   float* fp[] = {h->w, h->ring, h->h_state, h->c_state, h->carry, h->audio_dev, h->out_dev, h->sc.h0, h->sc.h1, h->sc.h2, h->sc.h3,
                  h->sc.z, h->sc.lstm_out, h->sc.e, h->sc.xl[0], h->sc.xl[1], h->sc.xl[2], h->sc.xl[3], h->sc.xl[4], h->sc.xn, h->sc.xmid, h->sc.att,
-                 h->sc.qkv, h->sc.qx, h->sc.kvx, h->sc.ffn, h->sc.gx};
+                 h->sc.qkv, h->sc.qx, h->sc.kvx, h->sc.ffn, h->sc.gx, h->sc.last[0], h->sc.last[1], h->sc.last[2],
+                 h->sc.last[3], h->sc.last[4], h->sc.last[5]};
   for (float* p : fp)
     if (p) (void)hipFree(p);
   int* ip[] = {h->frames_seen, h->ids_dev, h->sc.bn, h->sc.bhead};
@@ -452,6 +498,7 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
   CR(dalloc(&h->sc.qx, rows * 256));
   CR(dalloc(&h->sc.kvx, rows * 512));
   CR(dalloc(&h->sc.ffn, rows * 768));
+  for (int i = 0; i < 6; ++i) CR(dalloc(&h->sc.last[i], B * 2 * 256));
   CR(hipHostMalloc((void**)&h->out_pinned, B * VAPX_OUT_STRIDE * sizeof(float), hipHostMallocDefault));
   CR(hipHostMalloc((void**)&h->ids_pinned, B * sizeof(int), hipHostMallocDefault));
   h->n_groups = cfg->flags & 0xF;

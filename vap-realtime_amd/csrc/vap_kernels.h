@@ -50,8 +50,18 @@ struct AttnArgs {
   int T, ldq, ldkv, swap_kv;
 };
 
+struct LastRowArgs {
+  const float* x;       // [B*2][T][256]
+  const int* bn;
+  float* xlast;         // [B*2][256] row n-1 of every (stream, channel)
+  float* xnlast;        // LayerNorm(xlast; gamma, beta)
+  const float* gamma;
+  const float* beta;
+  int B, T;
+};
+
 struct HeadArgs {
-  const float* x;       // [B*2][T][256] stereo tower outputs (a = ch 0, b = ch 1)
+  const float* x;       // [B*2][T][256] stereo tower outputs (a = ch 0, b = ch 1); [B*2][256] if x_last_only
   const float* o;       // [B*2][T][256] ar_channel outputs
   const float* e;       // [B*2][256]
   const int* bn;
@@ -68,11 +78,13 @@ struct HeadArgs {
   const float* aw;      // [8][256]
   const float* ab;      // [8]
   float* out;           // [B][out_stride]
-  int B, T, mode, out_stride;
+  int B, T, mode, out_stride, x_last_only;
 };
 
 hipError_t launch_conv0(const Conv0Args& a, int B, hipStream_t st);
 hipError_t launch_lstm(const LstmArgs& a, hipStream_t st);
 hipError_t launch_gather_ln(const GatherArgs& a, hipStream_t st);
 hipError_t launch_attention(const AttnArgs& a, int B, hipStream_t st);
+hipError_t launch_gather_last_ln(const LastRowArgs& a, hipStream_t st);
+hipError_t launch_attention_last(const AttnArgs& a, int B, hipStream_t st);
 hipError_t launch_head(const HeadArgs& a, hipStream_t st);

@@ -352,6 +352,68 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// 4b. last-row path of the final layer.  Only the newest row of the last stereo layer reaches the
+//     heads (vap_main.py:316-317 takes [-1]); its K/V still need every row, but Q, the attention
+//     output, both projections and the FFN are needed for ONE row per (stream, channel).  Exact.
+// ------------------------------------------------------------------------------------------------
+// gather row n-1 of every (stream, channel) and LayerNorm it: one wave per (b,c)
+__global__ __launch_bounds__(256) void gather_last_ln_kernel(LastRowArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int bc = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bc >= a.B * 2) return;
+  const int n = a.bn[bc >> 1];
+  f32x4 v = *(const f32x4*)(a.x + ((long)bc * a.T + n - 1) * 256 + lane * 4);
+  *(f32x4*)(a.xlast + (long)bc * 256 + lane * 4) = v;
+  float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+  f32x4 d = v - mean;
+  float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.0f / 256.0f);
+  float rstd = rsqrtf(var + 1e-5f);
+  f32x4 g = *(const f32x4*)(a.gamma + lane * 4), be = *(const f32x4*)(a.beta + lane * 4);
+  *(f32x4*)(a.xnlast + (long)bc * 256 + lane * 4) = d * rstd * g + be;
+}
+
+// single-query attention: query = newest row (index n-1, so every key j < n is causal-visible),
+// one workgroup per (stream, channel), one wave per head.  Phase 1: lane = key j computes the
+// score; softmax across lanes; phase 2: lane = feature d accumulates sum_j p_j V[j][d].
+__global__ __launch_bounds__(256) void attention_last_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float sq[4][64];
+  __shared__ float sp[4][64];
+  const int bc = blockIdx.x, b = bc >> 1, h = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = a.bn[b], T = a.T;
+  const int kvbc = a.swap_kv ? (bc ^ 1) : bc;
+  sq[h][lane] = a.q[(long)bc * a.ldq + h * 64 + lane] * 0.0625f;
+  __syncthreads();
+  const float slope = exp2f(-2.0f * (float)(h + 1));
+  const float* kp = a.k + (long)kvbc * T * a.ldkv + h * 64;
+  const float* vp = a.v + (long)kvbc * T * a.ldkv + h * 64;
+  float mx = -1e30f, l = 0.f, o = 0.f;
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int j = j0 + lane;
+    float sc = -1e30f;
+    if (j < n) {
+      const f32x4* kr = (const f32x4*)(kp + (long)j * a.ldkv);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 16; ++c) acc += kr[c] * *(const f32x4*)&sq[h][c * 4];
+      sc = (acc[0] + acc[1]) + (acc[2] + acc[3]) + slope * (float)j;
+    }
+    const float mn = fmaxf(mx, wave_max(sc));
+    const float pj = j < n ? expf(sc - mn) : 0.f;
+    const float corr = expf(mx - mn);
+    l = l * corr + wave_sum(pj);
+    o *= corr;
+    mx = mn;
+    sp[h][lane] = pj;
+    __builtin_amdgcn_s_waitcnt(0);   // sp is private to this wave; LDS write -> read by other lanes
+    __builtin_amdgcn_wave_barrier();
+    const int jn = (n - j0) < 64 ? (n - j0) : 64;
+    for (int jj = 0; jj < jn; ++jj) o += sp[h][jj] * vp[(long)(j0 + jj) * a.ldkv + lane];
+    __builtin_amdgcn_wave_barrier();
+  }
+  a.out[(long)bc * 256 + h * 64 + lane] = o / l;
+}
+
+// ------------------------------------------------------------------------------------------------
 // 5. Combinator + heads on the newest row of each stream
 //    reference: Combinator.forward modules.py:449-464; vap_head / va_classifier / softmax
 //    vap_main.py:290-295,313-314; probs_next_speaker_aggregate objective.py:186-206;
@@ -400,7 +462,8 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
     b = b < a.B ? b : a.B - 1;
     nb[s] = a.bn[b];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) xs[s][c][j] = a.x[(((long)b * 2 + c) * a.T + nb[s] - 1) * 256 + j];
+    for (int c = 0; c < 2; ++c)
+      xs[s][c][j] = a.x_last_only ? a.x[((long)b * 2 + c) * 256 + j] : a.x[(((long)b * 2 + c) * a.T + nb[s] - 1) * 256 + j];
   }
   __syncthreads();
   // combinator projections
@@ -565,6 +628,14 @@ hipError_t launch_attention(const AttnArgs& a, int B, hipStream_t st) {
   if (n_tiles <= 2) hipLaunchKernelGGL(attention_mfma_kernel<2>, dim3(B * 2 * 4), dim3(64 * nw), lds, st, a);
   else if (n_tiles <= 8) hipLaunchKernelGGL(attention_mfma_kernel<8>, dim3(B * 2 * 4), dim3(64 * nw), lds, st, a);
   else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+hipError_t launch_gather_last_ln(const LastRowArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(gather_last_ln_kernel, dim3((a.B * 2 + 3) / 4), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_attention_last(const AttnArgs& a, int B, hipStream_t st) {
+  hipLaunchKernelGGL(attention_last_kernel, dim3(B * 2), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_head(const HeadArgs& a, hipStream_t st) {

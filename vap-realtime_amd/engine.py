@@ -25,7 +25,7 @@ EXPORTS = ("vapx_abi_version", "vapx_blob_floats", "vapx_create", "vapx_destroy"
            "vapx_transformer", "vapx_peek", "vapx_gemm", "vapx_last_error", "vapx_profile_enable",
            "vapx_profile_read")
 PROF_CLASSES = {0: "gemm_store", 1: "gemm_gelu", 2: "gemm_resid", 3: "gemm_resid_ln", 4: "gemm_cn_relu",
-                5: "gemm_bias_ln_gelu", 8: "conv0", 9: "lstm", 10: "gather_ln", 11: "attention", 12: "head"}
+                5: "gemm_bias_ln_gelu", 6: "ffn_block", 7: "last_row", 8: "conv0", 9: "lstm", 10: "gather_ln", 11: "attention", 12: "head"}
 
 
 class VapxError(RuntimeError):
@@ -103,7 +103,7 @@ class Engine:
     (``weights.pack_blob``)."""
 
     def __init__(self, blob: np.ndarray, frame_hz: int = 20, context_len_sec: float = 2.5,
-                 max_streams: int = 1, max_batch: Optional[int] = None, mode: str = "vap", device_id: int = 0, groups: int = 0):
+                 max_streams: int = 1, max_batch: Optional[int] = None, mode: str = "vap", device_id: int = 0, groups: int = 0, full_last_layer: bool = False):
         self.lib = load_library()
         self.frame_hz = frame_hz
         self.T = int(context_len_sec * frame_hz)           # vap_main.py:221
@@ -114,7 +114,7 @@ class Engine:
         self.mode = mode
         self.device_id = device_id
         blob = np.ascontiguousarray(blob, dtype=np.float32)
-        cfg = _Config(C.sizeof(_Config), device_id, frame_hz, self.T, max_streams, self.max_batch, MODE[mode], groups & 0xF)
+        cfg = _Config(C.sizeof(_Config), device_id, frame_hz, self.T, max_streams, self.max_batch, MODE[mode], (groups & 0xF) | (16 if full_last_layer else 0))
         h = C.c_void_p()
         rc = self.lib.vapx_create(C.byref(cfg), _np_ptr(blob), blob.size, C.byref(h))
         if rc != 0:
