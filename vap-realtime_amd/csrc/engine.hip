@@ -24,6 +24,7 @@ struct Layer {
   const float *ln_self_g, *ln_self_b, *wqkv, *wproj;
   const float *ln_src_g, *ln_src_b, *wq_x, *wkv_x, *wproj_x;
   const float *ln_ffn_g, *ln_ffn_b, *w0, *w3;
+  const float *w0f, *w3f, *wqkvf, *wkvxf;   // fragment-major copies (fused FFN block)
 };
 
 }  // namespace
@@ -273,13 +274,13 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
     // feed-forward (+ next layer's projections)
     FfnArgs fa;
     memset(&fa, 0, sizeof fa);
-    fa.xn = sc.xn; fa.xmid = sc.xmid; fa.w0 = Lw.w0; fa.w3 = Lw.w3; fa.xout = xout; fa.M = M;
+    fa.xn = sc.xn; fa.xmid = sc.xmid; fa.w0f = Lw.w0f; fa.w3f = Lw.w3f; fa.xout = xout; fa.M = M;
     if (l + 1 < l_end) {
       const Layer& Ln = h->layer[l + 1];
-      fa.ln_g = Ln.ln_self_g; fa.ln_b = Ln.ln_self_b; fa.wqkv = Ln.wqkv; fa.qkv = sc.qkv; fa.n_qkv = 768;
-      fa.wkvx = Ln.wkv_x; fa.kvx = sc.kvx;
+      fa.ln_g = Ln.ln_self_g; fa.ln_b = Ln.ln_self_b; fa.wqkvf = Ln.wqkvf; fa.qkv = sc.qkv; fa.n_qkv_chunks = 3;
+      fa.wkvxf = Ln.wkvxf; fa.kvx = sc.kvx;
       if (prune_last && l + 1 == 3) {   // the pruned layer needs K,V of every row but Q of one row only
-        fa.wqkv = Ln.wqkv + 256 * 256; fa.n_qkv = 512;
+        fa.wqkvf = Ln.wqkvf + 65536; fa.n_qkv_chunks = 2;
       }
     }
     { ProfScope ps(h, CLS_FFN, st); HIPCHK(h, launch_ffn_block(fa, st)); }
@@ -309,7 +310,7 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
     HIPCHK(h, launch_gemm_f32(g, EPI_RESID_LN, 0, st));
     FfnArgs fa;
     memset(&fa, 0, sizeof fa);
-    fa.xn = lxn; fa.xmid = lxmid; fa.w0 = Lw.w0; fa.w3 = Lw.w3; fa.xout = lout; fa.M = Ml;
+    fa.xn = lxn; fa.xmid = lxmid; fa.w0f = Lw.w0f; fa.w3f = Lw.w3f; fa.xout = lout; fa.M = Ml;
     HIPCHK(h, launch_ffn_block(fa, st));
   }
   return VAPX_OK;
@@ -468,6 +469,7 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
     Lw.ln_self_g = get("ln_self.g"); Lw.ln_self_b = get("ln_self.b"); Lw.wqkv = get("wqkv"); Lw.wproj = get("wproj");
     Lw.ln_src_g = get("ln_src.g"); Lw.ln_src_b = get("ln_src.b"); Lw.wq_x = get("wq_x"); Lw.wkv_x = get("wkv_x");
     Lw.wproj_x = get("wproj_x"); Lw.ln_ffn_g = get("ln_ffn.g"); Lw.ln_ffn_b = get("ln_ffn.b"); Lw.w0 = get("w0"); Lw.w3 = get("w3");
+    Lw.w0f = get("w0f"); Lw.w3f = get("w3f"); Lw.wqkvf = get("wqkvf"); Lw.wkvxf = get("wkvxf");
   }
   const size_t S = cfg->max_streams, B = cfg->max_batch, T = h->T;
   const int* P = h->P;

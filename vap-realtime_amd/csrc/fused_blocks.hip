@@ -12,71 +12,64 @@
 //  un-normalised other-channel input (cross, :276-283).
 //
 // Same MFMA scheme as gemm_f32.hip: v_mfma_f32_32x32x2_f32, 4 waves, wave w owns 64 of the 256
-// columns of a chunk (2 accumulators), K-contiguous operands read from LDS with one ds_read_b128
-// per 4 k-pairs, weight tiles [256 n][32 k] staged through LDS with register prefetch.
+// columns of a chunk (2 accumulators); the shared A rows are read from LDS with one ds_read_b128
+// per 4 k-pairs, the weights stream straight from L2 in fragment order.
 #include "fused_blocks.h"
 
 namespace {
 
-constexpr int LDT = 36;    // staged tile row stride (32 + 4 pad)
 constexpr int LDH = 260;   // resident [32][256] buffer row stride (256 + 4 pad)
 
+// Weights arrive pre-packed in MFMA-fragment-major order (weights.frag_pack): for a 256x256
+// sub-matrix, [4 wave][32 kc][2 ns][64 lane][4].  A wave owns 64 distinct output columns, so its B
+// fragments are shared with nobody: they go global -> VGPR directly (one coalesced 1 KiB load per
+// 4 MFMAs) and the K loops contain no barrier and no LDS store at all.  Only the A operand (the 32
+// activation rows all four waves share) lives in LDS.
 __global__ __launch_bounds__(256, 2) void ffn_block_kernel(const FfnArgs g) {
-  __shared__ __attribute__((aligned(16))) float lds[32 * LDH + 32 * LDT + 256 * LDT];
-  float* sH = lds;                 // [32][260] resident A operand (gelu chunk / raw x / LN(x))
-  float* sA = lds + 32 * LDH;      // [32][36]  staged A tile (xn from global)
-  float* sW = sA + 32 * LDT;       // [256][36] staged weight tile
+  __shared__ __attribute__((aligned(16))) float lds[2 * 32 * LDH + 128];
+  float* sX = lds;                 // [32][260] LN_ffn(x) tile (A operand of FFN1)
+  float* sH = lds + 32 * LDH;      // [32][260] gelu chunk / raw x / LN_self(x)
+  float* red = sH + 32 * LDH;      // [4][32] row partials
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5, kh = hi * 4;
   const int m0 = blockIdx.x * 32;
-  const int srow = tid >> 3, skq = (tid & 7) * 4;
-  int arow = m0 + srow;
-  arow = arow < g.M ? arow : g.M - 1;
 
-  // One software pipeline runs through ALL contractions of the block: while the MFMAs of k-step t
-  // execute, the weight (and A) tile of step t+1 is in flight in registers — including across the
-  // boundary between two contractions (`nxt`), so the ~2 us global-load latency is paid once per
-  // workgroup instead of once per contraction.
-  struct Src { const float* a; const float* w; long ldw; };   // a == nullptr: A operand is resident in sH
-  f32x4 ra, rb[8];
-  auto gload = [&](const Src& sdesc, int k0) {
-    if (sdesc.a) ra = *(const f32x4*)(sdesc.a + (long)arow * 256 + skq + k0);
-    const float* bp = sdesc.w + (long)srow * sdesc.ldw + skq + k0;
-    const long bstep = 32 * sdesc.ldw;
+  for (int i = tid; i < 32 * 64; i += 256) {
+    int row = i >> 6, q = (i & 63) * 4;
+    int m = m0 + row;
+    m = m < g.M ? m : g.M - 1;
+    *(f32x4*)&sX[row * LDH + q] = *(const f32x4*)(g.xn + (long)m * 256 + q);
+  }
+  __syncthreads();
+
+  // acc[2] += A[32 x 256] (LDS) . Wsub^T for this wave's 64 columns; wfrag = 256x256 fragment block.
+  // Explicit register pipeline: the fragments of the next 8-kc block (16 x 1 KiB per wave) are in
+  // flight while the 64 MFMAs of the current block run (~4k cycles of cover for the L2 latency),
+  // and the first block of the NEXT contraction is fetched during the last block of this one.
+  f32x4 ring[16];   // weight fragments of 8 kc steps (2 per step), refilled in place one block ahead
+  auto wbase = [&](const float* wfrag) { return (const f32x4*)wfrag + (long)w * 32 * 2 * 64 + lane; };
+  auto fetch = [&](const float* wfrag, int) {
+    const f32x4* wf = wbase(wfrag);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) rb[i] = *(const f32x4*)(bp + i * bstep);
+    for (int i = 0; i < 16; ++i) ring[i] = wf[i * 64];
   };
-  auto sstore = [&](bool with_a) {
-    if (with_a) *(f32x4*)&sA[srow * LDT + skq] = ra;
+  auto mm = [&](f32x16(&acc)[2], const float* A, const float* wfrag, const float* next_wfrag) {
+    const float* pa = A + l31 * LDH + kh;
+    const f32x4* wf = wbase(wfrag);
+    const f32x4* wnext = next_wfrag ? wbase(next_wfrag) : wf;   // no successor: harmless re-read
+#pragma unroll 1
+    for (int blk = 0; blk < 4; ++blk) {
+      const f32x4* nx = blk < 3 ? wf + (blk + 1) * 16 * 64 : wnext;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *(f32x4*)&sW[(i * 32 + srow) * LDT + skq] = rb[i];
-  };
-  // acc[2] += A[32 x 256] . W[256 n x 256 k]^T for this wave's 64 columns.  Tile 0 of `cur` must
-  // already be in (ra, rb); on return tile 0 of `nxt` is (when nxt.w != nullptr).
-  auto mm = [&](f32x16(&acc)[2], const Src cur, const Src nxt) {
-    const bool with_a = cur.a != nullptr;
-    sstore(with_a);
-    __syncthreads();
-    const float* pb = &sW[(w * 64 + l31) * LDT + kh];
-    for (int kt = 0; kt < 8; ++kt) {
-      if (kt + 1 < 8) gload(cur, (kt + 1) * 32);
-      else if (nxt.w) gload(nxt, 0);
-      const float* pa = with_a ? &sA[l31 * LDT + kh] : &sH[l31 * LDH + kt * 32 + kh];
-#pragma unroll
-      for (int kc = 0; kc < 4; ++kc) {
-        f32x4 a = *(const f32x4*)(pa + kc * 8);
-        f32x4 b0 = *(const f32x4*)(pb + kc * 8);
-        f32x4 b1 = *(const f32x4*)(pb + 32 * LDT + kc * 8);
+      for (int k8 = 0; k8 < 8; ++k8) {
+        f32x4 a = *(const f32x4*)(pa + (blk * 8 + k8) * 8);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b0[s], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b1[s], acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], ring[k8 * 2][s], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], ring[k8 * 2 + 1][s], acc[1], 0, 0, 0);
         }
-      }
-      __syncthreads();
-      if (kt + 1 < 8) {
-        sstore(with_a);
-        __syncthreads();
+        ring[k8 * 2] = nx[(k8 * 2) * 64];
+        ring[k8 * 2 + 1] = nx[(k8 * 2 + 1) * 64];
       }
     }
   };
@@ -97,33 +90,35 @@ __global__ __launch_bounds__(256, 2) void ffn_block_kernel(const FfnArgs g) {
       }
     }
   };
-
-  const Src none{nullptr, nullptr, 0};
-  auto w0c = [&](int c) { return Src{g.xn, g.w0 + (long)c * 256 * 256, 256}; };
-  auto w3c = [&](int c) { return Src{nullptr, g.w3 + c * 256, 768}; };
-  auto kvxc = [&](int nc) { return Src{nullptr, g.wkvx + (long)nc * 256 * 256, 256}; };
-  auto qkvc = [&](int nc) { return Src{nullptr, g.wqkv + (long)nc * 256 * 256, 256}; };
-  const int nq = g.wqkv ? (g.n_qkv >> 8) : 0;
-  // what follows the feed-forward
-  const Src after_ffn = g.wkvx ? kvxc(0) : (nq ? qkvc(0) : none);
-
-  // ---- feed-forward: x = xmid + gelu(xn W0^T) W3^T, hidden processed in 3 chunks of 256 ----
-  f32x16 out[2];
-  zero(out);
-  gload(w0c(0), 0);
-  for (int c = 0; c < 3; ++c) {
-    f32x16 hacc[2];
-    zero(hacc);
-    mm(hacc, w0c(c), w3c(c));
+  auto to_sH = [&](const f32x16(&acc)[2]) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      sH[lr * LDH + ccol] = gelu_erf(hacc[0][r]);
-      sH[lr * LDH + ccol + 32] = gelu_erf(hacc[1][r]);
+      sH[lr * LDH + ccol] = acc[0][r];
+      sH[lr * LDH + ccol + 32] = acc[1][r];
+    }
+  };
+
+  // ---- feed-forward: x = xmid + gelu(xn W0^T) W3^T, hidden processed in 3 chunks of 256 ----
+  const int nq = g.wqkvf ? g.n_qkv_chunks : 0;
+  const float* after_ffn = g.wkvxf ? g.wkvxf : (nq ? g.wqkvf : nullptr);
+  f32x16 out[2];
+  zero(out);
+  fetch(g.w0f, 0);
+  for (int c = 0; c < 3; ++c) {
+    f32x16 hacc[2];
+    zero(hacc);
+    mm(hacc, sX, g.w0f + (long)c * 65536, g.w3f + (long)c * 65536);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      hacc[0][r] = gelu_erf(hacc[0][r]);
+      hacc[1][r] = gelu_erf(hacc[1][r]);
       if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
+    __syncthreads();          // every wave is done reading the previous chunk from sH
+    to_sH(hacc);
     __syncthreads();
-    mm(out, w3c(c), c < 2 ? w0c(c + 1) : after_ffn);
+    mm(out, sH, g.w3f + (long)c * 65536, c < 2 ? g.w0f + (long)(c + 1) * 65536 : after_ffn);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -136,27 +131,23 @@ __global__ __launch_bounds__(256, 2) void ffn_block_kernel(const FfnArgs g) {
   store_global(out, g.xout, 256, 0);
 
   // ---- next layer's cross K,V from the RAW layer output ----
-  if (g.wkvx) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      sH[lr * LDH + ccol] = out[0][r];
-      sH[lr * LDH + ccol + 32] = out[1][r];
-    }
+  if (g.wkvxf) {
+    __syncthreads();
+    to_sH(out);
     __syncthreads();
     for (int nc = 0; nc < 2; ++nc) {
       f32x16 acc[2];
       zero(acc);
-      mm(acc, kvxc(nc), nc == 0 ? kvxc(1) : (nq ? qkvc(0) : none));
+      mm(acc, sH, g.wkvxf + (long)nc * 65536, nc == 0 ? g.wkvxf + 65536 : (nq ? g.wqkvf : nullptr));
       store_global(acc, g.kvx, 512, nc * 256);
     }
   }
   // ---- next layer's self Q,K,V from LayerNorm(x) ----
   if (nq) {
-    float* red = sA;  // [4 waves][32 rows] row partials (sA is idle: A comes from sH here)
     float s[16], mean[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = half_sum(out[0][r] + out[1][r]);
+    __syncthreads();          // also: every wave is done reading sH (cross K,V)
     if (l31 == 0)
 #pragma unroll
       for (int r = 0; r < 16; ++r) red[w * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = s[r];
@@ -189,8 +180,8 @@ __global__ __launch_bounds__(256, 2) void ffn_block_kernel(const FfnArgs g) {
     for (int nc = 0; nc < nq; ++nc) {
       f32x16 acc[2];
       zero(acc);
-      mm(acc, qkvc(nc), nc + 1 < nq ? qkvc(nc + 1) : none);
-      store_global(acc, g.qkv, g.n_qkv, nc * 256);
+      mm(acc, sH, g.wqkvf + (long)nc * 65536, nc + 1 < nq ? g.wqkvf + (long)(nc + 1) * 65536 : nullptr);
+      store_global(acc, g.qkv, g.n_qkv_chunks * 256, nc * 256);
     }
   }
 }

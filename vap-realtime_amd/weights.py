@@ -234,6 +234,13 @@ def blob_entries(K: int, mode: str) -> List[Tuple[str, int]]:
         e.append((f"{p}.ln_ffn.g", DIM)); e.append((f"{p}.ln_ffn.b", DIM))
         e.append((f"{p}.w0", FFN * DIM))
         e.append((f"{p}.w3", DIM * FFN))
+        # MFMA-fragment-major copies for the fused FFN block (csrc/fused_blocks.hip): per 256x256
+        # sub-matrix [4 wave][32 kc][2 ns][64 lane][4]
+        e.append((f"{p}.w0f", FFN * DIM))            # 3 column chunks of W0
+        e.append((f"{p}.w3f", DIM * FFN))            # 3 k-chunks of W3
+        e.append((f"{p}.wqkvf", 3 * DIM * DIM))      # 3 column chunks [Wq;Wk;Wv]
+        if l > 0:
+            e.append((f"{p}.wkvxf", 2 * DIM * DIM))  # 2 column chunks [Wk_x;Wv_x]
     e.append(("comb.wa", DIM * DIM)); e.append(("comb.wb", DIM * DIM))      # [N][K] (GEMM path)
     e.append(("comb.waT", DIM * DIM)); e.append(("comb.wbT", DIM * DIM))    # [K][N] (head kernel)
     e.append(("comb.g", DIM)); e.append(("comb.b", DIM))
@@ -252,6 +259,13 @@ def blob_layout(K: int, mode: str = "vap") -> "OrderedDict[str, Tuple[int, int]]
         off += (n + 63) // 64 * 64
     lay["__total__"] = (off, 0)
     return lay
+
+
+def frag_pack(W: np.ndarray, n0: int, k0: int) -> np.ndarray:
+    """256x256 sub-matrix W[n0:n0+256, k0:k0+256] -> v_mfma_f32_32x32x2 B-fragment order
+    [4 wave][32 kc][2 ns][64 lane][4 u] with value = W[n0 + 64w + 32ns + (lane&31)][k0 + 8kc + 4(lane>>5) + u]."""
+    sub = np.ascontiguousarray(W[n0:n0 + 256, k0:k0 + 256], dtype=np.float32)
+    return sub.reshape(4, 2, 32, 32, 2, 4).transpose(0, 3, 1, 4, 2, 5).reshape(-1)
 
 
 def pack_blob(cpc_sd: Dict[str, np.ndarray], vap_sd: Dict[str, np.ndarray], mode: str = "vap") -> np.ndarray:
@@ -313,8 +327,17 @@ def pack_blob(cpc_sd: Dict[str, np.ndarray], vap_sd: Dict[str, np.ndarray], mode
             put(f"{p}.wproj_x", A(vap_sd[f"{src}.mha_cross.proj.weight"]))
         put(f"{p}.ln_ffn.g", A(vap_sd[f"{src}.ln_ffnetwork.weight"]))
         put(f"{p}.ln_ffn.b", A(vap_sd[f"{src}.ln_ffnetwork.bias"]))
-        put(f"{p}.w0", A(vap_sd[f"{src}.ffnetwork.0.weight"]))
-        put(f"{p}.w3", A(vap_sd[f"{src}.ffnetwork.3.weight"]))
+        w0, w3 = A(vap_sd[f"{src}.ffnetwork.0.weight"]), A(vap_sd[f"{src}.ffnetwork.3.weight"])
+        put(f"{p}.w0", w0)
+        put(f"{p}.w3", w3)
+        put(f"{p}.w0f", np.concatenate([frag_pack(w0, c * 256, 0) for c in range(3)]))
+        put(f"{p}.w3f", np.concatenate([frag_pack(w3, 0, c * 256) for c in range(3)]))
+        wqkv = np.concatenate([A(vap_sd[f"{src}.mha.query.weight"]), A(vap_sd[f"{src}.mha.key.weight"]),
+                               A(vap_sd[f"{src}.mha.value.weight"])], axis=0)
+        put(f"{p}.wqkvf", np.concatenate([frag_pack(wqkv, c * 256, 0) for c in range(3)]))
+        if l > 0:
+            wkvx = np.concatenate([A(vap_sd[f"{src}.mha_cross.key.weight"]), A(vap_sd[f"{src}.mha_cross.value.weight"])], axis=0)
+            put(f"{p}.wkvxf", np.concatenate([frag_pack(wkvx, c * 256, 0) for c in range(2)]))
     put("comb.wa", A(vap_sd["ar.combinator.h0_a.weight"]))
     put("comb.wb", A(vap_sd["ar.combinator.h0_b.weight"]))
     put("comb.waT", A(vap_sd["ar.combinator.h0_a.weight"]).T)
