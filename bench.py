@@ -42,12 +42,14 @@ def macs_per_stream_frame(hz: int, T: int) -> dict:
         "lstm": 2 * ncpc * 2 * D * 4 * D,
         "gemm_bias_ln_gelu": 2 * ncpc * D * D,
         # executed work with exact last-layer pruning (only the newest row of layer 3 is consumed):
-        "gemm_store": rows * D * (768 + 2 * 256),                       # QKV of layer 0, cross-q of layers 1-2
-        "gemm_resid_ln": rows * 5 * D * D,                              # proj x3, proj_x x2
+        "gemm_store": rows * D * 768,                                   # QKV of layer 0
+        "gemm_resid_ln": 0,
         "ffn_block": rows * D * (3 * 2 * 768 + 2 * 768 + 512 + 3 * 512),  # FFN x3 + next QKV (x2 full, 1 K/V only) + next cross-KV x3
         "last_row": 2 * (4 * D * D + 2 * D * 768),                      # layer 3 on one row per channel
         "gemm_gelu": 0, "gemm_resid": 0,
-        "attention": 5 * 2 * 4 * (T * T * 64 * 2),       # dense T x T, as SURVEY counts it (layers 0-2)
+        # fused attention block: dense T x T attention (as SURVEY counts it) of layers 0-2 + output
+        # projections (x5) + cross-attention query projections (x2)
+        "attention": 5 * 2 * 4 * (T * T * 64 * 2) + rows * 7 * D * D,
         "head": 3 * D * D + 2 * D,
         "gather_ln": 0,
     }

@@ -24,7 +24,7 @@ struct Layer {
   const float *ln_self_g, *ln_self_b, *wqkv, *wproj;
   const float *ln_src_g, *ln_src_b, *wq_x, *wkv_x, *wproj_x;
   const float *ln_ffn_g, *ln_ffn_b, *w0, *w3;
-  const float *w0f, *w3f, *wqkvf, *wkvxf;   // fragment-major copies (fused FFN block)
+  const float *w0f, *w3f, *wqkvf, *wkvxf, *wprojf, *wqxf, *wprojxf;   // fragment-major copies (fused blocks)
 };
 
 }  // namespace
@@ -253,23 +253,40 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
         HIPCHK(h, gemm(h, g, EPI_STORE, st));
       }
     }
+    if (T <= 64) {
+      // fused: attention + output projection + residual + LayerNorm (+ cross-attention queries)
+      AttnBlockArgs ab;
+      memset(&ab, 0, sizeof ab);
+      ab.q = sc.qkv; ab.k = sc.qkv + 256; ab.v = sc.qkv + 512; ab.ldq = 768; ab.ldkv = 768; ab.swap_kv = 0;
+      ab.bn = sc.bn; ab.T = T; ab.wprojf = Lw.wprojf; ab.resid = xin; ab.xmid = sc.xmid; ab.xn = sc.xn;
+      if (l == 0) { ab.ln_g = Lw.ln_ffn_g; ab.ln_b = Lw.ln_ffn_b; }
+      else { ab.ln_g = Lw.ln_src_g; ab.ln_b = Lw.ln_src_b; ab.wqxf = Lw.wqxf; ab.qx = sc.qx; }
+      { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attn_block(ab, B, st)); }
+      if (l > 0) {
+        ab.q = sc.qx; ab.k = sc.kvx; ab.v = sc.kvx + 256; ab.ldq = 256; ab.ldkv = 512; ab.swap_kv = 1;
+        ab.wprojf = Lw.wprojxf; ab.resid = sc.xmid; ab.ln_g = Lw.ln_ffn_g; ab.ln_b = Lw.ln_ffn_b;
+        ab.wqxf = nullptr; ab.qx = nullptr;
+        { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attn_block(ab, B, st)); }
+      }
+    } else {
     // self attention
-    AttnArgs aa{sc.qkv, sc.qkv + 256, sc.qkv + 512, sc.att, sc.bn, T, 768, 768, 0};
-    { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attention(aa, B, st)); }
-    g = gemm_args(sc.att, r256, Lw.wproj, M, 256, 256, sc.xmid, r256);
-    g.resid = xin; g.C2 = sc.xn;
-    if (l == 0) { g.gamma = Lw.ln_ffn_g; g.beta = Lw.ln_ffn_b; }
-    else { g.gamma = Lw.ln_src_g; g.beta = Lw.ln_src_b; }
-    HIPCHK(h, gemm(h, g, EPI_RESID_LN, st));
-    if (l > 0) {
-      // cross attention: Q from LN_src(x), K/V from the OTHER channel's raw layer input
-      g = gemm_args(sc.xn, r256, Lw.wq_x, M, 256, 256, sc.qx, r256);
-      HIPCHK(h, gemm(h, g, EPI_STORE, st));
-      AttnArgs ax{sc.qx, sc.kvx, sc.kvx + 256, sc.att, sc.bn, T, 256, 512, 1};
-      { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attention(ax, B, st)); }
-      g = gemm_args(sc.att, r256, Lw.wproj_x, M, 256, 256, sc.xmid, r256);
-      g.resid = sc.xmid; g.C2 = sc.xn; g.gamma = Lw.ln_ffn_g; g.beta = Lw.ln_ffn_b;
+      AttnArgs aa{sc.qkv, sc.qkv + 256, sc.qkv + 512, sc.att, sc.bn, T, 768, 768, 0};
+      { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attention(aa, B, st)); }
+      g = gemm_args(sc.att, r256, Lw.wproj, M, 256, 256, sc.xmid, r256);
+      g.resid = xin; g.C2 = sc.xn;
+      if (l == 0) { g.gamma = Lw.ln_ffn_g; g.beta = Lw.ln_ffn_b; }
+      else { g.gamma = Lw.ln_src_g; g.beta = Lw.ln_src_b; }
       HIPCHK(h, gemm(h, g, EPI_RESID_LN, st));
+      if (l > 0) {
+        // cross attention: Q from LN_src(x), K/V from the OTHER channel's raw layer input
+        g = gemm_args(sc.xn, r256, Lw.wq_x, M, 256, 256, sc.qx, r256);
+        HIPCHK(h, gemm(h, g, EPI_STORE, st));
+        AttnArgs ax{sc.qx, sc.kvx, sc.kvx + 256, sc.att, sc.bn, T, 256, 512, 1};
+        { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attention(ax, B, st)); }
+        g = gemm_args(sc.att, r256, Lw.wproj_x, M, 256, 256, sc.xmid, r256);
+        g.resid = sc.xmid; g.C2 = sc.xn; g.gamma = Lw.ln_ffn_g; g.beta = Lw.ln_ffn_b;
+        HIPCHK(h, gemm(h, g, EPI_RESID_LN, st));
+      }
     }
     // feed-forward (+ next layer's projections)
     FfnArgs fa;
@@ -470,6 +487,7 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
     Lw.ln_src_g = get("ln_src.g"); Lw.ln_src_b = get("ln_src.b"); Lw.wq_x = get("wq_x"); Lw.wkv_x = get("wkv_x");
     Lw.wproj_x = get("wproj_x"); Lw.ln_ffn_g = get("ln_ffn.g"); Lw.ln_ffn_b = get("ln_ffn.b"); Lw.w0 = get("w0"); Lw.w3 = get("w3");
     Lw.w0f = get("w0f"); Lw.w3f = get("w3f"); Lw.wqkvf = get("wqkvf"); Lw.wkvxf = get("wkvxf");
+    Lw.wprojf = get("wprojf"); Lw.wqxf = get("wqxf"); Lw.wprojxf = get("wprojxf");
   }
   const size_t S = cfg->max_streams, B = cfg->max_batch, T = h->T;
   const int* P = h->P;

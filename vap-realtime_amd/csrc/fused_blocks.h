@@ -18,4 +18,21 @@ struct FfnArgs {
   int M;
 };
 
+struct AttnBlockArgs {
+  const float* q;       // row (bc*T + i), stride ldq, head h at column 64h
+  const float* k;
+  const float* v;       // rows of channel (bc ^ swap_kv), stride ldkv
+  const int* bn;
+  const float* wprojf;  // output projection, fragment-major 256x256
+  const float* resid;   // [B*2*T][256]
+  const float* ln_g;
+  const float* ln_b;
+  float* xmid;          // resid + att.Wproj^T
+  float* xn;            // LayerNorm(xmid)
+  const float* wqxf;    // optional: cross-attention query projection (fragment-major), null to skip
+  float* qx;            // [B*2*T][256]
+  int T, ldq, ldkv, swap_kv;
+};
+
+hipError_t launch_attn_block(const AttnBlockArgs& a, int B, hipStream_t st);   // T <= 64 only
 hipError_t launch_ffn_block(const FfnArgs& a, hipStream_t st);

@@ -186,7 +186,262 @@ __global__ __launch_bounds__(256, 2) void ffn_block_kernel(const FfnArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// attn_block_kernel: one workgroup per (stream, channel), wave = head.
+//     att   = causal ALiBi attention of the 4 heads           (as attention_mfma_kernel)
+//     x'    = resid + att . Wproj^T                           -> xmid (global)
+//     xn    = LayerNorm(x'; g, b)                             -> xn   (global)
+//     qx    = xn . Wq_x^T                (optional)           -> qx   (global; cross-attention queries)
+// reference: MultiHeadAttention.forward modules.py:82-110 incl. the output projection :107, the
+// residual + ln_src_attn / ln_ffnetwork of TransformerLayer.forward :263-286, and mha_cross.query.
+// K fragments come straight from global (A operand, reused by both query tiles), V sits in LDS
+// (zero rows beyond n), and once every head has finished P.V the same LDS bytes are re-used for
+// the [64 x 256] attention output that feeds the projection MFMAs — 70 KB, two workgroups per CU.
+// Only for T <= 64 (two 32-row tiles); longer windows use the unfused kernels.
+// ------------------------------------------------------------------------------------------------
+constexpr int KV_LD2 = 68;
+
+__global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * 64 * KV_LD2 + 256];
+  float* sAtt = lds;                        // [64][260] (aliases the V tiles after a barrier)
+  float* red = lds + 4 * 64 * KV_LD2;       // [4][64]
+  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5, kh = hi * 4;
+  const int bc = blockIdx.x, b = bc >> 1, T = a.T;
+  const int n = a.bn[b];
+  const int kvbc = a.swap_kv ? (bc ^ 1) : bc;
+  float* Vs = lds + h * 64 * KV_LD2;
+  const float* vp = a.v + (long)kvbc * T * a.ldkv + h * 64;
+  const float* kp = a.k + (long)kvbc * T * a.ldkv + h * 64;
+  for (int i = lane; i < 64 * 16; i += 64) {
+    int j = i >> 4, q4 = (i & 15) * 4;
+    f32x4 vv = {0.f, 0.f, 0.f, 0.f};
+    if (j < n) vv = *(const f32x4*)(vp + (long)j * a.ldkv + q4);
+    *(f32x4*)&Vs[j * KV_LD2 + q4] = vv;
+  }
+  const bool two = n > 32;                  // second query/key tile holds valid rows
+  // K fragments (A operand of S^T = K.Q^T): key row j, k-slots kc*8 + 4*hi ..+3; rows >= n are
+  // clamped (their scores are masked below)
+  f32x4 kf0[8];
+  {
+    int j0 = l31 < n ? l31 : n - 1;
+    const float* k0 = kp + (long)j0 * a.ldkv + kh;
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) kf0[kc] = *(const f32x4*)(k0 + kc * 8);
+  }
+  const float slope = exp2f(-2.0f * (float)(h + 1));
+
+  // one query tile `it` against key tiles 0..NJ-1; returns O^T tiles scaled by 1/rowsum
+  auto qtile = [&](int it, bool use_j1, f32x16& o0, f32x16& o1) {
+    const int i = it * 32 + l31;
+    const int iq = i < n ? i : n - 1;
+    const float* qp = a.q + ((long)bc * T + iq) * a.ldq + h * 64 + kh;
+    f32x4 qf[8];
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) qf[kc] = *(const f32x4*)(qp + kc * 8) * 0.0625f;
+    f32x16 s0, s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf0[kc][s], qf[kc][s], s0, 0, 0, 0);
+    if (use_j1) {   // second key tile: fragments fetched here (L2-hot) to keep tile 0 light on registers
+      int j1 = 32 + l31 < n ? 32 + l31 : n - 1;
+      const float* k1 = kp + (long)j1 * a.ldkv + kh;
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc) {
+        f32x4 kf1 = *(const f32x4*)(k1 + kc * 8);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf1[s], qf[kc][s], s1, 0, 0, 0);
+      }
+    }
+    float mx = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int j = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      float v0 = s0[r] + slope * (float)j;
+      v0 = ((j <= i) && (j < n)) ? v0 : -1e30f;
+      s0[r] = v0;
+      mx = fmaxf(mx, v0);
+      int j2 = j + 32;
+      float v1 = s1[r] + slope * (float)j2;
+      v1 = (use_j1 && (j2 <= i) && (j2 < n)) ? v1 : -1e30f;
+      s1[r] = v1;
+      mx = fmaxf(mx, v1);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float p0 = s0[r] > -1e29f ? expf(s0[r] - mx) : 0.f;
+      float p1 = s1[r] > -1e29f ? expf(s1[r] - mx) : 0.f;
+      s0[r] = p0; s1[r] = p1;
+      sum += p0 + p1;
+    }
+    sum += __shfl_xor(sum, 32);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float* va = &Vs[((r & 3) + 8 * (r >> 2) + 4 * hi) * KV_LD2 + l31];
+      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[0], s0[r], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32], s0[r], o1, 0, 0, 0);
+    }
+    if (use_j1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float* va = &Vs[(32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * KV_LD2 + l31];
+        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[0], s1[r], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32], s1[r], o1, 0, 0, 0);
+      }
+    }
+    const float inv = i < n ? 1.0f / sum : 0.f;    // rows beyond the window -> zeros
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= inv; o1[r] *= inv; }
+  };
+  f32x16 oa0, oa1, ob0, ob1;   // query tile 0 / 1, feature tile 0 / 1
+  qtile(0, false, oa0, oa1);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { ob0[r] = 0.f; ob1[r] = 0.f; }
+  if (two) qtile(1, true, ob0, ob1);
+  __syncthreads();             // every head is done with its V tile: the bytes become sAtt
+  // O^T accumulator r <-> feature d = dt*32 + (r&3) + 8*(r>>2) + 4*hi, query i = it*32 + l31
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    *(f32x4*)&sAtt[l31 * 260 + h * 64 + rr * 8 + kh] = f32x4{oa0[rr * 4], oa0[rr * 4 + 1], oa0[rr * 4 + 2], oa0[rr * 4 + 3]};
+    *(f32x4*)&sAtt[l31 * 260 + h * 64 + 32 + rr * 8 + kh] = f32x4{oa1[rr * 4], oa1[rr * 4 + 1], oa1[rr * 4 + 2], oa1[rr * 4 + 3]};
+    *(f32x4*)&sAtt[(32 + l31) * 260 + h * 64 + rr * 8 + kh] = f32x4{ob0[rr * 4], ob0[rr * 4 + 1], ob0[rr * 4 + 2], ob0[rr * 4 + 3]};
+    *(f32x4*)&sAtt[(32 + l31) * 260 + h * 64 + 32 + rr * 8 + kh] = f32x4{ob1[rr * 4], ob1[rr * 4 + 1], ob1[rr * 4 + 2], ob1[rr * 4 + 3]};
+  }
+  __syncthreads();
+
+  // ---- projection(s): [64 x 256] (LDS) . W^T, wave h owns columns 64h..64h+63 ----
+  const int w = h;
+  f32x4 ring[16];
+  auto wbase = [&](const float* wfrag) { return (const f32x4*)wfrag + (long)w * 32 * 2 * 64 + lane; };
+  auto fetch = [&](const float* wfrag) {
+    const f32x4* wf = wbase(wfrag);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ring[i] = wf[i * 64];
+  };
+  auto mm = [&](f32x16(&acc)[4], const float* wfrag, const float* next_wfrag) {
+    const float* pa = sAtt + l31 * 260 + kh;
+    const f32x4* wf = wbase(wfrag);
+    const f32x4* wnext = next_wfrag ? wbase(next_wfrag) : wf;
+#pragma unroll 1
+    for (int blk = 0; blk < 4; ++blk) {
+      const f32x4* nx = blk < 3 ? wf + (blk + 1) * 16 * 64 : wnext;
+#pragma unroll
+      for (int k8 = 0; k8 < 8; ++k8) {
+        f32x4 a0 = *(const f32x4*)(pa + (blk * 8 + k8) * 8);
+        f32x4 a1 = *(const f32x4*)(pa + 32 * 260 + (blk * 8 + k8) * 8);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], ring[k8 * 2][s], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], ring[k8 * 2 + 1][s], acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], ring[k8 * 2][s], acc[2], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], ring[k8 * 2 + 1][s], acc[3], 0, 0, 0);
+        }
+        ring[k8 * 2] = nx[(k8 * 2) * 64];
+        ring[k8 * 2 + 1] = nx[(k8 * 2 + 1) * 64];
+      }
+    }
+  };
+  // acc[mt*2 + ns][r] <-> row i = mt*32 + (r&3) + 8*(r>>2) + 4*hi, column 64w + 32ns + l31
+  const int ccol = w * 64 + l31;
+  f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  fetch(a.wprojf);
+  mm(acc, a.wprojf, a.wqxf);
+  // residual
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int i = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      i = i < T ? i : T - 1;
+      const float* rp = a.resid + ((long)bc * T + i) * 256 + ccol;
+      acc[mt * 2][r] += rp[0];
+      acc[mt * 2 + 1][r] += rp[32];
+      if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+  // LayerNorm over the 256 columns of each row (two-pass), partials across the 4 waves via LDS
+  float s[32], mean[32];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[mt * 16 + r] = half_sum(acc[mt * 2][r] + acc[mt * 2 + 1][r]);
+  if (l31 == 0)
+#pragma unroll
+    for (int t = 0; t < 32; ++t) red[w * 64 + (t >> 4) * 32 + (t & 3) + 8 * ((t & 15) >> 2) + 4 * hi] = s[t];
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 32; ++t) {
+    int lr = (t >> 4) * 32 + (t & 3) + 8 * ((t & 15) >> 2) + 4 * hi;
+    mean[t] = (red[lr] + red[64 + lr] + red[128 + lr] + red[192 + lr]) * (1.0f / 256.0f);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float d0 = acc[mt * 2][r] - mean[mt * 16 + r], d1 = acc[mt * 2 + 1][r] - mean[mt * 16 + r];
+      s[mt * 16 + r] = half_sum(d0 * d0 + d1 * d1);
+    }
+  if (l31 == 0)
+#pragma unroll
+    for (int t = 0; t < 32; ++t) red[w * 64 + (t >> 4) * 32 + (t & 3) + 8 * ((t & 15) >> 2) + 4 * hi] = s[t];
+  __syncthreads();   // (also: every wave has finished reading sAtt in mm)
+  const float g0 = a.ln_g[ccol], g1 = a.ln_g[ccol + 32], b0 = a.ln_b[ccol], b1 = a.ln_b[ccol + 32];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = mt * 16 + r;
+      const int i = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      float var = (red[i] + red[64 + i] + red[128 + i] + red[192 + i]) * (1.0f / 256.0f);
+      float rstd = rsqrtf(var + 1e-5f);
+      float y0 = (acc[mt * 2][r] - mean[t]) * rstd * g0 + b0;
+      float y1 = (acc[mt * 2 + 1][r] - mean[t]) * rstd * g1 + b1;
+      if (i < T) {
+        float* xm = a.xmid + ((long)bc * T + i) * 256 + ccol;
+        float* xo = a.xn + ((long)bc * T + i) * 256 + ccol;
+        xm[0] = acc[mt * 2][r]; xm[32] = acc[mt * 2 + 1][r];
+        xo[0] = y0; xo[32] = y1;
+      }
+      if (a.wqxf) { sAtt[i * 260 + ccol] = y0; sAtt[i * 260 + ccol + 32] = y1; }
+    }
+  if (a.wqxf) {
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    mm(acc, a.wqxf, nullptr);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (i < T) {
+          float* qo = a.qx + ((long)bc * T + i) * 256 + ccol;
+          qo[0] = acc[mt * 2][r]; qo[32] = acc[mt * 2 + 1][r];
+        }
+      }
+  }
+}
+
 }  // namespace
+
+hipError_t launch_attn_block(const AttnBlockArgs& a, int B, hipStream_t st) {
+  if (a.T > 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(attn_block_kernel, dim3(B * 2), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
 
 hipError_t launch_ffn_block(const FfnArgs& a, hipStream_t st) {
   if (a.M <= 0) return hipSuccess;

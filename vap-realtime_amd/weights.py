@@ -239,8 +239,11 @@ def blob_entries(K: int, mode: str) -> List[Tuple[str, int]]:
         e.append((f"{p}.w0f", FFN * DIM))            # 3 column chunks of W0
         e.append((f"{p}.w3f", DIM * FFN))            # 3 k-chunks of W3
         e.append((f"{p}.wqkvf", 3 * DIM * DIM))      # 3 column chunks [Wq;Wk;Wv]
+        e.append((f"{p}.wprojf", DIM * DIM))
         if l > 0:
             e.append((f"{p}.wkvxf", 2 * DIM * DIM))  # 2 column chunks [Wk_x;Wv_x]
+            e.append((f"{p}.wqxf", DIM * DIM))
+            e.append((f"{p}.wprojxf", DIM * DIM))
     e.append(("comb.wa", DIM * DIM)); e.append(("comb.wb", DIM * DIM))      # [N][K] (GEMM path)
     e.append(("comb.waT", DIM * DIM)); e.append(("comb.wbT", DIM * DIM))    # [K][N] (head kernel)
     e.append(("comb.g", DIM)); e.append(("comb.b", DIM))
@@ -335,9 +338,12 @@ def pack_blob(cpc_sd: Dict[str, np.ndarray], vap_sd: Dict[str, np.ndarray], mode
         wqkv = np.concatenate([A(vap_sd[f"{src}.mha.query.weight"]), A(vap_sd[f"{src}.mha.key.weight"]),
                                A(vap_sd[f"{src}.mha.value.weight"])], axis=0)
         put(f"{p}.wqkvf", np.concatenate([frag_pack(wqkv, c * 256, 0) for c in range(3)]))
+        put(f"{p}.wprojf", frag_pack(A(vap_sd[f"{src}.mha.proj.weight"]), 0, 0))
         if l > 0:
             wkvx = np.concatenate([A(vap_sd[f"{src}.mha_cross.key.weight"]), A(vap_sd[f"{src}.mha_cross.value.weight"])], axis=0)
             put(f"{p}.wkvxf", np.concatenate([frag_pack(wkvx, c * 256, 0) for c in range(2)]))
+            put(f"{p}.wqxf", frag_pack(A(vap_sd[f"{src}.mha_cross.query.weight"]), 0, 0))
+            put(f"{p}.wprojxf", frag_pack(A(vap_sd[f"{src}.mha_cross.proj.weight"]), 0, 0))
     put("comb.wa", A(vap_sd["ar.combinator.h0_a.weight"]))
     put("comb.wb", A(vap_sd["ar.combinator.h0_b.weight"]))
     put("comb.waT", A(vap_sd["ar.combinator.h0_a.weight"]).T)
