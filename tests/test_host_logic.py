@@ -32,7 +32,7 @@ def test_blob_layout_and_pack_inverse():
     wqkv = get("L2.wqkv").reshape(768, 256)
     np.testing.assert_array_equal(wqkv[256:512], vap["ar.layers.1.mha.key.weight"])
     # LSTM: undo fragment-major packing + gate permutation
-    wf = get("lstm.whh").reshape(4, 16, 16, 4, 16, 4)          # [w][kc][ns][kq][l15][u]
+    wf = get("lstm.whh").reshape(8, 16, 8, 4, 16, 4)           # [w][kc][ns][kq][l15][u]
     whh_perm = wf.transpose(0, 2, 4, 1, 3, 5).reshape(1024, 256)
     perm = W._lstm_perm()
     np.testing.assert_array_equal(whh_perm, vap_or(cpc, "gAR.baseNet.weight_hh_l0")[perm])

@@ -219,13 +219,10 @@ int run_encoder(vapx_engine* h, const Scratch& sc, const StateView& sv, int B, c
   LstmArgs la;
   la.gx = sc.gx; la.ids = ids_dev; la.h_state = sv.h_state; la.c_state = sv.c_state;
   la.wfrag = h->W("lstm.whh"); la.out = sc.lstm_out; la.M = B * 2; la.ncpc = h->ncpc;
+  // downsample (single-output Conv1d == dense [ncpc*256 -> 256]) + LN + GELU fused into the LSTM kernel
+  la.down_wf = h->W("down.wf"); la.down_b = h->W("down.b"); la.down_g = h->W("down.g"); la.down_beta = h->W("down.beta");
+  la.e = sc.e;
   { ProfScope ps(h, CLS_LSTM, st); HIPCHK(h, launch_lstm(la, st)); }
-  {  // downsample: single-output Conv1d == dense [ncpc*256 -> 256] + LN + GELU
-    GemmArgs g = gemm_args(sc.lstm_out, contiguous_rows((long)h->ncpc * 256), h->W("down.w"), B * 2, 256, h->ncpc * 256,
-                           sc.e, contiguous_rows(256));
-    g.bias = h->W("down.b"); g.gamma = h->W("down.g"); g.beta = h->W("down.beta");
-    HIPCHK(h, gemm(h, g, EPI_BIAS_LN_GELU, st));
-  }
   return VAPX_OK;
 }
 

@@ -22,8 +22,13 @@ struct LstmArgs {
   const int* ids;       // [M/2] or null
   float* h_state;       // [S*2][256]
   float* c_state;       // [S*2][256]
-  const float* wfrag;   // W_hh, fragment-major [4 w][16 kc][16 ns][64 lane][4]
+  const float* wfrag;   // W_hh, fragment-major [8 w][16 kc][8 ns][64 lane][4]
   float* out;           // [M][ncpc][256]
+  const float* down_wf; // downsample weight, fragment-major [ncpc][8 w][16 kc][2 ns][64 lane][4] (null: skip)
+  const float* down_b;  // [256] conv bias
+  const float* down_g;  // [256] LayerNorm weight
+  const float* down_beta;
+  float* e;             // [M][256] embeddings (written when down_wf != null)
   int M, ncpc;
 };
 

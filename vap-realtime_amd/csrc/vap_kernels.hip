@@ -65,22 +65,25 @@ __global__ __launch_bounds__(256) void conv0_kernel(Conv0Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// 2. LSTM (256 -> 256, 1 layer), n_cpc sequential steps, (h, c) persistent per (stream, channel)
+// 2. LSTM (256 -> 256, 1 layer), n_cpc sequential steps, persistent (h, c), + fused downsample
 //    reference: CPCAR.forward encoder_components.py:140-159 (nn.LSTM, gate order i,f,g,o, both
-//    biases), keepHidden=True (encoder.py:27).
-//    The input projection z.W_ih^T + b_ih + b_hh for all n_cpc steps is a plain batched GEMM
-//    (engine: gx = gemm(z, lstm.wih) + bias); only the K = 256 recurrence h_{t-1}.W_hh^T is
-//    sequential.  One workgroup = 16 (stream,channel) rows (v_mfma_f32_16x16x4_f32, so a small
-//    batch still spreads over many CUs); wave w owns hidden units 64w..64w+63 for all four gates
-//    (weight rows pre-permuted: its 256 columns are [i|f|g|o] x 64 -> the cell update is
-//    lane-local).  h lives in LDS between steps, c in registers, W_hh fragments stream from L2 in
-//    fragment-major order (one coalesced 1 KiB load per wave per 4 MFMAs).
+//    biases), keepHidden=True (encoder.py:27); downsample get_cnn_layer :496-511 with the weight
+//    swapped in at vap_main.py:204-212: Conv1d(256,256,K=n_cpc) over exactly n_cpc frames = one
+//    dense [n_cpc*256 -> 256] contraction, then LayerNorm + exact GELU.
+//    The input projection z.W_ih^T + b_ih + b_hh for all steps is a plain batched GEMM (engine:
+//    gx); only h_{t-1}.W_hh^T (K = 256) is sequential.  One workgroup = 16 (stream,channel) rows
+//    (v_mfma_f32_16x16x4_f32 so that a small batch still spreads over CUs), 8 waves; wave w owns
+//    hidden units 32w..32w+31 for all four gates (weight rows pre-permuted: its 128 columns are
+//    [i|f|g|o] x 32 -> the cell update is lane-local).  h lives in LDS between steps, c in registers,
+//    W_hh / W_down fragments stream from L2 in fragment-major order.  The downsample contribution of
+//    step t (h_t . Wd_t^T) rides in the MFMA phase of step t+1, which reads the same h_t from LDS.
 // ------------------------------------------------------------------------------------------------
 constexpr int H_LD = 260;  // 256 + 4 pad floats
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void lstm_kernel(LstmArgs a) {
+__global__ __launch_bounds__(512) void lstm_kernel(LstmArgs a) {
   __shared__ __attribute__((aligned(16))) float hbuf[16 * H_LD];
+  __shared__ float red[8 * 16];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, kq = lane >> 4;
   const int m0 = blockIdx.x * 16;
@@ -91,57 +94,103 @@ __global__ __launch_bounds__(256) void lstm_kernel(LstmArgs a) {
     int sid = a.ids ? a.ids[b] : b;
     return (long)sid * 2 + (m & 1);
   };
-  for (int i = tid; i < 16 * 64; i += 256) {
+  for (int i = tid; i < 16 * 64; i += 512) {
     int row = i >> 6, q = (i & 63) * 4;
     *(f32x4*)&hbuf[row * H_LD + q] = *(const f32x4*)(a.h_state + state_row(m0 + row) * 256 + q);
   }
-  // accumulator (ns, reg): row = 4*kq + reg, column ns*16 + l15 of this wave's 256 = gate ns/4,
-  // hidden unit j = 64w + 16*(ns%4) + l15.  c for (q = ns%4, reg) stays in registers.
-  float creg[4][4];
+  // accumulator (ns, reg): row = 4*kq + reg, column ns*16 + l15 of this wave's 128 = gate ns/2,
+  // hidden unit j = 32w + 16*(ns&1) + l15.  c for (q = ns&1, reg) stays in registers.
+  float creg[2][4];
   long srow[4];
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
     srow[reg] = state_row(m0 + kq * 4 + reg);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) creg[q][reg] = a.c_state[srow[reg] * 256 + w * 64 + q * 16 + l15];
+    for (int q = 0; q < 2; ++q) creg[q][reg] = a.c_state[srow[reg] * 256 + w * 32 + q * 16 + l15];
   }
-  const f32x4* wf = (const f32x4*)a.wfrag + (long)w * 16 * 16 * 64 + lane;
+  const f32x4* wf = (const f32x4*)a.wfrag + (long)w * 16 * 8 * 64 + lane;      // [8 w][16 kc][8 ns][64]
+  const f32x4* df = (const f32x4*)a.down_wf + (long)w * 16 * 2 * 64 + lane;     // [T][8 w][16 kc][2 ns][64]
   const float* pa = &hbuf[l15 * H_LD + kq * 4];
-  for (int t = 0; t < a.ncpc; ++t) {
-    __syncthreads();  // hbuf holds h_{t-1}
-    f32x4v acc[16];
+  // W_hh fragments run through a register ring 2 kc (= 64 MFMAs) ahead of their use; since every
+  // step multiplies by the same W_hh the ring simply wraps from kc 15 to kc 0 of the next step, so
+  // the L2 latency is never exposed — not even at step boundaries.
+  f32x4 ring[16];
 #pragma unroll
-    for (int ns = 0; ns < 16; ++ns) acc[ns] = f32x4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int kc = 0; kc < 16; ++kc) {
-      f32x4 av = *(const f32x4*)(pa + kc * 16);
-      f32x4 bv[16];
+  for (int i = 0; i < 16; ++i) ring[i] = wf[i * 64];
+  f32x4 dring[4];
+  if (a.down_wf) {
 #pragma unroll
-      for (int ns = 0; ns < 16; ++ns) bv[ns] = wf[((long)kc * 16 + ns) * 64];
+    for (int i = 0; i < 4; ++i) dring[i] = df[i * 64];
+  }
+  f32x4v dacc[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
+  auto down_step = [&](int t) {   // dacc += h_t (in hbuf) . Wd_t^T for this wave's 32 output columns
+    const f32x4* d = df + (long)t * 8 * 16 * 2 * 64;
+    const f32x4* dn = df + (long)(t + 1 < a.ncpc ? t + 1 : t) * 8 * 16 * 2 * 64;
+#pragma unroll 1
+    for (int kp = 0; kp < 8; ++kp) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int kc = kp * 2 + h2;
+        f32x4 av = *(const f32x4*)(pa + kc * 16);
 #pragma unroll
-        for (int ns = 0; ns < 16; ++ns)
-          acc[ns] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[ns][s], acc[ns], 0, 0, 0);
+        for (int s = 0; s < 4; ++s) {
+          dacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], dring[h2 * 2][s], dacc[0], 0, 0, 0);
+          dacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], dring[h2 * 2 + 1][s], dacc[1], 0, 0, 0);
+        }
+        const f32x4* nx = kc + 2 < 16 ? d + ((kc + 2) * 2) * 64 : dn + ((kc + 2 - 16) * 2) * 64;
+        dring[h2 * 2] = nx[0];
+        dring[h2 * 2 + 1] = nx[64];
+      }
     }
+  };
+  for (int t = 0; t < a.ncpc; ++t) {
+    // this step's input projection (issued early: in flight under the MFMAs)
+    float gxr[4][8];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      int m = m0 + kq * 4 + reg;
+      m = m < a.M ? m : a.M - 1;
+      const float* gx = a.gx + ((long)m * a.ncpc + t) * 1024 + w * 128 + l15;
+#pragma unroll
+      for (int c8 = 0; c8 < 8; ++c8) gxr[reg][c8] = gx[c8 * 16];
+    }
+    __syncthreads();  // hbuf holds h_{t-1}
+    f32x4v acc[8];
+#pragma unroll
+    for (int ns = 0; ns < 8; ++ns) acc[ns] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kp = 0; kp < 8; ++kp) {
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int kc = kp * 2 + h2;
+        f32x4 av = *(const f32x4*)(pa + kc * 16);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int ns = 0; ns < 8; ++ns)
+            acc[ns] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], ring[h2 * 8 + ns][s], acc[ns], 0, 0, 0);
+        const f32x4* nx = wf + (long)(((kc + 2) & 15) * 8) * 64;
+#pragma unroll
+        for (int ns = 0; ns < 8; ++ns) ring[h2 * 8 + ns] = nx[ns * 64];
+      }
+    }
+    if (t > 0 && a.down_wf) down_step(t - 1);
     __syncthreads();  // every wave has finished reading hbuf for this step
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int row = kq * 4 + reg;
-      int m = m0 + row;
+      const int m = m0 + row;
       const bool live = m < a.M;
-      m = live ? m : a.M - 1;
-      const float* gx = a.gx + ((long)m * a.ncpc + t) * 1024 + w * 256 + l15;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float ig = sigmoidf_(acc[0 + q][reg] + gx[0 * 64 + q * 16]);
-        float fg = sigmoidf_(acc[4 + q][reg] + gx[1 * 64 + q * 16]);
-        float gg = tanhf(acc[8 + q][reg] + gx[2 * 64 + q * 16]);
-        float og = sigmoidf_(acc[12 + q][reg] + gx[3 * 64 + q * 16]);
+      for (int q = 0; q < 2; ++q) {
+        float ig = sigmoidf_(acc[0 + q][reg] + gxr[reg][0 + q]);
+        float fg = sigmoidf_(acc[2 + q][reg] + gxr[reg][2 + q]);
+        float gg = tanhf(acc[4 + q][reg] + gxr[reg][4 + q]);
+        float og = sigmoidf_(acc[6 + q][reg] + gxr[reg][6 + q]);
         float cn = fg * creg[q][reg] + ig * gg;
         creg[q][reg] = cn;
         float hn = og * tanhf(cn);
-        const int j = w * 64 + q * 16 + l15;
+        const int j = w * 32 + q * 16 + l15;
         hbuf[row * H_LD + j] = hn;
         if (live) a.out[((long)m * a.ncpc + t) * 256 + j] = hn;
       }
@@ -153,11 +202,63 @@ __global__ __launch_bounds__(256) void lstm_kernel(LstmArgs a) {
     const int row = kq * 4 + reg;
     if (m0 + row < a.M) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int j = w * 64 + q * 16 + l15;
+      for (int q = 0; q < 2; ++q) {
+        const int j = w * 32 + q * 16 + l15;
         a.c_state[srow[reg] * 256 + j] = creg[q][reg];
         a.h_state[srow[reg] * 256 + j] = hbuf[row * H_LD + j];
       }
+    }
+  }
+  if (!a.down_wf) return;
+  // ---- downsample epilogue: + bias, LayerNorm over 256 outputs (8 waves), exact GELU -> e ----
+  down_step(a.ncpc - 1);
+  const int oc = w * 32 + l15;                       // output columns oc, oc + 16
+  const float b0 = a.down_b[oc], b1 = a.down_b[oc + 16];
+  float s[4], mean[4];
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    dacc[0][reg] += b0;
+    dacc[1][reg] += b1;
+    float t = dacc[0][reg] + dacc[1][reg];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o);   // 16 lanes that share kq
+    s[reg] = t;
+  }
+  if (l15 == 0)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) red[w * 16 + kq * 4 + reg] = s[reg];
+  __syncthreads();
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    float t = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t += red[u * 16 + kq * 4 + reg];
+    mean[reg] = t * (1.0f / 256.0f);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    float d0 = dacc[0][reg] - mean[reg], d1 = dacc[1][reg] - mean[reg];
+    float t = d0 * d0 + d1 * d1;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    s[reg] = t;
+  }
+  if (l15 == 0)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) red[w * 16 + kq * 4 + reg] = s[reg];
+  __syncthreads();
+  const float g0 = a.down_g[oc], g1 = a.down_g[oc + 16], be0 = a.down_beta[oc], be1 = a.down_beta[oc + 16];
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    float t = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t += red[u * 16 + kq * 4 + reg];
+    const float rstd = rsqrtf(t * (1.0f / 256.0f) + 1e-5f);
+    const int m = m0 + kq * 4 + reg;
+    if (m < a.M) {
+      a.e[(long)m * 256 + oc] = gelu_erf((dacc[0][reg] - mean[reg]) * rstd * g0 + be0);
+      a.e[(long)m * 256 + oc + 16] = gelu_erf((dacc[1][reg] - mean[reg]) * rstd * g1 + be1);
     }
   }
 }
@@ -449,9 +550,42 @@ __device__ __forceinline__ void block_max(float (&v)[N], float* red, int wave, i
   for (int i = 0; i < N; ++i) v[i] = fmaxf(fmaxf(red[i], red[N + i]), fmaxf(red[2 * N + i], red[3 * N + i]));
 }
 
+// y[s][j] = sum_k WT[k][j] * x[s][k] for the HB streams of the block: the k range is split over the 4
+// waves (64 k each), each lane accumulates 4 adjacent outputs with 16-byte weight loads (a 1 KiB
+// coalesced row per wave instruction), partials are combined through LDS.  Thread j returns y[.][j].
+template <int XS /* floats between consecutive streams in x */>
+__device__ __forceinline__ void block_matvec(const float* __restrict__ WT, const float* x, float* psum /* [4][HB][256] */,
+                                             float (&y)[HB], int j) {
+  const int lane = j & 63, w = j >> 6;
+  f32x4 part[HB];
+#pragma unroll
+  for (int s = 0; s < HB; ++s) part[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* wp = WT + (long)(w * 64) * 256 + lane * 4;
+#pragma unroll 2
+  for (int kk = 0; kk < 64; kk += 4) {
+    f32x4 wv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wv[u] = *(const f32x4*)(wp + (long)(kk + u) * 256);
+#pragma unroll
+    for (int s = 0; s < HB; ++s) {
+      f32x4 xv = *(const f32x4*)(x + s * XS + w * 64 + kk);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) part[s] += wv[u] * xv[u];
+    }
+  }
+  __syncthreads();   // psum may still be read from a previous call
+#pragma unroll
+  for (int s = 0; s < HB; ++s) *(f32x4*)&psum[(w * HB + s) * 256 + lane * 4] = part[s];
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < HB; ++s)
+    y[s] = (psum[(0 * HB + s) * 256 + j] + psum[(1 * HB + s) * 256 + j]) + (psum[(2 * HB + s) * 256 + j] + psum[(3 * HB + s) * 256 + j]);
+}
+
 __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
   __shared__ __attribute__((aligned(16))) float xs[HB][2][256];  // newest rows of the two towers
   __shared__ __attribute__((aligned(16))) float hs[HB][256];
+  __shared__ __attribute__((aligned(16))) float psum[4 * HB * 256];
   __shared__ float red[4 * 2 * HB];
   const int j = threadIdx.x, lane = j & 63, wave = j >> 6;
   const int b0 = blockIdx.x * HB;
@@ -468,26 +602,8 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
   __syncthreads();
   // combinator projections
   float ha[HB], hb[HB];
-#pragma unroll
-  for (int s = 0; s < HB; ++s) ha[s] = hb[s] = 0.f;
-  for (int k = 0; k < 256; k += 4) {
-    float wa[4], wb[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      wa[u] = a.waT[(k + u) * 256 + j];
-      wb[u] = a.wbT[(k + u) * 256 + j];
-    }
-#pragma unroll
-    for (int s = 0; s < HB; ++s) {
-      f32x4 xa = *(const f32x4*)&xs[s][0][k];
-      f32x4 xb = *(const f32x4*)&xs[s][1][k];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        ha[s] += wa[u] * xa[u];
-        hb[s] += wb[u] * xb[u];
-      }
-    }
-  }
+  block_matvec<512>(a.waT, &xs[0][0][0], psum, ha, j);
+  block_matvec<512>(a.wbT, &xs[0][1][0], psum, hb, j);
   // shared LayerNorm on both, exact GELU, sum
   float v[2 * HB];
 #pragma unroll
@@ -513,20 +629,10 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
   __syncthreads();
   // vap_head logits
   float lg[HB];
+  block_matvec<256>(a.hwT, &hs[0][0], psum, lg, j);
   const float hbias = a.hb[j];
 #pragma unroll
-  for (int s = 0; s < HB; ++s) lg[s] = hbias;
-  for (int k = 0; k < 256; k += 4) {
-    float wv[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) wv[u] = a.hwT[(k + u) * 256 + j];
-#pragma unroll
-    for (int s = 0; s < HB; ++s) {
-      f32x4 hv = *(const f32x4*)&hs[s][k];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) lg[s] += wv[u] * hv[u];
-    }
-  }
+  for (int s = 0; s < HB; ++s) lg[s] += hbias;
   float mxv[HB];
 #pragma unroll
   for (int s = 0; s < HB; ++s) mxv[s] = lg[s];
@@ -607,7 +713,7 @@ hipError_t launch_conv0(const Conv0Args& a, int B, hipStream_t st) {
   return hipGetLastError();
 }
 hipError_t launch_lstm(const LstmArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(lstm_kernel, dim3((a.M + 15) / 16), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(lstm_kernel, dim3((a.M + 15) / 16), dim3(512), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_gather_ln(const GatherArgs& a, hipStream_t st) {

@@ -197,12 +197,12 @@ def weights_fingerprint(cpc_sd, vap_sd) -> np.ndarray:
 # four gates of 64 hidden units (csrc/lstm.hip).
 
 def _lstm_perm() -> np.ndarray:
-    """new row index r' = w*256 + g*64 + jj  <-  old row g*256 + w*64 + jj."""
+    """new row index r' = w*128 + g*32 + jj  <-  old row g*256 + w*32 + jj  (8 waves x 32 hidden units)."""
     perm = np.empty(LSTM_GATES, dtype=np.int64)
-    for w in range(4):
+    for w in range(8):
         for g in range(4):
-            for jj in range(64):
-                perm[w * 256 + g * 64 + jj] = g * 256 + w * 64 + jj
+            for jj in range(32):
+                perm[w * 128 + g * 32 + jj] = g * 256 + w * 32 + jj
     return perm
 
 
@@ -217,9 +217,10 @@ def blob_entries(K: int, mode: str) -> List[Tuple[str, int]]:
         e.append((f"conv{i}.b", DIM))
         e.append((f"cn{i}.g", DIM)); e.append((f"cn{i}.b", DIM))
     e.append(("lstm.wih", LSTM_GATES * DIM))     # [perm row][256]  (plain GEMM operand)
-    e.append(("lstm.whh", LSTM_GATES * DIM))     # 16x16x4-MFMA fragment-major [4 w][16 kc][16 ns][64 lane][4]
+    e.append(("lstm.whh", LSTM_GATES * DIM))     # 16x16x4-MFMA fragment-major [8 w][16 kc][8 ns][64 lane][4]
     e.append(("lstm.b", LSTM_GATES))             # b_ih + b_hh, permuted
     e.append(("down.w", DIM * K * DIM))          # [cout][k*256+cin]
+    e.append(("down.wf", DIM * K * DIM))         # fragment-major [K steps][8 w][16 kc][2 ns][64 lane][4]
     e.append(("down.b", DIM)); e.append(("down.g", DIM)); e.append(("down.beta", DIM))
     for l in range(4):
         p = f"L{l}"
@@ -301,11 +302,14 @@ def pack_blob(cpc_sd: Dict[str, np.ndarray], vap_sd: Dict[str, np.ndarray], mode
     wih = A(cpc_sd["gAR.baseNet.weight_ih_l0"])[perm]
     whh = A(cpc_sd["gAR.baseNet.weight_hh_l0"])[perm]
     put("lstm.wih", wih)
-    # row = w*256 + ns*16 + l15 ; k = kc*16 + kq*4 + u  ->  [w][kc][ns][lane = kq*16 + l15][u]
-    put("lstm.whh", whh.reshape(4, 16, 16, 16, 4, 4).transpose(0, 3, 1, 4, 2, 5))
+    # row = w*128 + ns*16 + l15 ; k = kc*16 + kq*4 + u  ->  [w][kc][ns][lane = kq*16 + l15][u]
+    put("lstm.whh", whh.reshape(8, 8, 16, 16, 4, 4).transpose(0, 3, 1, 4, 2, 5))
     put("lstm.b", (A(cpc_sd["gAR.baseNet.bias_ih_l0"]) + A(cpc_sd["gAR.baseNet.bias_hh_l0"]))[perm])
     wd = A(vap_sd["encoder.downsample.1.weight"])        # [cout, cin, K]
     put("down.w", wd.transpose(0, 2, 1))
+    # out o = w*32 + ns*16 + l15 ; in c = kc*16 + kq*4 + u ; step t  ->  [t][w][kc][ns][lane = kq*16 + l15][u]
+    Kd = wd.shape[2]
+    put("down.wf", wd.transpose(2, 0, 1).reshape(Kd, 8, 2, 16, 16, 4, 4).transpose(0, 1, 4, 2, 5, 3, 6))
     put("down.b", A(vap_sd["encoder.downsample.1.bias"]))
     put("down.g", A(vap_sd["encoder.downsample.2.ln.weight"]))
     put("down.beta", A(vap_sd["encoder.downsample.2.ln.bias"]))
