@@ -117,6 +117,8 @@ def test_aux_heads(name):
             np.testing.assert_allclose(o["aux"][:, 1], c.z["p_nod_short"][f].reshape(-1), rtol=0, atol=TOL)
             np.testing.assert_allclose(o["aux"][:, 2], c.z["p_nod_long"][f].reshape(-1), rtol=0, atol=TOL)
             np.testing.assert_allclose(o["aux"][:, 3], c.z["p_nod_long_p"][f].reshape(-1), rtol=0, atol=TOL)
+            n = min(f + 1, c.T)        # p_bc for every row of the window (batch-index quirk of the reference)
+            np.testing.assert_allclose(o["logits"][:, :n], c.z["p_bc"][f][:, :n], rtol=0, atol=TOL)
     eng.close()
 
 

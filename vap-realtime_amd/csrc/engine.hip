@@ -330,6 +330,24 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
   return VAPX_OK;
 }
 
+// nod variant: p_bc = sigmoid(bc_head(comb)) for EVERY row of the window (vap_nod_main.py:276 indexes the
+// batch dim, so all n rows are emitted); one wave per (stream, row); written over the (unused in
+// nod mode) logits slots of the output row.
+__global__ void pbc_rows_kernel(const float* comb, const float* w, const float* bias, const int* bn, float* out,
+                                int B, int T, int out_stride) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long)B * T) return;
+  const int b = (int)(row / T), t = (int)(row - (long)b * T);
+  float v = 0.f;
+  if (t < bn[b]) {
+    f32x4 x = *(const f32x4*)(comb + row * 256 + lane * 4), ww = *(const f32x4*)(w + lane * 4);
+    float d = wave_sum(x[0] * ww[0] + x[1] * ww[1] + x[2] * ww[2] + x[3] * ww[3]);
+    v = 1.0f / (1.0f + expf(-(d + bias[0])));
+  }
+  if (lane == 0 && t < 256) out[(long)b * out_stride + VAPX_OUT_LOGITS + t] = v;
+}
+
 __global__ void fill_int_kernel(int* p, int v, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -363,6 +381,22 @@ int upload_ids(vapx_engine* h, int n, const int32_t* ids, int flags, hipStream_t
 }
 
 
+// Combinator on ALL rows: comb = gelu(LN(a.Wa^T)) + gelu(LN(b.Wb^T)), shared LN (modules.py:449-464).
+// Tower rows of channel c of stream b sit at ((b*2+c)*T + t).  Result in sc.xmid as [n][T][256].
+int run_combinator_all_rows(vapx_engine* h, const Scratch& sc, int n, hipStream_t st) {
+  const int T = h->T, M = n * T;
+  for (int c = 0; c < 2; ++c) {
+    RowMap am{(long)2 * T * 256, 256, T};
+    GemmArgs g = gemm_args(sc.xl[4] + (long)c * T * 256, am, h->W(c ? "comb.wb" : "comb.wa"), M, 256, 256,
+                           c ? sc.qx : sc.att, contiguous_rows(256));
+    g.gamma = h->W("comb.g"); g.beta = h->W("comb.b");
+    HIPCHK(h, gemm(h, g, EPI_BIAS_LN_GELU, st));
+  }
+  const long tot = (long)M * 256;
+  hipLaunchKernelGGL(add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, sc.xmid, sc.att, sc.qx, tot);
+  return VAPX_OK;
+}
+
 // one sub-batch of a tick: encoder -> ring -> transformer -> heads.  `b0` is the offset of the
 // group inside the caller's batch (identity stream ids when ids == nullptr start at b0).
 int step_group(vapx_engine* h, const Scratch& sc, int nb, int b0, const int* ids, const float* audio, int spc,
@@ -378,7 +412,8 @@ int step_group(vapx_engine* h, const Scratch& sc, int nb, int b0, const int* ids
   ga.x0 = sc.xl[0]; ga.xn = sc.xn; ga.gamma = h->layer[0].ln_self_g; ga.beta = h->layer[0].ln_self_b;
   ga.B = nb; ga.T = h->T; ga.rows_in = 0;
   { ProfScope ps(h, CLS_GATHER, st); HIPCHK(h, launch_gather_ln(ga, st)); }
-  const bool prune = !(h->cfg.flags & VAPX_FLAG_FULL_LAST_LAYER);
+  // the nod variant emits p_bc for every row of the window, which needs the whole last layer
+  const bool prune = !(h->cfg.flags & VAPX_FLAG_FULL_LAST_LAYER) && h->cfg.mode != VAPX_MODE_NOD;
   rc = run_layers(h, sc, nb, st, 0, 4, prune);
   if (rc) return rc;
   HeadArgs ha;
@@ -388,6 +423,14 @@ int step_group(vapx_engine* h, const Scratch& sc, int nb, int b0, const int* ids
   ha.aw = h->W("aux.w"); ha.ab = h->W("aux.b"); ha.out = out; ha.B = nb; ha.T = h->T; ha.mode = h->cfg.mode;
   ha.out_stride = VAPX_OUT_STRIDE;
   { ProfScope ps(h, CLS_HEAD, st); HIPCHK(h, launch_head(ha, st)); }
+  if (h->cfg.mode == VAPX_MODE_NOD) {
+    rc = run_combinator_all_rows(h, sc, nb, st);
+    if (rc) return rc;
+    const long rows = (long)nb * h->T;
+    hipLaunchKernelGGL(pbc_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, sc.xmid, h->W("aux.w") + 4 * 256,
+                       h->W("aux.b") + 4, sc.bn, out, nb, h->T, VAPX_OUT_STRIDE);
+    HIPCHK(h, hipGetLastError());
+  }
   return VAPX_OK;
 }
 
@@ -514,7 +557,7 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
   CR(dalloc(&h->sc.qkv, rows * 768));
   CR(dalloc(&h->sc.qx, rows * 256));
   CR(dalloc(&h->sc.kvx, rows * 512));
-  CR(dalloc(&h->sc.ffn, rows * 768));
+  h->sc.ffn = nullptr;  // FFN hidden activations never leave the fused FFN block
   for (int i = 0; i < 6; ++i) CR(dalloc(&h->sc.last[i], B * 2 * 256));
   CR(hipHostMalloc((void**)&h->out_pinned, B * VAPX_OUT_STRIDE * sizeof(float), hipHostMallocDefault));
   CR(hipHostMalloc((void**)&h->ids_pinned, B * sizeof(int), hipHostMallocDefault));
@@ -686,18 +729,8 @@ int vapx_transformer(vapx_handle h, int32_t n, int32_t rows, const float* x, flo
   if (o) hipLaunchKernelGGL(compact_rows_kernel, dim3(cgrid), dim3(256), 0, st, o, h->sc.xl[1], T, rows, nro);
   if (x12) hipLaunchKernelGGL(compact_rows_kernel, dim3(cgrid), dim3(256), 0, st, x12, h->sc.xl[4], T, rows, nro);
   if (comb) {
-    // Combinator on all rows: gelu(LN(a.Wa^T)) + gelu(LN(b.Wb^T)), shared LN (modules.py:449-464).
-    // Tower rows of channel c of stream b sit at ((b*2+c)*T + t): address them with a RowMap.
-    const int M = n * T;
-    for (int c = 0; c < 2; ++c) {
-      RowMap am{(long)2 * T * 256, 256, T};
-      GemmArgs g = gemm_args(h->sc.xl[4] + (long)c * T * 256, am, h->W(c ? "comb.wb" : "comb.wa"), M, 256, 256,
-                             c ? h->sc.qx : h->sc.att, contiguous_rows(256));
-      g.gamma = h->W("comb.g"); g.beta = h->W("comb.b");
-      HIPCHK(h, gemm(h, g, EPI_BIAS_LN_GELU, st));
-    }
-    const long tot = (long)M * 256;
-    hipLaunchKernelGGL(add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->sc.xmid, h->sc.att, h->sc.qx, tot);
+    rc = run_combinator_all_rows(h, h->sc, n, st);
+    if (rc) return rc;
     const long nrc = (long)n * rows;
     // xmid is [n][T][256]; compact with "2 channels" folded: treat as bc = stream
     hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)((nrc * 64 + 255) / 256)), dim3(256), 0, st, comb, h->sc.xmid, T, rows, nrc);

@@ -107,6 +107,7 @@ class VAPRealTime:
             self.result_p_nod_short = [float(o["aux"][0, 1])]
             self.result_p_nod_long = [float(o["aux"][0, 2])]
             self.result_p_nod_long_p = [float(o["aux"][0, 3])]
+            self.result_p_bc = o["logits"][0, :int(o["n"][0])].reshape(-1, 1).copy()   # all n rows (reference quirk)
         self.result_last_time = time.time()
         self.list_process_time_context.append(time.time() - time_start)
         if len(self.list_process_time_context) > self.CALC_PROCESS_TIME_INTERVAL:
