@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--groups", type=int, default=0, help="intra-tick overlap groups (0 = engine default)")
+    ap.add_argument("--mode", default="vap", choices=["vap", "bc", "nod"], help="model variant (config 5: bc / nod)")
     ap.add_argument("--subtick-streams", type=int, default=1024,
                     help="sub-tick size for the <=10 ms latency leg (0 = skip)")
     args = ap.parse_args()
@@ -84,8 +85,9 @@ def main():
     T = int(args.ctx_sec * hz)
     hop = 16000 // hz
     my_streams = shard_streams(S * world, world, rank)           # global stream ids of this rank
-    cpc, vap = W.synthetic_weights(0, hz, "vap")
-    eng = engine.Engine(W.pack_blob(cpc, vap), hz, args.ctx_sec, max_streams=S, device_id=local_rank, groups=args.groups)
+    cpc, vap = W.synthetic_weights(0, hz, args.mode)
+    eng = engine.Engine(W.pack_blob(cpc, vap, args.mode), hz, args.ctx_sec, max_streams=S, device_id=local_rank,
+                        groups=args.groups, mode=args.mode)
 
     NF = 32                                                      # distinct audio frames, cycled
     base = synth.dialogue_batch(my_streams[:min(S, 64)], hop * NF)   # [<=64,2,hop*NF]
@@ -142,6 +144,15 @@ def main():
     achieved_tf = flop_per_launch / avg_launch_s / 1e12
     gflop_sf = GFLOP_PER_STREAM_FRAME.get((hz, T), 2.0 * sum(macs.values()) / 1e9)
 
+    traffic = None
+    try:   # HBM bytes/launch of the dominant kernel from the committed PMC passes (cannot be collected live)
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pt = json.load(f)
+        if S == 256 and hz == 20 and T == 50:
+            traffic = pt["256x20hz_T50"].get(dominant, {}).get("bytes_per_launch_corrected")
+    except Exception:
+        traffic = None
+
     result = {
         "metric": "VAP frames/sec (concurrent 16 kHz stereo streams, one frame per stream per step)",
         "value": value,
@@ -156,13 +167,13 @@ def main():
         "dtype": "f32",
         "data": "synthetic (seeded two-speaker dialogue audio, seeded random weights)",
         "config": {"workload": f"{S} concurrent synthetic stereo streams per GPU, {args.ctx_sec} s / {hz} Hz (T={T}), 1 MI355X per rank",
-                   "streams_per_gpu": S, "frame_hz": hz, "ctx_frames": T, "parallelism": f"stream-sharded x{world}, no collective"},
+                   "streams_per_gpu": S, "frame_hz": hz, "ctx_frames": T, "mode": args.mode, "parallelism": f"stream-sharded x{world}, no collective"},
         "realtime_streams_sustained": value / hz,
         "step_tflops": value * gflop_sf / 1e3,
         "step_frac_of_fp32_mfma_peak": value * gflop_sf / 1e3 / (FP32_MFMA_PEAK_TF * world),
-        "roofline": {"bound": "mfma", "kernel": f"gemm_f32_kernel ({dominant})", "achieved": achieved_tf,
+        "roofline": {"bound": "mfma", "kernel": {"ffn_block": "ffn_block_kernel", "attention": "attn_block_kernel"}.get(dominant, f"gemm_f32_kernel ({dominant})"), "achieved": achieved_tf,
                      "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": achieved_tf / FP32_MFMA_PEAK_TF,
-                     "traffic": None, "avg_launch_us": avg_launch_s * 1e6, "launches_per_step": launches_per_step,
+                     "traffic": traffic, "avg_launch_us": avg_launch_s * 1e6, "launches_per_step": launches_per_step,
                      "gflop_per_launch": flop_per_launch / 1e9},
         "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1])},
     }
@@ -179,7 +190,7 @@ def main():
         result["latency_ms_host_inclusive"] = {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)),
                                                "max": float(lat.max())}
 
-    if rank == 0 and not args.no_latency and args.subtick_streams > 0 and hz == 20:
+    if rank == 0 and not args.no_latency and args.subtick_streams > 0 and hz == 20 and args.mode == "vap":
         # "concurrent streams at <= 10 ms/frame p99": a frame period (50 ms at 20 Hz) is filled with
         # phase-staggered sub-ticks; each sub-tick is host audio -> results on host.  Streams one GPU
         # sustains = sub-tick size x (sub-ticks that fit into one frame period at the p99 latency).
@@ -203,7 +214,7 @@ def main():
             "note": "host-inclusive (pageable H2D + kernels + D2H + sync); streams = sub-tick size x floor(50 ms / p99)"}
         eng2.close()
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "vap":
         from oracle.vap_oracle import ServerFramer, VapOracle
         torch.set_num_threads(1)
         o = VapOracle(cpc, vap, hz, args.ctx_sec)
