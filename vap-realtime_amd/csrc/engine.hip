@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -82,6 +83,7 @@ struct vapx_engine {
   hipEvent_t gdone[kMaxGroups] = {};
   hipEvent_t gstart = nullptr;
   int n_groups = 1;
+  int ffn_tile_rows = 0;   // tuning knob (env VAPX_FFN_TILE): 32 or 64 rows per FFN-block workgroup
   float* out_pinned = nullptr;
   int* ids_pinned = nullptr;
   hipEvent_t ids_evt = nullptr;
@@ -289,6 +291,7 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
     FfnArgs fa;
     memset(&fa, 0, sizeof fa);
     fa.xn = sc.xn; fa.xmid = sc.xmid; fa.w0f = Lw.w0f; fa.w3f = Lw.w3f; fa.xout = xout; fa.M = M;
+    fa.tile_rows = h->ffn_tile_rows ? h->ffn_tile_rows : 32;
     if (l + 1 < l_end) {
       const Layer& Ln = h->layer[l + 1];
       fa.ln_g = Ln.ln_self_g; fa.ln_b = Ln.ln_self_b; fa.wqkvf = Ln.wqkvf; fa.qkv = sc.qkv; fa.n_qkv_chunks = 3;
@@ -561,6 +564,7 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
   for (int i = 0; i < 6; ++i) CR(dalloc(&h->sc.last[i], B * 2 * 256));
   CR(hipHostMalloc((void**)&h->out_pinned, B * VAPX_OUT_STRIDE * sizeof(float), hipHostMallocDefault));
   CR(hipHostMalloc((void**)&h->ids_pinned, B * sizeof(int), hipHostMallocDefault));
+  if (const char* ev = getenv("VAPX_FFN_TILE")) h->ffn_tile_rows = atoi(ev);
   h->n_groups = cfg->flags & 0xF;
   if (h->n_groups == 0) h->n_groups = 1;   // measured: no gain at 256 streams, +2 % at 4096 with 2
   if (h->n_groups > vapx_engine::kMaxGroups) h->n_groups = vapx_engine::kMaxGroups;

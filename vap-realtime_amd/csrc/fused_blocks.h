@@ -15,6 +15,7 @@ struct FfnArgs {
   const float* wkvxf;  // next layer's cross K,V projections, 2 fragment-major chunks (null: skip)
   float* kvx;          // [M][512]
   int n_qkv_chunks;    // 3 (Q,K,V) or 2 (K,V only: pass wqkvf + 65536)
+  int tile_rows;       // 32 (default) or 64 rows per workgroup
   int M;
 };
 

@@ -25,16 +25,23 @@ constexpr int LDH = 260;   // resident [32][256] buffer row stride (256 + 4 pad)
 // fragments are shared with nobody: they go global -> VGPR directly (one coalesced 1 KiB load per
 // 4 MFMAs) and the K loops contain no barrier and no LDS store at all.  Only the A operand (the 32
 // activation rows all four waves share) lives in LDS.
-__global__ __launch_bounds__(256, 2) void ffn_block_kernel(const FfnArgs g) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * 32 * LDH + 128];
-  float* sX = lds;                 // [32][260] LN_ffn(x) tile (A operand of FFN1)
-  float* sH = lds + 32 * LDH;      // [32][260] gelu chunk / raw x / LN_self(x)
-  float* red = sH + 32 * LDH;      // [4][32] row partials
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+// MT = 32-row sub-tiles per workgroup (1: 32 rows, 67 KB LDS, 2 workgroups/CU; 2: 64 rows, 133 KB,
+// 1 workgroup/CU but every weight fragment feeds two MFMAs -> half the L2->VGPR weight traffic).
+template <int MT>
+__global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const FfnArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int BM = 32 * MT;
+  float* sX = lds;                 // [BM][260] LN_ffn(x) tile (A operand of FFN1)
+  float* sH = lds + BM * LDH;      // [BM][260] gelu chunk / raw x / LN_self(x)
+  float* red = sH + BM * LDH;      // [4][BM] row partials
+  const int tid = threadIdx.x, lane = tid & 63;
+  // wave index as an SGPR: weight-fragment addresses become scalar base + lane offset (SALU pointer
+  // bumps, saddr loads) instead of per-lane 64-bit VALU adds — measured 2.8 -> ~1.6 VALU per MFMA
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5, kh = hi * 4;
-  const int m0 = blockIdx.x * 32;
+  const int m0 = blockIdx.x * BM;
 
-  for (int i = tid; i < 32 * 64; i += 256) {
+  for (int i = tid; i < BM * 64; i += 256) {
     int row = i >> 6, q = (i & 63) * 4;
     int m = m0 + row;
     m = m < g.M ? m : g.M - 1;
@@ -42,18 +49,17 @@ __global__ __launch_bounds__(256, 2) void ffn_block_kernel(const FfnArgs g) {
   }
   __syncthreads();
 
-  // acc[2] += A[32 x 256] (LDS) . Wsub^T for this wave's 64 columns; wfrag = 256x256 fragment block.
-  // Explicit register pipeline: the fragments of the next 8-kc block (16 x 1 KiB per wave) are in
-  // flight while the 64 MFMAs of the current block run (~4k cycles of cover for the L2 latency),
-  // and the first block of the NEXT contraction is fetched during the last block of this one.
-  f32x4 ring[16];   // weight fragments of 8 kc steps (2 per step), refilled in place one block ahead
-  auto wbase = [&](const float* wfrag) { return (const f32x4*)wfrag + (long)w * 32 * 2 * 64 + lane; };
-  auto fetch = [&](const float* wfrag, int) {
+  // acc[mt][2] += A[BM x 256] (LDS) . Wsub^T for this wave's 64 columns; wfrag = 256x256 fragment
+  // block.  Weight fragments run through an in-place register ring one 8-kc block ahead (~4k MFMA
+  // cycles of cover for the L2 latency), including across contraction boundaries (next_wfrag).
+  f32x4 ring[16];
+  auto wbase = [&](const float* wfrag) { return (const f32x4*)wfrag + (long)w * 32 * 2 * 64; };   // wave-uniform
+  auto fetch = [&](const float* wfrag) {
     const f32x4* wf = wbase(wfrag);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) ring[i] = wf[i * 64];
+    for (int i = 0; i < 16; ++i) ring[i] = wf[i * 64 + lane];
   };
-  auto mm = [&](f32x16(&acc)[2], const float* A, const float* wfrag, const float* next_wfrag) {
+  auto mm = [&](f32x16(&acc)[MT][2], const float* A, const float* wfrag, const float* next_wfrag) {
     const float* pa = A + l31 * LDH + kh;
     const f32x4* wf = wbase(wfrag);
     const f32x4* wnext = next_wfrag ? wbase(next_wfrag) : wf;   // no successor: harmless re-read
@@ -62,72 +68,86 @@ __global__ __launch_bounds__(256, 2) void ffn_block_kernel(const FfnArgs g) {
       const f32x4* nx = blk < 3 ? wf + (blk + 1) * 16 * 64 : wnext;
 #pragma unroll
       for (int k8 = 0; k8 < 8; ++k8) {
-        f32x4 a = *(const f32x4*)(pa + (blk * 8 + k8) * 8);
+        f32x4 a[MT];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], ring[k8 * 2][s], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], ring[k8 * 2 + 1][s], acc[1], 0, 0, 0);
-        }
-        ring[k8 * 2] = nx[(k8 * 2) * 64];
-        ring[k8 * 2 + 1] = nx[(k8 * 2 + 1) * 64];
+        for (int mt = 0; mt < MT; ++mt) a[mt] = *(const f32x4*)(pa + mt * 32 * LDH + (blk * 8 + k8) * 8);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], ring[k8 * 2][s], acc[mt][0], 0, 0, 0);
+            acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], ring[k8 * 2 + 1][s], acc[mt][1], 0, 0, 0);
+          }
+        ring[k8 * 2] = nx[(k8 * 2) * 64 + lane];
+        ring[k8 * 2 + 1] = nx[(k8 * 2 + 1) * 64 + lane];
       }
     }
   };
-  auto zero = [](f32x16(&acc)[2]) {
+  auto zero = [](f32x16(&acc)[MT][2]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[mt][0][r] = 0.f; acc[mt][1][r] = 0.f; }
   };
-  // accumulator (ns, r) <-> tile row lr = (r&3) + 8*(r>>2) + 4*hi, chunk column w*64 + ns*32 + l31
+  // accumulator (mt, ns, r) <-> tile row lr = 32mt + (r&3) + 8*(r>>2) + 4*hi, chunk column w*64 + ns*32 + l31
   const int ccol = w * 64 + l31;
-  auto store_global = [&](const f32x16(&acc)[2], float* base, int ld, int col0) {
+  auto store_global = [&](const f32x16(&acc)[MT][2], float* base, int ld, int col0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (m < g.M) {
-        float* p = base + (long)m * ld + col0 + ccol;
-        p[0] = acc[0][r];
-        p[32] = acc[1][r];
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (m < g.M) {
+          float* p = base + (long)m * ld + col0 + ccol;
+          p[0] = acc[mt][0][r];
+          p[32] = acc[mt][1][r];
+        }
       }
-    }
   };
-  auto to_sH = [&](const f32x16(&acc)[2]) {
+  auto to_sH = [&](const f32x16(&acc)[MT][2]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      sH[lr * LDH + ccol] = acc[0][r];
-      sH[lr * LDH + ccol + 32] = acc[1][r];
-    }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int lr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        sH[lr * LDH + ccol] = acc[mt][0][r];
+        sH[lr * LDH + ccol + 32] = acc[mt][1][r];
+      }
   };
 
   // ---- feed-forward: x = xmid + gelu(xn W0^T) W3^T, hidden processed in 3 chunks of 256 ----
   const int nq = g.wqkvf ? g.n_qkv_chunks : 0;
   const float* after_ffn = g.wkvxf ? g.wkvxf : (nq ? g.wqkvf : nullptr);
-  f32x16 out[2];
+  f32x16 out[MT][2];
   zero(out);
-  fetch(g.w0f, 0);
+  fetch(g.w0f);
   for (int c = 0; c < 3; ++c) {
-    f32x16 hacc[2];
+    f32x16 hacc[MT][2];
     zero(hacc);
     mm(hacc, sX, g.w0f + (long)c * 65536, g.w3f + (long)c * 65536);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      hacc[0][r] = gelu_erf(hacc[0][r]);
-      hacc[1][r] = gelu_erf(hacc[1][r]);
-      if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        hacc[mt][0][r] = gelu_erf(hacc[mt][0][r]);
+        hacc[mt][1][r] = gelu_erf(hacc[mt][1][r]);
+        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
     __syncthreads();          // every wave is done reading the previous chunk from sH
     to_sH(hacc);
     __syncthreads();
     mm(out, sH, g.w3f + (long)c * 65536, c < 2 ? g.w0f + (long)(c + 1) * 65536 : after_ffn);
   }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-    m = m < g.M ? m : g.M - 1;
-    const float* rp = g.xmid + (long)m * 256 + ccol;
-    out[0][r] += rp[0];
-    out[1][r] += rp[32];
-  }
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      m = m < g.M ? m : g.M - 1;
+      const float* rp = g.xmid + (long)m * 256 + ccol;
+      out[mt][0][r] += rp[0];
+      out[mt][1][r] += rp[32];
+    }
   store_global(out, g.xout, 256, 0);
 
   // ---- next layer's cross K,V from the RAW layer output ----
@@ -136,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void ffn_block_kernel(const FfnArgs g) {
     to_sH(out);
     __syncthreads();
     for (int nc = 0; nc < 2; ++nc) {
-      f32x16 acc[2];
+      f32x16 acc[MT][2];
       zero(acc);
       mm(acc, sH, g.wkvxf + (long)nc * 65536, nc == 0 ? g.wkvxf + 65536 : (nq ? g.wqkvf : nullptr));
       store_global(acc, g.kvx, 512, nc * 256);
@@ -144,44 +164,56 @@ __global__ __launch_bounds__(256, 2) void ffn_block_kernel(const FfnArgs g) {
   }
   // ---- next layer's self Q,K,V from LayerNorm(x) ----
   if (nq) {
-    float s[16], mean[16];
+    float s[MT][16], mean[MT][16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = half_sum(out[0][r] + out[1][r]);
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[mt][r] = half_sum(out[mt][0][r] + out[mt][1][r]);
     __syncthreads();          // also: every wave is done reading sH (cross K,V)
     if (l31 == 0)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) red[w * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = s[r];
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[w * BM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = s[mt][r];
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      mean[r] = (red[lr] + red[32 + lr] + red[64 + lr] + red[96 + lr]) * (1.0f / 256.0f);
-    }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int lr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        mean[mt][r] = (red[lr] + red[BM + lr] + red[2 * BM + lr] + red[3 * BM + lr]) * (1.0f / 256.0f);
+      }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float d0 = out[0][r] - mean[r], d1 = out[1][r] - mean[r];
-      s[r] = half_sum(d0 * d0 + d1 * d1);
-    }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float d0 = out[mt][0][r] - mean[mt][r], d1 = out[mt][1][r] - mean[mt][r];
+        s[mt][r] = half_sum(d0 * d0 + d1 * d1);
+      }
     if (l31 == 0)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) red[w * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = s[r];
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[w * BM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = s[mt][r];
     __syncthreads();
     const float g0 = g.ln_g[ccol], g1 = g.ln_g[ccol + 32], b0 = g.ln_b[ccol], b1 = g.ln_b[ccol + 32];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      float var = (red[lr] + red[32 + lr] + red[64 + lr] + red[96 + lr]) * (1.0f / 256.0f);
-      float rstd = rsqrtf(var + 1e-5f);
-      sH[lr * LDH + ccol] = (out[0][r] - mean[r]) * rstd * g0 + b0;
-      sH[lr * LDH + ccol + 32] = (out[1][r] - mean[r]) * rstd * g1 + b1;
-    }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int lr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float var = (red[lr] + red[BM + lr] + red[2 * BM + lr] + red[3 * BM + lr]) * (1.0f / 256.0f);
+        float rstd = rsqrtf(var + 1e-5f);
+        sH[lr * LDH + ccol] = (out[mt][0][r] - mean[mt][r]) * rstd * g0 + b0;
+        sH[lr * LDH + ccol + 32] = (out[mt][1][r] - mean[mt][r]) * rstd * g1 + b1;
+      }
     __syncthreads();
     for (int nc = 0; nc < nq; ++nc) {
-      f32x16 acc[2];
+      f32x16 acc[MT][2];
       zero(acc);
       mm(acc, sH, g.wqkvf + (long)nc * 65536, nc + 1 < nq ? g.wqkvf + (long)(nc + 1) * 65536 : nullptr);
-      store_global(acc, g.qkv, g.n_qkv_chunks * 256, nc * 256);
+      store_global(acc, g.qkv, nq * 256, nc * 256);
     }
   }
 }
@@ -205,7 +237,8 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
   __shared__ __attribute__((aligned(16))) float lds[4 * 64 * KV_LD2 + 256];
   float* sAtt = lds;                        // [64][260] (aliases the V tiles after a barrier)
   float* red = lds + 4 * 64 * KV_LD2;       // [4][64]
-  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int h = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar wave / head index (see ffn_block_kernel)
   const int l31 = lane & 31, hi = lane >> 5, kh = hi * 4;
   const int bc = blockIdx.x, b = bc >> 1, T = a.T;
   const int n = a.bn[b];
@@ -319,11 +352,11 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
   // ---- projection(s): [64 x 256] (LDS) . W^T, wave h owns columns 64h..64h+63 ----
   const int w = h;
   f32x4 ring[16];
-  auto wbase = [&](const float* wfrag) { return (const f32x4*)wfrag + (long)w * 32 * 2 * 64 + lane; };
+  auto wbase = [&](const float* wfrag) { return (const f32x4*)wfrag + (long)w * 32 * 2 * 64; };   // wave-uniform
   auto fetch = [&](const float* wfrag) {
     const f32x4* wf = wbase(wfrag);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) ring[i] = wf[i * 64];
+    for (int i = 0; i < 16; ++i) ring[i] = wf[i * 64 + lane];
   };
   auto mm = [&](f32x16(&acc)[4], const float* wfrag, const float* next_wfrag) {
     const float* pa = sAtt + l31 * 260 + kh;
@@ -343,8 +376,8 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
           acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], ring[k8 * 2][s], acc[2], 0, 0, 0);
           acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], ring[k8 * 2 + 1][s], acc[3], 0, 0, 0);
         }
-        ring[k8 * 2] = nx[(k8 * 2) * 64];
-        ring[k8 * 2 + 1] = nx[(k8 * 2 + 1) * 64];
+        ring[k8 * 2] = nx[(k8 * 2) * 64 + lane];
+        ring[k8 * 2 + 1] = nx[(k8 * 2 + 1) * 64 + lane];
       }
     }
   };
@@ -445,6 +478,15 @@ hipError_t launch_attn_block(const AttnBlockArgs& a, int B, hipStream_t st) {
 
 hipError_t launch_ffn_block(const FfnArgs& a, hipStream_t st) {
   if (a.M <= 0) return hipSuccess;
-  hipLaunchKernelGGL(ffn_block_kernel, dim3((a.M + 31) / 32), dim3(256), 0, st, a);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)ffn_block_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_block_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const int mt = a.tile_rows == 64 ? 2 : 1;
+  const size_t lds = (size_t)(2 * 32 * mt * LDH + 4 * 32 * mt) * sizeof(float);
+  if (mt == 2) hipLaunchKernelGGL(ffn_block_kernel<2>, dim3((a.M + 63) / 64), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL(ffn_block_kernel<1>, dim3((a.M + 31) / 32), dim3(256), lds, st, a);
   return hipGetLastError();
 }

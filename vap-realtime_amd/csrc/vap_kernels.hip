@@ -84,7 +84,8 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(512) void lstm_kernel(LstmArgs a) {
   __shared__ __attribute__((aligned(16))) float hbuf[16 * H_LD];
   __shared__ float red[8 * 16];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar wave index -> SGPR-based fragment addressing
   const int l15 = lane & 15, kq = lane >> 4;
   const int m0 = blockIdx.x * 16;
 
@@ -108,19 +109,19 @@ __global__ __launch_bounds__(512) void lstm_kernel(LstmArgs a) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) creg[q][reg] = a.c_state[srow[reg] * 256 + w * 32 + q * 16 + l15];
   }
-  const f32x4* wf = (const f32x4*)a.wfrag + (long)w * 16 * 8 * 64 + lane;      // [8 w][16 kc][8 ns][64]
-  const f32x4* df = (const f32x4*)a.down_wf + (long)w * 16 * 2 * 64 + lane;     // [T][8 w][16 kc][2 ns][64]
+  const f32x4* wf = (const f32x4*)a.wfrag + (long)w * 16 * 8 * 64;      // [8 w][16 kc][8 ns][64], wave-uniform
+  const f32x4* df = (const f32x4*)a.down_wf + (long)w * 16 * 2 * 64;     // [T][8 w][16 kc][2 ns][64]
   const float* pa = &hbuf[l15 * H_LD + kq * 4];
   // W_hh fragments run through a register ring 2 kc (= 64 MFMAs) ahead of their use; since every
   // step multiplies by the same W_hh the ring simply wraps from kc 15 to kc 0 of the next step, so
   // the L2 latency is never exposed — not even at step boundaries.
   f32x4 ring[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) ring[i] = wf[i * 64];
+  for (int i = 0; i < 16; ++i) ring[i] = wf[i * 64 + lane];
   f32x4 dring[4];
   if (a.down_wf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dring[i] = df[i * 64];
+    for (int i = 0; i < 4; ++i) dring[i] = df[i * 64 + lane];
   }
   f32x4v dacc[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
   auto down_step = [&](int t) {   // dacc += h_t (in hbuf) . Wd_t^T for this wave's 32 output columns
@@ -138,8 +139,8 @@ __global__ __launch_bounds__(512) void lstm_kernel(LstmArgs a) {
           dacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], dring[h2 * 2 + 1][s], dacc[1], 0, 0, 0);
         }
         const f32x4* nx = kc + 2 < 16 ? d + ((kc + 2) * 2) * 64 : dn + ((kc + 2 - 16) * 2) * 64;
-        dring[h2 * 2] = nx[0];
-        dring[h2 * 2 + 1] = nx[64];
+        dring[h2 * 2] = nx[lane];
+        dring[h2 * 2 + 1] = nx[64 + lane];
       }
     }
   };
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(512) void lstm_kernel(LstmArgs a) {
             acc[ns] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], ring[h2 * 8 + ns][s], acc[ns], 0, 0, 0);
         const f32x4* nx = wf + (long)(((kc + 2) & 15) * 8) * 64;
 #pragma unroll
-        for (int ns = 0; ns < 8; ++ns) ring[h2 * 8 + ns] = nx[ns * 64];
+        for (int ns = 0; ns < 8; ++ns) ring[h2 * 8 + ns] = nx[ns * 64 + lane];
       }
     }
     if (t > 0 && a.down_wf) down_step(t - 1);
