@@ -139,3 +139,61 @@ def test_state_roundtrip_and_reset():
     fresh = split_outputs(eng.step(c.new_samples(0), [0]))
     np.testing.assert_allclose(fresh["logits"], c.z["logits"][0], rtol=0, atol=TOL)
     eng.close()
+
+
+def test_5hz_k20_against_oracle():
+    """5 Hz frames: L = 3520, 20 CPC frames per VAP frame (downsample K = 20), T = 15 (3 s)."""
+    from oracle.vap_oracle import ServerFramer, VapOracle
+    from vap_realtime_amd import engine, synth, weights as W
+    cpc, vap = W.synthetic_weights(31, 5, "vap")
+    o = VapOracle(cpc, vap, 5, 3.0)
+    S, F_, hop = 2, 18, 3200
+    audio = synth.dialogue_batch([60, 61], hop * F_)
+    st, fr = o.new_state(S), ServerFramer(S, hop)
+    eng = engine.Engine(W.pack_blob(cpc, vap), 5, 3.0, max_streams=S)
+    assert eng.T == 15
+    for f in range(F_):
+        new = audio[:, :, f * hop:(f + 1) * hop]
+        want = o.step(fr.frame(new), st)
+        got = engine.split_outputs(eng.step(new))
+        for k in ("p_now", "p_future", "vad", "logits", "e"):
+            np.testing.assert_allclose(got[k], want[k], rtol=0, atol=TOL, err_msg=f"frame {f} {k}")
+    eng.close()
+
+
+def test_device_path_equals_host_path():
+    """vapx_step with device audio / device output / device stream ids on a non-default HIP stream
+    (what bench.py times) gives the same numbers as the host path."""
+    import torch
+    from vap_realtime_amd import engine
+    c = Case("multi3")
+    a, b = make_engine(c, max_streams=8), make_engine(c, max_streams=8)
+    ids = [6, 1, 3]
+    d_ids = torch.tensor(ids, dtype=torch.int32, device="cuda")
+    d_out = torch.zeros(3, engine.OUT_STRIDE, device="cuda")
+    side = torch.cuda.Stream()
+    for f in range(8):
+        new = c.new_samples(f)
+        want = a.step(new, ids)
+        d_audio = torch.from_numpy(np.ascontiguousarray(new)).cuda()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            b.step_device(3, d_audio.data_ptr(), c.hop, d_out.data_ptr(), ids_ptr=d_ids.data_ptr(), stream=side.cuda_stream)
+        side.synchronize()
+        np.testing.assert_array_equal(d_out.cpu().numpy(), want)
+    a.close(); b.close()
+
+
+def test_error_paths():
+    from vap_realtime_amd import engine
+    c = Case("vap20")
+    eng = make_engine(c, max_streams=2)
+    with pytest.raises(engine.VapxError, match="samples_per_ch"):
+        eng.step(np.zeros((1, 2, 123), np.float32))
+    with pytest.raises(engine.VapxError, match="out of range"):
+        eng.step(np.zeros((1, 2, 800), np.float32), [5])
+    with pytest.raises(engine.VapxError):
+        eng.step(np.zeros((3, 2, 800), np.float32))
+    with pytest.raises(engine.VapxError):
+        eng.reset_stream(2)
+    eng.close()
