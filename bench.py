@@ -39,10 +39,10 @@ def macs_per_stream_frame(hz: int, T: int) -> dict:
     m = {
         "conv0": 2 * P0 * D * 10,
         "gemm_cn_relu": 2 * (P1 * 8 + P2 * 4 + P3 * 4 + ncpc * 4) * D * D,
-        "lstm": 2 * ncpc * 2 * D * 4 * D,
-        "gemm_bias_ln_gelu": 2 * ncpc * D * D,
+        "lstm": 2 * ncpc * D * 4 * D + 2 * ncpc * D * D,                # recurrence (K=256) + fused downsample
+        "gemm_bias_ln_gelu": 0,
         # executed work with exact last-layer pruning (only the newest row of layer 3 is consumed):
-        "gemm_store": rows * D * 768,                                   # QKV of layer 0
+        "gemm_store": 2 * ncpc * D * 4 * D + 2 * D * 768,               # LSTM input projection + layer-0 QKV of the NEW row (others cached)
         "gemm_resid_ln": 0,
         "ffn_block": rows * D * (3 * 2 * 768 + 2 * 768 + 512 + 3 * 512),  # FFN x3 + next QKV (x2 full, 1 K/V only) + next cross-KV x3
         "last_row": 2 * (4 * D * D + 2 * D * 768),                      # layer 3 on one row per channel

@@ -35,7 +35,8 @@ struct Scratch {
   float *h0 = nullptr, *h1 = nullptr, *h2 = nullptr, *h3 = nullptr, *z = nullptr, *gx = nullptr, *lstm_out = nullptr, *e = nullptr;
   float* xl[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // layer inputs/outputs: x0, o, stereo0..2
   float *xn = nullptr, *xmid = nullptr, *att = nullptr, *qkv = nullptr, *qx = nullptr, *kvx = nullptr, *ffn = nullptr;
-  float* last[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [B*2][256] each: x, xn, q, att, xmid, out (last-row path)
+  float* last[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  float *en = nullptr, *qkv_new = nullptr;   // [B*2][256], [B*2][768]: LN0(e) and layer-0 Q|K|V of the new row  // [B*2][256] each: x, xn, q, att, xmid, out (last-row path)
   Scratch slice(size_t b0, const int* P, int ncpc, int T) const {
     Scratch s = *this;
     const size_t bc = b0 * 2, rows = bc * T;
@@ -46,6 +47,7 @@ struct Scratch {
     s.xn += rows * 256; s.xmid += rows * 256; s.att += rows * 256; s.qkv += rows * 768; s.qx += rows * 256;
     s.kvx += rows * 512; s.ffn += rows * 768;
     for (int i = 0; i < 6; ++i) s.last[i] += bc * 256;
+    s.en += bc * 256; s.qkv_new += bc * 768;
     return s;
   }
 };
@@ -53,7 +55,7 @@ struct Scratch {
 // per-stream state bases; for identity stream ids of a sub-batch starting at slot b0 the bases are
 // simply advanced by b0 streams
 struct StateView {
-  float *ring, *h_state, *c_state, *carry;
+  float *ring, *ring_qkv, *h_state, *c_state, *carry;
   int* frames_seen;
 };
 
@@ -69,7 +71,7 @@ struct vapx_engine {
   Layer layer[4];
 
   // per-stream state
-  float *ring = nullptr, *h_state = nullptr, *c_state = nullptr, *carry = nullptr;
+  float *ring = nullptr, *ring_qkv = nullptr, *h_state = nullptr, *c_state = nullptr, *carry = nullptr;
   int* frames_seen = nullptr;
 
   // scratch (max_batch); every buffer is linear in the batch index, so a sub-batch starting at
@@ -224,6 +226,7 @@ int run_encoder(vapx_engine* h, const Scratch& sc, const StateView& sv, int B, c
   // downsample (single-output Conv1d == dense [ncpc*256 -> 256]) + LN + GELU fused into the LSTM kernel
   la.down_wf = h->W("down.wf"); la.down_b = h->W("down.b"); la.down_g = h->W("down.g"); la.down_beta = h->W("down.beta");
   la.e = sc.e;
+  la.ln0_g = h->layer[0].ln_self_g; la.ln0_b = h->layer[0].ln_self_b; la.en = use_state_meta ? sc.en : nullptr;
   { ProfScope ps(h, CLS_LSTM, st); HIPCHK(h, launch_lstm(la, st)); }
   return VAPX_OK;
 }
@@ -233,7 +236,7 @@ int run_encoder(vapx_engine* h, const Scratch& sc, const StateView& sv, int B, c
 // cross-attention, proj+residual+LN) -> fused FFN block, which also emits the NEXT layer's
 // projections so that only the first executed layer needs stand-alone projection GEMMs.
 int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_begin = 0, int l_end = 4,
-               bool prune_last = false) {
+               bool prune_last = false, bool qkv0_ready = false) {
   const int T = h->T;
   const int M = B * 2 * T;
   const RowMap r256 = contiguous_rows(256), r768 = contiguous_rows(768), r512 = contiguous_rows(512);
@@ -244,7 +247,7 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
     const float* xin = sc.xl[l];
     float* xout = sc.xl[l + 1];
     GemmArgs g;
-    if (l == l_begin) {
+    if (l == l_begin && !(l == 0 && qkv0_ready)) {
       g = gemm_args(sc.xn, r256, Lw.wqkv, M, 768, 256, sc.qkv, r768);
       HIPCHK(h, gemm(h, g, EPI_STORE, st));
       if (l > 0) {
@@ -406,18 +409,25 @@ int step_group(vapx_engine* h, const Scratch& sc, int nb, int b0, const int* ids
                float* out, hipStream_t st) {
   // identity ids: kernels index state by batch slot, so advance the state bases by b0 streams
   const size_t s0 = ids ? 0 : (size_t)b0;
-  const StateView sv{h->ring + s0 * 2 * h->T * 256, h->h_state + s0 * 512, h->c_state + s0 * 512,
+  const StateView sv{h->ring + s0 * 2 * h->T * 256, h->ring_qkv + s0 * 2 * h->T * 768, h->h_state + s0 * 512, h->c_state + s0 * 512,
                      h->carry + s0 * 2 * VAPX_PAD, h->frames_seen + s0};
   int rc = run_encoder(h, sc, sv, nb, ids, audio, spc, true, st);
   if (rc) return rc;
+  {  // layer-0 Q|K|V of the NEW row only: they are per-row functions of the embedding, so the other
+     // rows' values are cached next to the ring (exact; saves the [rows x 768] GEMM every tick)
+    GemmArgs g = gemm_args(sc.en, contiguous_rows(256), h->layer[0].wqkv, nb * 2, 768, 256, sc.qkv_new, contiguous_rows(768));
+    HIPCHK(h, gemm(h, g, EPI_STORE, st));
+  }
   GatherArgs ga;
-  ga.ring = sv.ring; ga.e = sc.e; ga.xin = nullptr; ga.ids = ids; ga.bn = sc.bn; ga.bhead = sc.bhead;
+  memset(&ga, 0, sizeof ga);
+  ga.ring = sv.ring; ga.ring_qkv = sv.ring_qkv; ga.qkv_new = sc.qkv_new; ga.qkv = sc.qkv;
+  ga.e = sc.e; ga.xin = nullptr; ga.ids = ids; ga.bn = sc.bn; ga.bhead = sc.bhead;
   ga.x0 = sc.xl[0]; ga.xn = sc.xn; ga.gamma = h->layer[0].ln_self_g; ga.beta = h->layer[0].ln_self_b;
   ga.B = nb; ga.T = h->T; ga.rows_in = 0;
   { ProfScope ps(h, CLS_GATHER, st); HIPCHK(h, launch_gather_ln(ga, st)); }
   // the nod variant emits p_bc for every row of the window, which needs the whole last layer
   const bool prune = !(h->cfg.flags & VAPX_FLAG_FULL_LAST_LAYER) && h->cfg.mode != VAPX_MODE_NOD;
-  rc = run_layers(h, sc, nb, st, 0, 4, prune);
+  rc = run_layers(h, sc, nb, st, 0, 4, prune, /*qkv0_ready=*/true);
   if (rc) return rc;
   HeadArgs ha;
   ha.x = prune ? sc.last[5] : sc.xl[4]; ha.x_last_only = prune ? 1 : 0; ha.o = sc.xl[1]; ha.e = sc.e; ha.bn = sc.bn; ha.ids = ids; ha.frames_seen = sv.frames_seen;
@@ -459,10 +469,10 @@ void vapx_destroy(vapx_handle h) {
   if (!h) return;
   (void)hipSetDevice(h->cfg.device_id);
   (void)hipDeviceSynchronize();
-  float* fp[] = {h->w, h->ring, h->h_state, h->c_state, h->carry, h->audio_dev, h->out_dev, h->sc.h0, h->sc.h1, h->sc.h2, h->sc.h3,
+  float* fp[] = {h->w, h->ring, h->ring_qkv, h->h_state, h->c_state, h->carry, h->audio_dev, h->out_dev, h->sc.h0, h->sc.h1, h->sc.h2, h->sc.h3,
                  h->sc.z, h->sc.lstm_out, h->sc.e, h->sc.xl[0], h->sc.xl[1], h->sc.xl[2], h->sc.xl[3], h->sc.xl[4], h->sc.xn, h->sc.xmid, h->sc.att,
                  h->sc.qkv, h->sc.qx, h->sc.kvx, h->sc.ffn, h->sc.gx, h->sc.last[0], h->sc.last[1], h->sc.last[2],
-                 h->sc.last[3], h->sc.last[4], h->sc.last[5]};
+                 h->sc.last[3], h->sc.last[4], h->sc.last[5], h->sc.en, h->sc.qkv_new};
   for (float* p : fp)
     if (p) (void)hipFree(p);
   int* ip[] = {h->frames_seen, h->ids_dev, h->sc.bn, h->sc.bhead};
@@ -535,6 +545,7 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
   const size_t S = cfg->max_streams, B = cfg->max_batch, T = h->T;
   const int* P = h->P;
   CR(dalloc(&h->ring, S * 2 * T * 256));
+  CR(dalloc(&h->ring_qkv, S * 2 * T * 768));   // layer-0 Q|K|V cache, one entry per ring row
   CR(dalloc(&h->h_state, S * 2 * 256));
   CR(dalloc(&h->c_state, S * 2 * 256));
   CR(dalloc(&h->carry, S * 2 * VAPX_PAD));
@@ -562,6 +573,8 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
   CR(dalloc(&h->sc.kvx, rows * 512));
   h->sc.ffn = nullptr;  // FFN hidden activations never leave the fused FFN block
   for (int i = 0; i < 6; ++i) CR(dalloc(&h->sc.last[i], B * 2 * 256));
+  CR(dalloc(&h->sc.en, B * 2 * 256));
+  CR(dalloc(&h->sc.qkv_new, B * 2 * 768));
   CR(hipHostMalloc((void**)&h->out_pinned, B * VAPX_OUT_STRIDE * sizeof(float), hipHostMallocDefault));
   CR(hipHostMalloc((void**)&h->ids_pinned, B * sizeof(int), hipHostMallocDefault));
   if (const char* ev = getenv("VAPX_FFN_TILE")) h->ffn_tile_rows = atoi(ev);
@@ -679,6 +692,20 @@ int vapx_set_state(vapx_handle h, int32_t sid, const float* ring, int32_t n_fram
     for (int c = 0; c < 2; ++c)
       HIPCHK(h, hipMemcpy(h->ring + ((size_t)sid * 2 + c) * T * 256, ring + (size_t)c * T * 256, (size_t)n_frames * 256 * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->frames_seen + sid, &n_frames, sizeof(int), hipMemcpyHostToDevice));
+    if (n_frames > 0) {
+      // rebuild the layer-0 Q|K|V cache of the imported rows: LN(ring rows) . Wqkv^T (slots 0..n-1)
+      hipLaunchKernelGGL(fill_int_kernel, dim3(1), dim3(64), 0, nullptr, h->sc.bn, T, 1);
+      GatherArgs ga;
+      memset(&ga, 0, sizeof ga);
+      ga.xin = h->ring + (size_t)sid * 2 * T * 256; ga.bn = h->sc.bn; ga.bhead = h->sc.bhead;
+      ga.x0 = h->sc.xl[0]; ga.xn = h->sc.xn; ga.gamma = h->layer[0].ln_self_g; ga.beta = h->layer[0].ln_self_b;
+      ga.B = 1; ga.T = T; ga.rows_in = T;
+      HIPCHK(h, launch_gather_ln(ga, nullptr));
+      GemmArgs g = gemm_args(h->sc.xn, contiguous_rows(256), h->layer[0].wqkv, 2 * T, 768, 256,
+                             h->ring_qkv + (size_t)sid * 2 * T * 768, contiguous_rows(768));
+      HIPCHK(h, launch_gemm_f32(g, EPI_STORE, 0, nullptr));
+      HIPCHK(h, hipDeviceSynchronize());
+    }
   }
   if (lstm) {
     for (int c = 0; c < 2; ++c) {
@@ -699,7 +726,7 @@ int vapx_encode_audio(vapx_handle h, int32_t n, const int32_t* stream_ids, const
   const int* ids = nullptr;
   int rc = upload_ids(h, n, stream_ids, 0, st, &ids);
   if (rc) return rc;
-  const StateView sv{h->ring, h->h_state, h->c_state, h->carry, h->frames_seen};
+  const StateView sv{h->ring, h->ring_qkv, h->h_state, h->c_state, h->carry, h->frames_seen};
   rc = run_encoder(h, h->sc, sv, n, ids, frames, h->L, false, st);
   if (rc) return rc;
   HIPCHK(h, hipMemcpyAsync(e, h->sc.e, (size_t)n * 2 * 256 * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -722,6 +749,7 @@ int vapx_transformer(vapx_handle h, int32_t n, int32_t rows, const float* x, flo
   const int l_begin = stage == 2 ? 1 : 0, l_end = stage == 1 ? 1 : 4;
   hipLaunchKernelGGL(fill_int_kernel, dim3((n + 255) / 256), dim3(256), 0, st, h->sc.bn, rows, n);
   GatherArgs ga;
+  memset(&ga, 0, sizeof ga);
   ga.ring = nullptr; ga.e = nullptr; ga.xin = x; ga.ids = nullptr; ga.bn = h->sc.bn; ga.bhead = h->sc.bhead;
   ga.x0 = h->sc.xl[l_begin]; ga.xn = h->sc.xn; ga.gamma = h->layer[l_begin].ln_self_g; ga.beta = h->layer[l_begin].ln_self_b;
   ga.B = n; ga.T = T; ga.rows_in = rows;

@@ -29,11 +29,17 @@ struct LstmArgs {
   const float* down_g;  // [256] LayerNorm weight
   const float* down_beta;
   float* e;             // [M][256] embeddings (written when down_wf != null)
+  const float* ln0_g;   // transformer layer-0 ln_self (for en)
+  const float* ln0_b;
+  float* en;            // [M][256] LayerNorm(e; ln0) or null
   int M, ncpc;
 };
 
 struct GatherArgs {
   float* ring;          // [S*2][T][256] or null (then xin is used)
+  float* ring_qkv;      // [S*2][T][768] cached layer-0 Q|K|V per ring row, or null
+  const float* qkv_new; // [B*2][768] this frame's layer-0 Q|K|V (when ring_qkv)
+  float* qkv;           // [B*2][T][768] chronological gather target (when ring_qkv)
   const float* e;       // [B*2][256] this frame's embeddings
   const float* xin;     // [B*2][rows_in][256] explicit context (stage API)
   const int* ids;

@@ -250,6 +250,7 @@ __global__ __launch_bounds__(512) void lstm_kernel(LstmArgs a) {
     for (int reg = 0; reg < 4; ++reg) red[w * 16 + kq * 4 + reg] = s[reg];
   __syncthreads();
   const float g0 = a.down_g[oc], g1 = a.down_g[oc + 16], be0 = a.down_beta[oc], be1 = a.down_beta[oc + 16];
+  float ev[2][4];
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
     float t = 0.f;
@@ -257,9 +258,55 @@ __global__ __launch_bounds__(512) void lstm_kernel(LstmArgs a) {
     for (int u = 0; u < 8; ++u) t += red[u * 16 + kq * 4 + reg];
     const float rstd = rsqrtf(t * (1.0f / 256.0f) + 1e-5f);
     const int m = m0 + kq * 4 + reg;
+    ev[0][reg] = gelu_erf((dacc[0][reg] - mean[reg]) * rstd * g0 + be0);
+    ev[1][reg] = gelu_erf((dacc[1][reg] - mean[reg]) * rstd * g1 + be1);
     if (m < a.M) {
-      a.e[(long)m * 256 + oc] = gelu_erf((dacc[0][reg] - mean[reg]) * rstd * g0 + be0);
-      a.e[(long)m * 256 + oc + 16] = gelu_erf((dacc[1][reg] - mean[reg]) * rstd * g1 + be1);
+      a.e[(long)m * 256 + oc] = ev[0][reg];
+      a.e[(long)m * 256 + oc + 16] = ev[1][reg];
+    }
+  }
+  if (!a.en) return;
+  // ---- en = LayerNorm(e; ln_self of transformer layer 0): input of the cached layer-0 Q/K/V ----
+  auto rows_allsum = [&](float(&v)[4]) {   // sum over the 256 columns of each of this lane's 4 rows
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      float t = v[reg];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o);
+      v[reg] = t;
+    }
+    __syncthreads();
+    if (l15 == 0)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) red[w * 16 + kq * 4 + reg] = v[reg];
+    __syncthreads();
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      float t = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t += red[u * 16 + kq * 4 + reg];
+      v[reg] = t;
+    }
+  };
+  float sm[4], sv[4];
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) sm[reg] = ev[0][reg] + ev[1][reg];
+  rows_allsum(sm);
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    sm[reg] *= (1.0f / 256.0f);
+    float d0 = ev[0][reg] - sm[reg], d1 = ev[1][reg] - sm[reg];
+    sv[reg] = d0 * d0 + d1 * d1;
+  }
+  rows_allsum(sv);
+  const float lg0 = a.ln0_g[oc], lg1 = a.ln0_g[oc + 16], lb0 = a.ln0_b[oc], lb1 = a.ln0_b[oc + 16];
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const float rstd = rsqrtf(sv[reg] * (1.0f / 256.0f) + 1e-5f);
+    const int m = m0 + kq * 4 + reg;
+    if (m < a.M) {
+      a.en[(long)m * 256 + oc] = (ev[0][reg] - sm[reg]) * rstd * lg0 + lb0;
+      a.en[(long)m * 256 + oc + 16] = (ev[1][reg] - sm[reg]) * rstd * lg1 + lb1;
     }
   }
 }
@@ -276,24 +323,41 @@ __global__ __launch_bounds__(256) void gather_ln_kernel(GatherArgs a) {
   const int bc = (int)(row / a.T), b = bc >> 1, c = bc & 1;
   const int n = a.bn[b];
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  f32x4 q0 = v, q1 = v, q2 = v;
   if (t < n) {
     if (a.ring) {
       const int sid = a.ids ? a.ids[b] : b;
       const int head = a.bhead[b];
       float* rb = a.ring + ((long)sid * 2 + c) * a.T * 256;
+      float* rq = a.ring_qkv ? a.ring_qkv + ((long)sid * 2 + c) * a.T * 768 : nullptr;
       if (t == n - 1) {
         v = *(const f32x4*)(a.e + (long)bc * 256 + lane * 4);
         *(f32x4*)(rb + (long)head * 256 + lane * 4) = v;
+        if (rq) {
+          const float* qn = a.qkv_new + (long)bc * 768 + lane * 4;
+          q0 = *(const f32x4*)(qn); q1 = *(const f32x4*)(qn + 256); q2 = *(const f32x4*)(qn + 512);
+          float* qs = rq + (long)head * 768 + lane * 4;
+          *(f32x4*)(qs) = q0; *(f32x4*)(qs + 256) = q1; *(f32x4*)(qs + 512) = q2;
+        }
       } else {
         int slot = head + 1 - n + t;
         slot = slot < 0 ? slot + a.T : slot;
         v = *(const f32x4*)(rb + (long)slot * 256 + lane * 4);
+        if (rq) {
+          const float* qs = rq + (long)slot * 768 + lane * 4;
+          q0 = *(const f32x4*)(qs); q1 = *(const f32x4*)(qs + 256); q2 = *(const f32x4*)(qs + 512);
+        }
       }
     } else {
       v = *(const f32x4*)(a.xin + ((long)bc * a.rows_in + t) * 256 + lane * 4);
     }
   }
   *(f32x4*)(a.x0 + row * 256 + lane * 4) = v;
+  if (a.ring && a.ring_qkv) {   // layer-0 Q/K/V come from the per-row cache: no LayerNorm / GEMM needed
+    float* qo = a.qkv + row * 768 + lane * 4;
+    *(f32x4*)(qo) = q0; *(f32x4*)(qo + 256) = q1; *(f32x4*)(qo + 512) = q2;
+    return;
+  }
   float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
   f32x4 d = v - mean;
   float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.0f / 256.0f);
