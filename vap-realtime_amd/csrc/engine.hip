@@ -791,7 +791,11 @@ int64_t vapx_peek(vapx_handle h, const char* name, float* dst, size_t max_floats
   else if (!strcmp(name, "o")) { src = h->sc.xl[1]; n = B * 2 * T * 256; }
   else if (!strcmp(name, "stereo0")) { src = h->sc.xl[2]; n = B * 2 * T * 256; }
   else if (!strcmp(name, "stereo1")) { src = h->sc.xl[3]; n = B * 2 * T * 256; }
-  else if (!strcmp(name, "stereo2")) { src = h->sc.xl[4]; n = B * 2 * T * 256; }
+  else if (!strcmp(name, "stereo2")) {
+    if (!(h->cfg.flags & VAPX_FLAG_FULL_LAST_LAYER) && h->cfg.mode != VAPX_MODE_NOD)
+      return fail(h, VAPX_E_INVAL, "\"stereo2\" is only materialised with VAPX_FLAG_FULL_LAST_LAYER (default: last layer runs on the newest row only)");
+    src = h->sc.xl[4]; n = B * 2 * T * 256;
+  }
   else return fail(h, VAPX_E_INVAL, "unknown buffer '%s'", name);
   if (n > max_floats) n = max_floats;
   HIPCHK(h, hipMemcpy(dst, src, n * sizeof(float), hipMemcpyDeviceToHost));
