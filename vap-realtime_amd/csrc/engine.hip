@@ -36,7 +36,8 @@ struct Scratch {
   float* xl[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // layer inputs/outputs: x0, o, stereo0..2
   float *xn = nullptr, *xmid = nullptr, *att = nullptr, *qkv = nullptr, *qx = nullptr, *kvx = nullptr, *ffn = nullptr;
   float* last[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  float *en = nullptr, *qkv_new = nullptr;   // [B*2][256], [B*2][768]: LN0(e) and layer-0 Q|K|V of the new row  // [B*2][256] each: x, xn, q, att, xmid, out (last-row path)
+  float *en = nullptr, *qkv_new = nullptr;   // [B*2][256], [B*2][768]: LN0(e) and layer-0 Q|K|V of the new row
+  float* lffn = nullptr;                     // [B*2][768] FFN hidden of the last-row path  // [B*2][256] each: x, xn, q, att, xmid, out (last-row path)
   Scratch slice(size_t b0, const int* P, int ncpc, int T) const {
     Scratch s = *this;
     const size_t bc = b0 * 2, rows = bc * T;
@@ -47,7 +48,7 @@ struct Scratch {
     s.xn += rows * 256; s.xmid += rows * 256; s.att += rows * 256; s.qkv += rows * 768; s.qx += rows * 256;
     s.kvx += rows * 512; s.ffn += rows * 768;
     for (int i = 0; i < 6; ++i) s.last[i] += bc * 256;
-    s.en += bc * 256; s.qkv_new += bc * 768;
+    s.en += bc * 256; s.qkv_new += bc * 768; s.lffn += bc * 768;
     return s;
   }
 };
@@ -328,10 +329,12 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
     g = gemm_args(latt, r256, Lw.wproj_x, Ml, 256, 256, lxmid, r256);
     g.resid = lxmid; g.C2 = lxn; g.gamma = Lw.ln_ffn_g; g.beta = Lw.ln_ffn_b;
     HIPCHK(h, launch_gemm_f32(g, EPI_RESID_LN, 0, st));
-    FfnArgs fa;
-    memset(&fa, 0, sizeof fa);
-    fa.xn = lxn; fa.xmid = lxmid; fa.w0f = Lw.w0f; fa.w3f = Lw.w3f; fa.xout = lout; fa.M = Ml;
-    HIPCHK(h, launch_ffn_block(fa, st));
+    // FFN on 2B rows: two plain GEMMs spread over more workgroups than one fused 32-row block would
+    g = gemm_args(lxn, r256, Lw.w0, Ml, 768, 256, sc.lffn, r768);
+    HIPCHK(h, launch_gemm_f32(g, EPI_GELU, 0, st));
+    g = gemm_args(sc.lffn, r768, Lw.w3, Ml, 256, 768, lout, r256);
+    g.resid = lxmid;
+    HIPCHK(h, launch_gemm_f32(g, EPI_RESID, 0, st));
   }
   return VAPX_OK;
 }
@@ -472,7 +475,7 @@ void vapx_destroy(vapx_handle h) {
   float* fp[] = {h->w, h->ring, h->ring_qkv, h->h_state, h->c_state, h->carry, h->audio_dev, h->out_dev, h->sc.h0, h->sc.h1, h->sc.h2, h->sc.h3,
                  h->sc.z, h->sc.lstm_out, h->sc.e, h->sc.xl[0], h->sc.xl[1], h->sc.xl[2], h->sc.xl[3], h->sc.xl[4], h->sc.xn, h->sc.xmid, h->sc.att,
                  h->sc.qkv, h->sc.qx, h->sc.kvx, h->sc.ffn, h->sc.gx, h->sc.last[0], h->sc.last[1], h->sc.last[2],
-                 h->sc.last[3], h->sc.last[4], h->sc.last[5], h->sc.en, h->sc.qkv_new};
+                 h->sc.last[3], h->sc.last[4], h->sc.last[5], h->sc.en, h->sc.qkv_new, h->sc.lffn};
   for (float* p : fp)
     if (p) (void)hipFree(p);
   int* ip[] = {h->frames_seen, h->ids_dev, h->sc.bn, h->sc.bhead};
@@ -575,6 +578,7 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
   for (int i = 0; i < 6; ++i) CR(dalloc(&h->sc.last[i], B * 2 * 256));
   CR(dalloc(&h->sc.en, B * 2 * 256));
   CR(dalloc(&h->sc.qkv_new, B * 2 * 768));
+  CR(dalloc(&h->sc.lffn, B * 2 * 768));
   CR(hipHostMalloc((void**)&h->out_pinned, B * VAPX_OUT_STRIDE * sizeof(float), hipHostMallocDefault));
   CR(hipHostMalloc((void**)&h->ids_pinned, B * sizeof(int), hipHostMallocDefault));
   if (const char* ev = getenv("VAPX_FFN_TILE")) h->ffn_tile_rows = atoi(ev);
