@@ -146,7 +146,7 @@ void geometry(int hz, int* hop, int* L, int P[5], int* ncpc) {
 }
 
 // kernel classes for profiling: 0..5 = GEMM by epilogue, then the rest
-enum { CLS_FFN = 6, CLS_LASTROW = 7, CLS_CONV0 = 8, CLS_LSTM = 9, CLS_GATHER = 10, CLS_ATTN = 11, CLS_HEAD = 12, CLS_COUNT = 13 };
+enum { CLS_CONVTAIL = 5, CLS_FFN = 6, CLS_LASTROW = 7, CLS_CONV0 = 8, CLS_LSTM = 9, CLS_GATHER = 10, CLS_ATTN = 11, CLS_HEAD = 12, CLS_COUNT = 13 };
 
 struct ProfScope {
   vapx_engine* h; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; int cls;
@@ -198,8 +198,10 @@ int run_encoder(vapx_engine* h, const Scratch& sc, const StateView& sv, int B, c
       {sc.h1, P[1], 1, 4, 2, sc.h2, P[2], 1, "2"},
       {sc.h2, P[2], 1, 4, 2, sc.h3, P[3], 1, "3"},
   };
+  // one stream per workgroup pays 27 % row padding: worth it only while the three GEMMs cannot fill the chip
+  const bool fused_tail = conv_tail_supported(P[1], h->ncpc) && !(h->cfg.flags & VAPX_FLAG_UNFUSED_CONV) && B <= 512;
   char nm[32];
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < (fused_tail ? 1 : 3); ++i) {
     const ConvSpec& c = cs[i];
     RowMap am{(long)(c.Pin + 2 * c.guard_in) * 256, (long)c.s * 256, c.Pout};
     RowMap cm{(long)(c.Pout + 2 * c.guard_out) * 256, 256, c.Pout};
@@ -210,7 +212,16 @@ int run_encoder(vapx_engine* h, const Scratch& sc, const StateView& sv, int B, c
     snprintf(nm, sizeof nm, "cn%s.b", c.idx); g.beta = h->W(nm);
     HIPCHK(h, gemm(h, g, EPI_CN_RELU, st));
   }
-  {  // conv4: only positions 1..P4-2 survive z[:, 1:-1] (encoder.py:76)
+  if (fused_tail) {
+    // conv2 -> conv3 -> conv4 for one stream per workgroup, intermediates in LDS
+    ConvTailArgs ct;
+    ct.h1 = sc.h1; ct.w2f = h->W("conv2.wf"); ct.w3f = h->W("conv3.wf"); ct.w4f = h->W("conv4.wf");
+    ct.b2 = h->W("conv2.b"); ct.g2 = h->W("cn2.g"); ct.be2 = h->W("cn2.b");
+    ct.b3 = h->W("conv3.b"); ct.g3 = h->W("cn3.g"); ct.be3 = h->W("cn3.b");
+    ct.b4 = h->W("conv4.b"); ct.g4 = h->W("cn4.g"); ct.be4 = h->W("cn4.b");
+    ct.z = sc.z; ct.P1 = P[1]; ct.ncpc = h->ncpc;
+    { ProfScope ps(h, CLS_CONVTAIL, st); HIPCHK(h, launch_conv_tail(ct, B, st)); }
+  } else {  // conv4: only positions 1..P4-2 survive z[:, 1:-1] (encoder.py:76)
     RowMap am{(long)(P[3] + 2) * 256, 2 * 256, h->ncpc};
     GemmArgs g = gemm_args(sc.h3 + 2 * 256, am, h->W("conv4.w"), B * 2 * h->ncpc, 256, 4 * 256, sc.z, contiguous_rows(256));
     g.bias = h->W("conv4.b"); g.gamma = h->W("cn4.g"); g.beta = h->W("cn4.b");

@@ -35,5 +35,19 @@ struct AttnBlockArgs {
   int T, ldq, ldkv, swap_kv;
 };
 
+struct ConvTailArgs {
+  const float* h1;     // [B*2][P1+2][256] conv1 output, channels-last, one zero guard row each side
+  const float* w2f;    // conv2 weight: 4 taps x fragment-major 256x256 block (tap t = W[:, :, t])
+  const float* w3f;
+  const float* w4f;
+  const float *b2, *g2, *be2;   // conv bias, ChannelNorm weight / bias
+  const float *b3, *g3, *be3;
+  const float *b4, *g4, *be4;
+  float* z;            // [B*2][ncpc][256] conv4 positions 1..ncpc
+  int P1, ncpc;
+};
+
+bool conv_tail_supported(int P1, int ncpc);
+hipError_t launch_conv_tail(const ConvTailArgs& a, int B, hipStream_t st);
 hipError_t launch_attn_block(const AttnBlockArgs& a, int B, hipStream_t st);   // T <= 64 only
 hipError_t launch_ffn_block(const FfnArgs& a, hipStream_t st);

@@ -468,7 +468,199 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv_tail_kernel: conv2 -> conv3 -> conv4 of the CPC encoder for ONE stream (both channels) per
+// workgroup, intermediates in LDS.
+// reference: CPCEncoder.forward encoder_components.py:98-104 (Conv1d k4 s2 p1 + ChannelNorm
+// (unbiased variance) + ReLU, three times); only conv4 positions 1..P4-2 survive z[:,1:-1]
+// (encoder.py:76).  At a few hundred streams these three layers are tiny GEMMs (M = 28, 14, 5 rows
+// per channel) that cannot fill 256 CUs one launch at a time; fused, every CU runs one stream's
+// whole tail.  Implicit GEMM: the A row of output position p is the 4 input rows 2p..2p+3 of the
+// guarded channels-last slab (tap t -> row 2p+t), K = 4 x 256; weights stream fragment-major per tap.
+// Requires P2 <= 32, 2*P3 <= 32, 2*ncpc <= 32 (20 Hz and 50 Hz frames).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void conv_tail_kernel(const ConvTailArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int P1 = g.P1, P2 = P1 / 2, P3 = P2 / 2, ncpc = g.ncpc;
+  const int rows_in = P1 + 2, rows2 = P2 + 2, rows3 = P3 + 2;
+  float* sIn = lds;                              // [P1+2][260]   one channel's conv1 output (guarded)
+  float* sH2 = sIn + rows_in * LDH;              // [2][P2+2][260] conv2 outputs of both channels (guarded)
+  float* red = sH2 + 2 * rows2 * LDH;            // [4][32]
+  float* sH3 = sIn;                              // [2][P3+2][260] conv3 outputs, aliases sIn once conv2 is done
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5, kh = hi * 4;
+  const int b = blockIdx.x;                      // stream in the batch
+  const int ccol = w * 64 + l31;
+
+  f32x4 ring[16];
+  auto wbase = [&](const float* wfrag) { return (const f32x4*)wfrag + (long)w * 32 * 2 * 64; };
+  auto fetch = [&](const float* wfrag) {
+    const f32x4* wf = wbase(wfrag);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ring[i] = wf[i * 64 + lane];
+  };
+  // acc += A(32 rows, this lane's row at `arow`, 256 k) . Wtap^T
+  auto mm = [&](f32x16(&acc)[2], const float* arow, const float* wfrag, const float* next_wfrag) {
+    const float* pa = arow + kh;
+    const f32x4* wf = wbase(wfrag);
+    const f32x4* wnext = next_wfrag ? wbase(next_wfrag) : wf;
+#pragma unroll 1
+    for (int blk = 0; blk < 4; ++blk) {
+      const f32x4* nx = blk < 3 ? wf + (blk + 1) * 16 * 64 : wnext;
+#pragma unroll
+      for (int k8 = 0; k8 < 8; ++k8) {
+        f32x4 a = *(const f32x4*)(pa + (blk * 8 + k8) * 8);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], ring[k8 * 2][s], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], ring[k8 * 2 + 1][s], acc[1], 0, 0, 0);
+        }
+        ring[k8 * 2] = nx[(k8 * 2) * 64 + lane];
+        ring[k8 * 2 + 1] = nx[(k8 * 2 + 1) * 64 + lane];
+      }
+    }
+  };
+  // bias + ChannelNorm (unbiased variance over the 256 channels) + ReLU on a 32-row tile
+  auto cn_relu = [&](f32x16(&acc)[2], const float* bias, const float* gam, const float* bet) {
+    const float bi0 = bias[ccol], bi1 = bias[ccol + 32];
+    float s[16], mean[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc[0][r] += bi0; acc[1][r] += bi1;
+      s[r] = half_sum(acc[0][r] + acc[1][r]);
+    }
+    __syncthreads();
+    if (l31 == 0)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[w * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = s[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      mean[r] = (red[lr] + red[32 + lr] + red[64 + lr] + red[96 + lr]) * (1.0f / 256.0f);
+      float d0 = acc[0][r] - mean[r], d1 = acc[1][r] - mean[r];
+      s[r] = half_sum(d0 * d0 + d1 * d1);
+    }
+    __syncthreads();
+    if (l31 == 0)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[w * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = s[r];
+    __syncthreads();
+    const float g0 = gam[ccol], g1 = gam[ccol + 32], b0 = bet[ccol], b1 = bet[ccol + 32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      float var = (red[lr] + red[32 + lr] + red[64 + lr] + red[96 + lr]) * (1.0f / 255.0f);
+      float rstd = rsqrtf(var + 1e-5f);
+      acc[0][r] = fmaxf((acc[0][r] - mean[r]) * rstd * g0 + b0, 0.f);
+      acc[1][r] = fmaxf((acc[1][r] - mean[r]) * rstd * g1 + b1, 0.f);
+    }
+  };
+  auto zero = [](f32x16(&acc)[2]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+  };
+
+  // zero the guard rows of sH2 (rows 0 and P2+1 of each channel slab); sH3's are written later
+  for (int i = tid; i < 4 * 64; i += 256) {
+    int u = i >> 7, which = (i >> 6) & 1, q = (i & 63) * 4;
+    *(f32x4*)&sH2[(u * rows2 + (which ? P2 + 1 : 0)) * LDH + q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  fetch(g.w2f);
+  // ---- conv2: one 32-row tile per channel ----
+  for (int u = 0; u < 2; ++u) {
+    __syncthreads();                         // previous channel's MFMAs are done with sIn
+    const float* src = g.h1 + ((long)b * 2 + u) * rows_in * 256;
+    for (int i = tid; i < rows_in * 64; i += 256) {
+      int row = i >> 6, q = (i & 63) * 4;
+      *(f32x4*)&sIn[row * LDH + q] = *(const f32x4*)(src + (long)row * 256 + q);
+    }
+    __syncthreads();
+    const int p = l31 < P2 ? l31 : P2 - 1;   // pad rows recompute the last position (discarded)
+    f32x16 acc[2];
+    zero(acc);
+#pragma unroll 1
+    for (int t = 0; t < 4; ++t)
+      mm(acc, &sIn[(2 * p + t) * LDH], g.w2f + (long)t * 65536,
+         t < 3 ? g.w2f + (long)(t + 1) * 65536 : (u == 0 ? g.w2f : g.w3f));
+    cn_relu(acc, g.b2, g.g2, g.be2);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (lr < P2) {
+        sH2[(u * rows2 + 1 + lr) * LDH + ccol] = acc[0][r];
+        sH2[(u * rows2 + 1 + lr) * LDH + ccol + 32] = acc[1][r];
+      }
+    }
+  }
+  __syncthreads();                           // sH2 complete; sIn is free -> becomes sH3
+  for (int i = tid; i < 4 * 64; i += 256) {
+    int u = i >> 7, which = (i >> 6) & 1, q = (i & 63) * 4;
+    *(f32x4*)&sH3[(u * rows3 + (which ? P3 + 1 : 0)) * LDH + q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // ---- conv3: both channels in one tile (rows r = u*P3 + p) ----
+  {
+    int r0 = l31 < 2 * P3 ? l31 : 2 * P3 - 1;
+    const int u = r0 / P3, p = r0 - u * P3;
+    f32x16 acc[2];
+    zero(acc);
+#pragma unroll 1
+    for (int t = 0; t < 4; ++t)
+      mm(acc, &sH2[(u * rows2 + 2 * p + t) * LDH], g.w3f + (long)t * 65536, t < 3 ? g.w3f + (long)(t + 1) * 65536 : g.w4f);
+    cn_relu(acc, g.b3, g.g3, g.be3);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (lr < 2 * P3) {
+        int uu = lr / P3, pp = lr - uu * P3;
+        sH3[(uu * rows3 + 1 + pp) * LDH + ccol] = acc[0][r];
+        sH3[(uu * rows3 + 1 + pp) * LDH + ccol + 32] = acc[1][r];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- conv4: positions 1..ncpc of both channels in one tile (rows r = u*ncpc + p') ----
+  {
+    int r0 = l31 < 2 * ncpc ? l31 : 2 * ncpc - 1;
+    const int u = r0 / ncpc, pq = r0 - u * ncpc;          // output position pq + 1 -> slab rows 2pq+2 ..
+    f32x16 acc[2];
+    zero(acc);
+#pragma unroll 1
+    for (int t = 0; t < 4; ++t)
+      mm(acc, &sH3[(u * rows3 + 2 * pq + 2 + t) * LDH], g.w4f + (long)t * 65536, t < 3 ? g.w4f + (long)(t + 1) * 65536 : nullptr);
+    cn_relu(acc, g.b4, g.g4, g.be4);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (lr < 2 * ncpc) {
+        int uu = lr / ncpc, pp = lr - uu * ncpc;
+        float* zp = g.z + (((long)b * 2 + uu) * ncpc + pp) * 256 + ccol;
+        zp[0] = acc[0][r];
+        zp[32] = acc[1][r];
+      }
+    }
+  }
+}
+
 }  // namespace
+
+bool conv_tail_supported(int P1, int ncpc) {
+  const int P2 = P1 / 2, P3 = P2 / 2;
+  return P2 <= 32 && 2 * P3 <= 32 && 2 * ncpc <= 32 && ((size_t)((P1 + 2) + 2 * (P2 + 2)) * LDH + 128) * 4 <= 160 * 1024;
+}
+
+hipError_t launch_conv_tail(const ConvTailArgs& a, int B, hipStream_t st) {
+  if (!conv_tail_supported(a.P1, a.ncpc)) return hipErrorInvalidValue;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const size_t lds = ((size_t)((a.P1 + 2) + 2 * (a.P1 / 2 + 2)) * LDH + 128) * sizeof(float);
+  hipLaunchKernelGGL(conv_tail_kernel, dim3(B), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
 
 hipError_t launch_attn_block(const AttnBlockArgs& a, int B, hipStream_t st) {
   if (a.T > 64) return hipErrorInvalidValue;

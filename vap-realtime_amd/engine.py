@@ -25,7 +25,7 @@ EXPORTS = ("vapx_abi_version", "vapx_blob_floats", "vapx_create", "vapx_destroy"
            "vapx_transformer", "vapx_peek", "vapx_gemm", "vapx_last_error", "vapx_profile_enable",
            "vapx_profile_read")
 PROF_CLASSES = {0: "gemm_store", 1: "gemm_gelu", 2: "gemm_resid", 3: "gemm_resid_ln", 4: "gemm_cn_relu",
-                5: "gemm_bias_ln_gelu", 6: "ffn_block", 7: "last_row", 8: "conv0", 9: "lstm", 10: "gather_ln", 11: "attention", 12: "head"}
+                5: "conv_tail", 6: "ffn_block", 7: "last_row", 8: "conv0", 9: "lstm", 10: "gather_ln", 11: "attention", 12: "head"}
 
 
 class VapxError(RuntimeError):

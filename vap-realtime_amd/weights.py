@@ -216,6 +216,8 @@ def blob_entries(K: int, mode: str) -> List[Tuple[str, int]]:
         e.append((f"conv{i}.w", DIM * k * DIM))  # [cout][tap*256+cin]
         e.append((f"conv{i}.b", DIM))
         e.append((f"cn{i}.g", DIM)); e.append((f"cn{i}.b", DIM))
+    for i in (2, 3, 4):
+        e.append((f"conv{i}.wf", 4 * DIM * DIM))  # fused conv tail: 4 taps x fragment-major 256x256 block
     e.append(("lstm.wih", LSTM_GATES * DIM))     # [perm row][256]  (plain GEMM operand)
     e.append(("lstm.whh", LSTM_GATES * DIM))     # 16x16x4-MFMA fragment-major [8 w][16 kc][8 ns][64 lane][4]
     e.append(("lstm.b", LSTM_GATES))             # b_ih + b_hh, permuted
@@ -295,6 +297,8 @@ def pack_blob(cpc_sd: Dict[str, np.ndarray], vap_sd: Dict[str, np.ndarray], mode
     for i in (1, 2, 3, 4):
         w = A(cpc_sd[f"gEncoder.conv{i}.weight"])       # [cout, cin, k]
         put(f"conv{i}.w", w.transpose(0, 2, 1))          # [cout][k][cin]
+        if i >= 2:
+            put(f"conv{i}.wf", np.concatenate([frag_pack(np.ascontiguousarray(w[:, :, t]), 0, 0) for t in range(4)]))
         put(f"conv{i}.b", A(cpc_sd[f"gEncoder.conv{i}.bias"]))
         put(f"cn{i}.g", A(cpc_sd[f"gEncoder.batchNorm{i}.weight"]))
         put(f"cn{i}.b", A(cpc_sd[f"gEncoder.batchNorm{i}.bias"]))
