@@ -197,3 +197,30 @@ def test_error_paths():
     with pytest.raises(engine.VapxError):
         eng.reset_stream(2)
     eng.close()
+
+
+def test_long_run_does_not_drift():
+    """300 frames (15 s): the persistent LSTM state and the ring / QKV cache wrap six times; the HIP path
+    must stay within tolerance of the oracle all the way (no error accumulation)."""
+    from oracle.vap_oracle import ServerFramer, VapOracle
+    from vap_realtime_amd import engine, synth, weights as W
+    cpc, vap = W.synthetic_weights(77, 20, "vap")
+    o = VapOracle(cpc, vap, 20, 2.5)
+    S, F_ = 2, 300
+    audio = synth.dialogue_batch([90, 91], 800 * F_)
+    st, fr = o.new_state(S), ServerFramer(S, 800)
+    eng = engine.Engine(W.pack_blob(cpc, vap), 20, 2.5, max_streams=S)
+    worst = 0.0
+    for f in range(F_):
+        new = audio[:, :, f * 800:(f + 1) * 800]
+        want = o.step(fr.frame(new), st)
+        got = engine.split_outputs(eng.step(new))
+        for k in ("p_now", "p_future", "vad", "logits"):
+            worst = max(worst, float(np.abs(got[k] - want[k]).max()))
+    print("long run worst |diff| =", worst)
+    assert worst <= TOL
+    # the exported LSTM state still matches the oracle's
+    stt = eng.get_state(0)
+    np.testing.assert_allclose(stt["lstm"][:, 0], st.h[0].numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(stt["lstm"][:, 1], st.c[0].numpy(), rtol=0, atol=1e-4)
+    eng.close()
