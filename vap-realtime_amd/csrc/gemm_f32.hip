@@ -242,8 +242,8 @@ hipError_t launch_gemm_f32(const GemmArgs& g, int epi, int tile_rows, hipStream_
     // measured on MI355X (tools/gemm_sweep.py, profiles/r01_gemm_sweep.txt): 64-row tiles win for
     // N = 256 (more workgroups -> less tile quantisation, 3 waves/SIMD), 128-row tiles for the
     // plain-store wide GEMMs, 32-row tiles when M is too small to fill 256 CUs otherwise.
-    if (g.N >= 512 && epi == EPI_STORE) tile_rows = 128;
-    else if (g.M < 12000) tile_rows = 32;
+    if (g.M < 12000) tile_rows = 32;
+    else if (g.N >= 512 && epi == EPI_STORE) tile_rows = 128;
     else if (g.K >= 2048 && g.M >= 200000) tile_rows = 128;
     else tile_rows = 64;
   }
