@@ -246,11 +246,20 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
   float* Vs = lds + h * 64 * KV_LD2;
   const float* vp = a.v + (long)kvbc * T * a.ldkv + h * 64;
   const float* kp = a.k + (long)kvbc * T * a.ldkv + h * 64;
-  for (int i = lane; i < 64 * 16; i += 64) {
-    int j = i >> 4, q4 = (i & 15) * 4;
-    f32x4 vv = {0.f, 0.f, 0.f, 0.f};
-    if (j < n) vv = *(const f32x4*)(vp + (long)j * a.ldkv + q4);
-    *(f32x4*)&Vs[j * KV_LD2 + q4] = vv;
+  {  // this head's V tile -> LDS: all 16 loads in flight first (rows >= n clamp to a valid row, then zeroed)
+    f32x4 vv[16];
+    const int q4 = (lane & 15) * 4, jb = lane >> 4;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      int j = u * 4 + jb;
+      int jc = j < n ? j : n - 1;
+      vv[u] = *(const f32x4*)(vp + (long)jc * a.ldkv + q4);
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      int j = u * 4 + jb;
+      *(f32x4*)&Vs[j * KV_LD2 + q4] = j < n ? vv[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   }
   const bool two = n > 32;                  // second query/key tile holds valid rows
   // K fragments (A operand of S^T = K.Q^T): key row j, k-slots kc*8 + 4*hi ..+3; rows >= n are
