@@ -63,14 +63,19 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
     const float* pa = A + l31 * LDH + kh;
     const f32x4* wf = wbase(wfrag);
     const f32x4* wnext = next_wfrag ? wbase(next_wfrag) : wf;   // no successor: harmless re-read
+    f32x4 a[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[mt] = *(const f32x4*)(pa + mt * 32 * LDH);
 #pragma unroll 1
     for (int blk = 0; blk < 4; ++blk) {
       const f32x4* nx = blk < 3 ? wf + (blk + 1) * 16 * 64 : wnext;
 #pragma unroll
       for (int k8 = 0; k8 < 8; ++k8) {
-        f32x4 a[MT];
+        // A fragment of the NEXT k-step is requested before this step's MFMAs (LDS latency hidden)
+        f32x4 an[MT];
+        const int kn = (blk * 8 + k8 + 1) & 31;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = *(const f32x4*)(pa + mt * 32 * LDH + (blk * 8 + k8) * 8);
+        for (int mt = 0; mt < MT; ++mt) an[mt] = *(const f32x4*)(pa + mt * 32 * LDH + kn * 8);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -80,6 +85,11 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
           }
         ring[k8 * 2] = nx[(k8 * 2) * 64 + lane];
         ring[k8 * 2 + 1] = nx[(k8 * 2 + 1) * 64 + lane];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = an[mt];
+        // pin the refill right behind the MFMAs that consumed the slot: left alone, hipcc sinks all 16
+        // loads to the end of the block and waits for them at the top of the next one (zero prefetch)
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
@@ -387,6 +397,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
         }
         ring[k8 * 2] = nx[(k8 * 2) * 64 + lane];
         ring[k8 * 2 + 1] = nx[(k8 * 2 + 1) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);   // keep the refill behind its MFMAs (see ffn_block_kernel)
       }
     }
   };
@@ -527,6 +538,7 @@ __global__ __launch_bounds__(256, 1) void conv_tail_kernel(const ConvTailArgs g)
         }
         ring[k8 * 2] = nx[(k8 * 2) * 64 + lane];
         ring[k8 * 2 + 1] = nx[(k8 * 2 + 1) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);   // keep the refill behind its MFMAs (see ffn_block_kernel)
       }
     }
   };

@@ -141,6 +141,7 @@ __global__ __launch_bounds__(512) void lstm_kernel(LstmArgs a) {
         const f32x4* nx = kc + 2 < 16 ? d + ((kc + 2) * 2) * 64 : dn + ((kc + 2 - 16) * 2) * 64;
         dring[h2 * 2] = nx[lane];
         dring[h2 * 2 + 1] = nx[64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(512) void lstm_kernel(LstmArgs a) {
         const f32x4* nx = wf + (long)(((kc + 2) & 15) * 8) * 64;
 #pragma unroll
         for (int ns = 0; ns < 8; ++ns) ring[h2 * 8 + ns] = nx[ns * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);   // keep the refill behind its MFMAs (hipcc would sink it)
       }
     }
     if (t > 0 && a.down_wf) down_step(t - 1);
