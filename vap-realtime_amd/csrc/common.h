@@ -37,6 +37,14 @@ static inline RowMap contiguous_rows(long ld) {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// branch-free gate non-linearities for the LSTM recurrence (40 evaluations per lane per step): v_exp +
+// v_rcp (1 ulp) instead of libm's branchy tanhf and IEEE division.  Absolute error ~1e-7.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) {
+  float t = __expf(-2.0f * fabsf(x));
+  float r = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
+  return copysignf(r, x);
+}
 
 // 64-lane butterfly all-reduce (sum / max)
 __device__ __forceinline__ float wave_sum(float v) {

@@ -186,13 +186,13 @@ __global__ __launch_bounds__(512) void lstm_kernel(LstmArgs a) {
       const bool live = m < a.M;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        float ig = sigmoidf_(acc[0 + q][reg] + gxr[reg][0 + q]);
-        float fg = sigmoidf_(acc[2 + q][reg] + gxr[reg][2 + q]);
-        float gg = tanhf(acc[4 + q][reg] + gxr[reg][4 + q]);
-        float og = sigmoidf_(acc[6 + q][reg] + gxr[reg][6 + q]);
+        float ig = fast_sigmoid(acc[0 + q][reg] + gxr[reg][0 + q]);
+        float fg = fast_sigmoid(acc[2 + q][reg] + gxr[reg][2 + q]);
+        float gg = fast_tanh(acc[4 + q][reg] + gxr[reg][4 + q]);
+        float og = fast_sigmoid(acc[6 + q][reg] + gxr[reg][6 + q]);
         float cn = fg * creg[q][reg] + ig * gg;
         creg[q][reg] = cn;
-        float hn = og * tanhf(cn);
+        float hn = og * fast_tanh(cn);
         const int j = w * 32 + q * 16 + l15;
         hbuf[row * H_LD + j] = hn;
         if (live) a.out[((long)m * a.ncpc + t) * 256 + j] = hn;
