@@ -73,6 +73,25 @@ def test_intermediates_match_reference():
     eng.close()
 
 
+def test_fused_conv_tail_equals_three_gemms():
+    """conv2-4 fused in LDS (default up to 512 streams) vs the three implicit-GEMM launches; h2/h3 are
+    only peekable on the unfused path."""
+    from vap_realtime_amd import engine
+    c = Case("vap20")
+    a, b = make_engine(c), make_engine(c, unfused_conv=True)
+    for f in range(3):
+        oa = engine.split_outputs(a.step(c.new_samples(f)))
+        ob = engine.split_outputs(b.step(c.new_samples(f)))
+        np.testing.assert_allclose(oa["e"], ob["e"], rtol=0, atol=5e-6)
+        np.testing.assert_allclose(a.peek("z", (2, 5, 256)), b.peek("z", (2, 5, 256)), rtol=0, atol=5e-6)
+    assert b.peek("h3", (2, 16, 256)).shape == (2, 16, 256)
+    with pytest.raises(engine.VapxError, match="fused conv tail"):
+        a.peek("h2", (2, 30, 256))
+    with pytest.raises(engine.VapxError, match="FULL_LAST_LAYER"):
+        a.peek("stereo2", (2, 50, 256))
+    a.close(); b.close()
+
+
 def test_pruned_last_layer_equals_full_last_layer():
     """Default path computes only the newest row of the last layer; it must agree with the
     full-layer path (VAPX_FLAG_FULL_LAST_LAYER) far below the parity tolerance."""

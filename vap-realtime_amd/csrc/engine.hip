@@ -797,8 +797,12 @@ int64_t vapx_peek(vapx_handle h, const char* name, float* dst, size_t max_floats
   size_t n = 0;
   if (!strcmp(name, "h0")) { src = h->sc.h0; n = B * 2 * (P[0] + 4) * 256; }
   else if (!strcmp(name, "h1")) { src = h->sc.h1; n = B * 2 * (P[1] + 2) * 256; }
-  else if (!strcmp(name, "h2")) { src = h->sc.h2; n = B * 2 * (P[2] + 2) * 256; }
-  else if (!strcmp(name, "h3")) { src = h->sc.h3; n = B * 2 * (P[3] + 2) * 256; }
+  else if (!strcmp(name, "h2") || !strcmp(name, "h3")) {
+    if (conv_tail_supported(P[1], h->ncpc) && !(h->cfg.flags & VAPX_FLAG_UNFUSED_CONV) && B <= 512)
+      return fail(h, VAPX_E_INVAL, "\"%s\" stays in LDS in the fused conv tail; create the engine with VAPX_FLAG_UNFUSED_CONV to peek it", name);
+    if (name[1] == '2') { src = h->sc.h2; n = B * 2 * (P[2] + 2) * 256; }
+    else { src = h->sc.h3; n = B * 2 * (P[3] + 2) * 256; }
+  }
   else if (!strcmp(name, "z")) { src = h->sc.z; n = B * 2 * h->ncpc * 256; }
   else if (!strcmp(name, "lstm_out")) { src = h->sc.lstm_out; n = B * 2 * h->ncpc * 256; }
   else if (!strcmp(name, "e")) { src = h->sc.e; n = B * 2 * 256; }
