@@ -243,3 +243,32 @@ def test_long_run_does_not_drift():
     np.testing.assert_allclose(stt["lstm"][:, 0], st.h[0].numpy(), rtol=0, atol=1e-5)
     np.testing.assert_allclose(stt["lstm"][:, 1], st.c[0].numpy(), rtol=0, atol=1e-4)
     eng.close()
+
+
+def test_streams_joining_at_different_times():
+    """Streams that start at different ticks sit in one batch with different window fills n (one still
+    warming up, one already sliding) and a third one is reset mid-run: each must equal its own
+    independent oracle run."""
+    from oracle.vap_oracle import ServerFramer, VapOracle
+    from vap_realtime_amd import engine, synth, weights as W
+    cpc, vap = W.synthetic_weights(5, 20, "vap")
+    F_ = 70
+    audio = synth.dialogue_batch([200, 201, 202], 800 * F_)
+    start = [0, 37, 12]                   # first tick of each stream
+    eng = engine.Engine(W.pack_blob(cpc, vap), 20, 2.5, max_streams=4)
+    oracles = [VapOracle(cpc, vap, 20, 2.5) for _ in range(3)]
+    states = [o.new_state(1) for o in oracles]
+    framers = [ServerFramer(1, 800) for _ in range(3)]
+    for f in range(F_):
+        if f == 55:                       # stream 2 hangs up and a new dialogue takes its slot
+            eng.reset_stream(3)
+            states[2], framers[2] = oracles[2].new_state(1), ServerFramer(1, 800)
+        live = [s for s in range(3) if f >= start[s]]
+        ids = [[0, 2, 3][s] for s in live]
+        new = np.stack([audio[s, :, (f - start[s]) * 800:(f - start[s] + 1) * 800] for s in live])
+        got = engine.split_outputs(eng.step(new, ids))
+        for k, s in enumerate(live):
+            want = oracles[s].step(framers[s].frame(new[k:k + 1]), states[s])
+            for key in ("p_now", "p_future", "vad", "logits"):
+                np.testing.assert_allclose(got[key][k], want[key][0], rtol=0, atol=TOL, err_msg=f"frame {f} stream {s} {key}")
+    eng.close()
