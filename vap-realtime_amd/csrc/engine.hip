@@ -274,12 +274,12 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
       ab.q = sc.qkv; ab.k = sc.qkv + 256; ab.v = sc.qkv + 512; ab.ldq = 768; ab.ldkv = 768; ab.swap_kv = 0;
       ab.bn = sc.bn; ab.T = T; ab.wprojf = Lw.wprojf; ab.resid = xin; ab.xmid = sc.xmid; ab.xn = sc.xn;
       if (l == 0) { ab.ln_g = Lw.ln_ffn_g; ab.ln_b = Lw.ln_ffn_b; }
-      else { ab.ln_g = Lw.ln_src_g; ab.ln_b = Lw.ln_src_b; ab.wqxf = Lw.wqxf; ab.qx = sc.qx; }
+      else { ab.ln_g = Lw.ln_src_g; ab.ln_b = Lw.ln_src_b; ab.wqxf = Lw.wqxf; ab.qx = sc.qx; ab.xn = nullptr; }
       { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attn_block(ab, B, st)); }
       if (l > 0) {
         ab.q = sc.qx; ab.k = sc.kvx; ab.v = sc.kvx + 256; ab.ldq = 256; ab.ldkv = 512; ab.swap_kv = 1;
         ab.wprojf = Lw.wprojxf; ab.resid = sc.xmid; ab.ln_g = Lw.ln_ffn_g; ab.ln_b = Lw.ln_ffn_b;
-        ab.wqxf = nullptr; ab.qx = nullptr;
+        ab.wqxf = nullptr; ab.qx = nullptr; ab.xn = sc.xn;
         { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attn_block(ab, B, st)); }
       }
     } else {

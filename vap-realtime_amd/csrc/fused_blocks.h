@@ -29,7 +29,7 @@ struct AttnBlockArgs {
   const float* ln_g;
   const float* ln_b;
   float* xmid;          // resid + att.Wproj^T
-  float* xn;            // LayerNorm(xmid)
+  float* xn;            // LayerNorm(xmid), or null when only the fused cross-q projection consumes it
   const float* wqxf;    // optional: cross-attention query projection (fragment-major), null to skip
   float* qx;            // [B*2*T][256]
   int T, ldq, ldkv, swap_kv;

@@ -462,9 +462,11 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
       float y1 = (acc[mt * 2 + 1][r] - mean[t]) * rstd * g1 + b1;
       if (i < T) {
         float* xm = a.xmid + ((long)bc * T + i) * 256 + ccol;
-        float* xo = a.xn + ((long)bc * T + i) * 256 + ccol;
         xm[0] = acc[mt * 2][r]; xm[32] = acc[mt * 2 + 1][r];
-        xo[0] = y0; xo[32] = y1;
+        if (a.xn) {   // LN output is only needed in global when another kernel consumes it (ffn_block)
+          float* xo = a.xn + ((long)bc * T + i) * 256 + ccol;
+          xo[0] = y0; xo[32] = y1;
+        }
       }
       if (a.wqxf) { sAtt[i * 260 + ccol] = y0; sAtt[i * 260 + ccol + 32] = y1; }
     }
