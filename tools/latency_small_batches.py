@@ -1,5 +1,8 @@
-import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+#!/usr/bin/env python3
+"""Host-inclusive vapx_step latency for small batches (1 / 8 / 64 streams) on the GPU."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vap_realtime_amd import engine, synth, weights as W
 cpc, vap = W.synthetic_weights(0, 20)
 for S in (1, 8, 64):
