@@ -31,7 +31,7 @@ struct Layer {
 }  // namespace
 
 struct Scratch {
-  int *bn = nullptr, *bhead = nullptr;
+  int *bn = nullptr, *bhead = nullptr, *rot = nullptr;
   float *h0 = nullptr, *h1 = nullptr, *h2 = nullptr, *h3 = nullptr, *z = nullptr, *gx = nullptr, *lstm_out = nullptr, *e = nullptr;
   float* xl[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // layer inputs/outputs: x0, o, stereo0..2
   float *xn = nullptr, *xmid = nullptr, *att = nullptr, *qkv = nullptr, *qx = nullptr, *kvx = nullptr, *ffn = nullptr;
@@ -41,7 +41,7 @@ struct Scratch {
   Scratch slice(size_t b0, const int* P, int ncpc, int T) const {
     Scratch s = *this;
     const size_t bc = b0 * 2, rows = bc * T;
-    s.bn += b0; s.bhead += b0;
+    s.bn += b0; s.bhead += b0; s.rot += b0;
     s.h0 += bc * (P[0] + 4) * 256; s.h1 += bc * (P[1] + 2) * 256; s.h2 += bc * (P[2] + 2) * 256; s.h3 += bc * (P[3] + 2) * 256;
     s.z += bc * ncpc * 256; s.gx += bc * ncpc * 1024; s.lstm_out += bc * ncpc * 256; s.e += bc * 256;
     for (int i = 0; i < 5; ++i) s.xl[i] += rows * 256;
@@ -243,12 +243,14 @@ int run_encoder(vapx_engine* h, const Scratch& sc, const StateView& sv, int B, c
   return VAPX_OK;
 }
 
+struct RingView { const float* ring; const float* ring_qkv; const int* ids; };   // layer 0 reads the rings directly
+
 // ---- 1 self + 3 self/cross layers on x0 = xl[l_begin] (LN_self already in xn) ---------------------
 // Per layer: [QKV (+cross KV) projections] -> self-attention -> proj+residual+LN -> (cross: q GEMM,
 // cross-attention, proj+residual+LN) -> fused FFN block, which also emits the NEXT layer's
 // projections so that only the first executed layer needs stand-alone projection GEMMs.
 int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_begin = 0, int l_end = 4,
-               bool prune_last = false, bool qkv0_ready = false) {
+               bool prune_last = false, bool qkv0_ready = false, const RingView* rv = nullptr) {
   const int T = h->T;
   const int M = B * 2 * T;
   const RowMap r256 = contiguous_rows(256), r768 = contiguous_rows(768), r512 = contiguous_rows(512);
@@ -273,13 +275,17 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
       memset(&ab, 0, sizeof ab);
       ab.q = sc.qkv; ab.k = sc.qkv + 256; ab.v = sc.qkv + 512; ab.ldq = 768; ab.ldkv = 768; ab.swap_kv = 0;
       ab.bn = sc.bn; ab.T = T; ab.wprojf = Lw.wprojf; ab.resid = xin; ab.xmid = sc.xmid; ab.xn = sc.xn;
+      if (l == 0 && rv && rv->ring) {   // Q|K|V and the residual straight from the per-stream rings
+        ab.q = rv->ring_qkv; ab.k = rv->ring_qkv + 256; ab.v = rv->ring_qkv + 512; ab.resid = rv->ring;
+        ab.ring_rot = sc.rot; ab.ids = rv->ids;
+      }
       if (l == 0) { ab.ln_g = Lw.ln_ffn_g; ab.ln_b = Lw.ln_ffn_b; }
       else { ab.ln_g = Lw.ln_src_g; ab.ln_b = Lw.ln_src_b; ab.wqxf = Lw.wqxf; ab.qx = sc.qx; ab.xn = nullptr; }
       { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attn_block(ab, B, st)); }
       if (l > 0) {
         ab.q = sc.qx; ab.k = sc.kvx; ab.v = sc.kvx + 256; ab.ldq = 256; ab.ldkv = 512; ab.swap_kv = 1;
         ab.wprojf = Lw.wprojxf; ab.resid = sc.xmid; ab.ln_g = Lw.ln_ffn_g; ab.ln_b = Lw.ln_ffn_b;
-        ab.wqxf = nullptr; ab.qx = nullptr; ab.xn = sc.xn;
+        ab.wqxf = nullptr; ab.qx = nullptr; ab.xn = sc.xn; ab.ring_rot = nullptr; ab.ids = nullptr;
         { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attn_block(ab, B, st)); }
       }
     } else {
@@ -438,10 +444,14 @@ int step_group(vapx_engine* h, const Scratch& sc, int nb, int b0, const int* ids
   ga.e = sc.e; ga.xin = nullptr; ga.ids = ids; ga.bn = sc.bn; ga.bhead = sc.bhead;
   ga.x0 = sc.xl[0]; ga.xn = sc.xn; ga.gamma = h->layer[0].ln_self_g; ga.beta = h->layer[0].ln_self_b;
   ga.B = nb; ga.T = h->T; ga.rows_in = 0;
-  { ProfScope ps(h, CLS_GATHER, st); HIPCHK(h, launch_gather_ln(ga, st)); }
+  const bool ring_direct = h->T <= 64 && !(h->cfg.flags & VAPX_FLAG_MATERIALIZE_X0);
+  ga.rot = sc.rot;
+  if (ring_direct) { ProfScope ps(h, CLS_GATHER, st); HIPCHK(h, launch_ring_append(ga, st)); }
+  else { ProfScope ps(h, CLS_GATHER, st); HIPCHK(h, launch_gather_ln(ga, st)); }
   // the nod variant emits p_bc for every row of the window, which needs the whole last layer
   const bool prune = !(h->cfg.flags & VAPX_FLAG_FULL_LAST_LAYER) && h->cfg.mode != VAPX_MODE_NOD;
-  rc = run_layers(h, sc, nb, st, 0, 4, prune, /*qkv0_ready=*/true);
+  RingView rv{ring_direct ? sv.ring : nullptr, sv.ring_qkv, ids};
+  rc = run_layers(h, sc, nb, st, 0, 4, prune, /*qkv0_ready=*/true, ring_direct ? &rv : nullptr);
   if (rc) return rc;
   HeadArgs ha;
   ha.x = prune ? sc.last[5] : sc.xl[4]; ha.x_last_only = prune ? 1 : 0; ha.o = sc.xl[1]; ha.e = sc.e; ha.bn = sc.bn; ha.ids = ids; ha.frames_seen = sv.frames_seen;
@@ -489,7 +499,7 @@ void vapx_destroy(vapx_handle h) {
                  h->sc.last[3], h->sc.last[4], h->sc.last[5], h->sc.en, h->sc.qkv_new, h->sc.lffn};
   for (float* p : fp)
     if (p) (void)hipFree(p);
-  int* ip[] = {h->frames_seen, h->ids_dev, h->sc.bn, h->sc.bhead};
+  int* ip[] = {h->frames_seen, h->ids_dev, h->sc.bn, h->sc.bhead, h->sc.rot};
   for (int* p : ip)
     if (p) (void)hipFree(p);
   if (h->out_pinned) (void)hipHostFree(h->out_pinned);
@@ -569,6 +579,7 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
   CR(dalloc(&h->ids_dev, B));
   CR(dalloc(&h->sc.bn, B));
   CR(dalloc(&h->sc.bhead, B));
+  CR(dalloc(&h->sc.rot, B));
   CR(dalloc(&h->sc.h0, B * 2 * (P[0] + 4) * 256));  // guard rows stay zero forever
   CR(dalloc(&h->sc.h1, B * 2 * (P[1] + 2) * 256));
   CR(dalloc(&h->sc.h2, B * 2 * (P[2] + 2) * 256));
@@ -806,7 +817,11 @@ int64_t vapx_peek(vapx_handle h, const char* name, float* dst, size_t max_floats
   else if (!strcmp(name, "z")) { src = h->sc.z; n = B * 2 * h->ncpc * 256; }
   else if (!strcmp(name, "lstm_out")) { src = h->sc.lstm_out; n = B * 2 * h->ncpc * 256; }
   else if (!strcmp(name, "e")) { src = h->sc.e; n = B * 2 * 256; }
-  else if (!strcmp(name, "x0")) { src = h->sc.xl[0]; n = B * 2 * T * 256; }
+  else if (!strcmp(name, "x0")) {
+    if (h->T <= 64 && !(h->cfg.flags & VAPX_FLAG_MATERIALIZE_X0))
+      return fail(h, VAPX_E_INVAL, "\"x0\" is read straight from the ring; create the engine with VAPX_FLAG_MATERIALIZE_X0 to peek it");
+    src = h->sc.xl[0]; n = B * 2 * T * 256;
+  }
   else if (!strcmp(name, "o")) { src = h->sc.xl[1]; n = B * 2 * T * 256; }
   else if (!strcmp(name, "stereo0")) { src = h->sc.xl[2]; n = B * 2 * T * 256; }
   else if (!strcmp(name, "stereo1")) { src = h->sc.xl[3]; n = B * 2 * T * 256; }

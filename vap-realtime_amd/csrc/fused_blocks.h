@@ -32,6 +32,9 @@ struct AttnBlockArgs {
   float* xn;            // LayerNorm(xmid), or null when only the fused cross-q projection consumes it
   const float* wqxf;    // optional: cross-attention query projection (fragment-major), null to skip
   float* qx;            // [B*2*T][256]
+  const int* ring_rot;  // [B] or null.  Non-null: q/k/v/resid are per-stream RINGS (slab = slot*2+channel, logical
+                        // row i in ring slot (i + ring_rot[b]) % T) instead of chronological batch buffers
+  const int* ids;       // [B] stream slots (null: identity); only used with ring_rot
   int T, ldq, ldkv, swap_kv;
 };
 

@@ -254,8 +254,15 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
   const int n = a.bn[b];
   const int kvbc = a.swap_kv ? (bc ^ 1) : bc;
   float* Vs = lds + h * 64 * KV_LD2;
-  const float* vp = a.v + (long)kvbc * T * a.ldkv + h * 64;
-  const float* kp = a.k + (long)kvbc * T * a.ldkv + h * 64;
+  // Layer 0 reads Q|K|V and the residual straight from the per-stream rings (no chronological copy):
+  // slab = stream slot * 2 + channel, logical row i lives in ring slot (i + rot) % T.
+  const bool ringed = a.ring_rot != nullptr;
+  const int rot = ringed ? a.ring_rot[b] : 0;
+  const long slab_q = ringed ? ((long)(a.ids ? a.ids[b] : b) * 2 + (bc & 1)) : (long)bc;
+  const long slab_kv = ringed ? slab_q : (long)kvbc;
+  auto prow = [&](int i) { int r = i + rot; return r >= T ? r - T : r; };
+  const float* vp = a.v + slab_kv * T * a.ldkv + h * 64;
+  const float* kp = a.k + slab_kv * T * a.ldkv + h * 64;
   {  // this head's V tile -> LDS: all 16 loads in flight first (rows >= n clamp to a valid row, then zeroed)
     f32x4 vv[16];
     const int q4 = (lane & 15) * 4, jb = lane >> 4;
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
     for (int u = 0; u < 16; ++u) {
       int j = u * 4 + jb;
       int jc = j < n ? j : n - 1;
-      vv[u] = *(const f32x4*)(vp + (long)jc * a.ldkv + q4);
+      vv[u] = *(const f32x4*)(vp + (long)prow(jc) * a.ldkv + q4);
     }
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
@@ -277,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
   f32x4 kf0[8];
   {
     int j0 = l31 < n ? l31 : n - 1;
-    const float* k0 = kp + (long)j0 * a.ldkv + kh;
+    const float* k0 = kp + (long)prow(j0) * a.ldkv + kh;
 #pragma unroll
     for (int kc = 0; kc < 8; ++kc) kf0[kc] = *(const f32x4*)(k0 + kc * 8);
   }
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
   auto qtile = [&](int it, bool use_j1, f32x16& o0, f32x16& o1) {
     const int i = it * 32 + l31;
     const int iq = i < n ? i : n - 1;
-    const float* qp = a.q + ((long)bc * T + iq) * a.ldq + h * 64 + kh;
+    const float* qp = a.q + (slab_q * T + prow(iq)) * a.ldq + h * 64 + kh;
     f32x4 qf[8];
 #pragma unroll
     for (int kc = 0; kc < 8; ++kc) qf[kc] = *(const f32x4*)(qp + kc * 8) * 0.0625f;
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
       for (int s = 0; s < 4; ++s) s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf0[kc][s], qf[kc][s], s0, 0, 0, 0);
     if (use_j1) {   // second key tile: fragments fetched here (L2-hot) to keep tile 0 light on registers
       int j1 = 32 + l31 < n ? 32 + l31 : n - 1;
-      const float* k1 = kp + (long)j1 * a.ldkv + kh;
+      const float* k1 = kp + (long)prow(j1) * a.ldkv + kh;
 #pragma unroll
       for (int kc = 0; kc < 8; ++kc) {
         f32x4 kf1 = *(const f32x4*)(k1 + kc * 8);
@@ -417,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
     for (int r = 0; r < 16; ++r) {
       int i = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
       i = i < T ? i : T - 1;
-      const float* rp = a.resid + ((long)bc * T + i) * 256 + ccol;
+      const float* rp = a.resid + (slab_q * T + prow(i)) * 256 + ccol;
       acc[mt * 2][r] += rp[0];
       acc[mt * 2 + 1][r] += rp[32];
       if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);

@@ -40,6 +40,7 @@ struct GatherArgs {
   float* ring_qkv;      // [S*2][T][768] cached layer-0 Q|K|V per ring row, or null
   const float* qkv_new; // [B*2][768] this frame's layer-0 Q|K|V (when ring_qkv)
   float* qkv;           // [B*2][T][768] chronological gather target (when ring_qkv)
+  int* rot;             // [B] out (ring_append_kernel): ring slot of the oldest row
   const float* e;       // [B*2][256] this frame's embeddings
   const float* xin;     // [B*2][rows_in][256] explicit context (stage API)
   const int* ids;
@@ -94,6 +95,7 @@ struct HeadArgs {
 
 hipError_t launch_conv0(const Conv0Args& a, int B, hipStream_t st);
 hipError_t launch_lstm(const LstmArgs& a, hipStream_t st);
+hipError_t launch_ring_append(const GatherArgs& a, hipStream_t st);
 hipError_t launch_gather_ln(const GatherArgs& a, hipStream_t st);
 hipError_t launch_attention(const AttnArgs& a, int B, hipStream_t st);
 hipError_t launch_gather_last_ln(const LastRowArgs& a, hipStream_t st);

@@ -317,6 +317,30 @@ __global__ __launch_bounds__(512) void lstm_kernel(LstmArgs a) {
 // 3. context-ring append + chronological gather + LayerNorm(ln_self of layer 0)
 //    reference: vap_main.py:274-283 (append, keep last T, cat).  One wave per row.
 // ------------------------------------------------------------------------------------------------
+// ring-direct mode: append this frame's embedding and layer-0 Q|K|V to the rings and publish the
+// rotation that maps logical (chronological) rows to ring slots; nothing else moves.  One wave per
+// (stream, channel).
+__global__ __launch_bounds__(256) void ring_append_kernel(GatherArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int bc = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bc >= a.B * 2) return;
+  const int b = bc >> 1, c = bc & 1;
+  const int sid = a.ids ? a.ids[b] : b;
+  const int head = a.bhead[b], n = a.bn[b];
+  float* rb = a.ring + ((long)sid * 2 + c) * a.T * 256;
+  float* rq = a.ring_qkv + ((long)sid * 2 + c) * a.T * 768;
+  *(f32x4*)(rb + (long)head * 256 + lane * 4) = *(const f32x4*)(a.e + (long)bc * 256 + lane * 4);
+  const float* qn = a.qkv_new + (long)bc * 768 + lane * 4;
+  float* qs = rq + (long)head * 768 + lane * 4;
+  *(f32x4*)(qs) = *(const f32x4*)(qn);
+  *(f32x4*)(qs + 256) = *(const f32x4*)(qn + 256);
+  *(f32x4*)(qs + 512) = *(const f32x4*)(qn + 512);
+  if (c == 0 && lane == 0) {
+    int rot = head + 1 - n;           // slot of the oldest row
+    a.rot[b] = rot < 0 ? rot + a.T : rot;
+  }
+}
+
 __global__ __launch_bounds__(256) void gather_ln_kernel(GatherArgs a) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -781,6 +805,10 @@ hipError_t launch_conv0(const Conv0Args& a, int B, hipStream_t st) {
 }
 hipError_t launch_lstm(const LstmArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(lstm_kernel, dim3((a.M + 15) / 16), dim3(512), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_ring_append(const GatherArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(ring_append_kernel, dim3((a.B * 2 + 3) / 4), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_gather_ln(const GatherArgs& a, hipStream_t st) {
