@@ -272,3 +272,26 @@ def test_streams_joining_at_different_times():
             for key in ("p_now", "p_future", "vad", "logits"):
                 np.testing.assert_allclose(got[key][k], want[key][0], rtol=0, atol=TOL, err_msg=f"frame {f} stream {s} {key}")
     eng.close()
+
+
+@pytest.mark.parametrize("S", [67, 300])
+def test_odd_batch_sizes_hit_every_tile_tail(S):
+    """Batches that are not multiples of any tile size (32/64-row GEMM tiles, 16-row LSTM tiles, 8-stream
+    head groups, 4-row gather blocks), with a shuffled slot assignment: every stream must match the
+    batched oracle."""
+    from oracle.vap_oracle import ServerFramer, VapOracle
+    from vap_realtime_amd import engine, synth, weights as W
+    cpc, vap = W.synthetic_weights(11, 20, "vap")
+    o = VapOracle(cpc, vap, 20, 2.5)
+    F_ = 4
+    audio = synth.noise_batch(S, 800 * F_, seed=S) * np.linspace(0.2, 3.0, S, dtype=np.float32)[:, None, None]
+    st, fr = o.new_state(S), ServerFramer(S, 800)
+    eng = engine.Engine(W.pack_blob(cpc, vap), 20, 2.5, max_streams=S + 5)
+    ids = np.random.default_rng(S).permutation(S + 5)[:S].astype(np.int32)
+    for f in range(F_):
+        new = audio[:, :, f * 800:(f + 1) * 800]
+        want = o.step(fr.frame(new), st)
+        got = engine.split_outputs(eng.step(new, ids))
+        for k in ("p_now", "p_future", "vad", "logits", "e"):
+            np.testing.assert_allclose(got[k], want[k], rtol=0, atol=TOL, err_msg=f"S={S} frame {f} {k}")
+    eng.close()
