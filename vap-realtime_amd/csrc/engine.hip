@@ -274,7 +274,7 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
       AttnBlockArgs ab;
       memset(&ab, 0, sizeof ab);
       ab.q = sc.qkv; ab.k = sc.qkv + 256; ab.v = sc.qkv + 512; ab.ldq = 768; ab.ldkv = 768; ab.swap_kv = 0;
-      ab.bn = sc.bn; ab.T = T; ab.wprojf = Lw.wprojf; ab.resid = xin; ab.xmid = sc.xmid; ab.xn = sc.xn;
+      ab.bn = sc.bn; ab.T = T; ab.wprojf = Lw.wprojf; ab.resid = xin; ab.xmid = sc.xmid; ab.xn = nullptr;
       if (l == 0 && rv && rv->ring) {   // Q|K|V and the residual straight from the per-stream rings
         ab.q = rv->ring_qkv; ab.k = rv->ring_qkv + 256; ab.v = rv->ring_qkv + 512; ab.resid = rv->ring;
         ab.ring_rot = sc.rot; ab.ids = rv->ids;
@@ -285,7 +285,7 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
       if (l > 0) {
         ab.q = sc.qx; ab.k = sc.kvx; ab.v = sc.kvx + 256; ab.ldq = 256; ab.ldkv = 512; ab.swap_kv = 1;
         ab.wprojf = Lw.wprojxf; ab.resid = sc.xmid; ab.ln_g = Lw.ln_ffn_g; ab.ln_b = Lw.ln_ffn_b;
-        ab.wqxf = nullptr; ab.qx = nullptr; ab.xn = sc.xn; ab.ring_rot = nullptr; ab.ids = nullptr;
+        ab.wqxf = nullptr; ab.qx = nullptr; ab.xn = nullptr; ab.ring_rot = nullptr; ab.ids = nullptr;
         { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attn_block(ab, B, st)); }
       }
     } else {
@@ -311,7 +311,7 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
     // feed-forward (+ next layer's projections)
     FfnArgs fa;
     memset(&fa, 0, sizeof fa);
-    fa.xn = sc.xn; fa.xmid = sc.xmid; fa.w0f = Lw.w0f; fa.w3f = Lw.w3f; fa.xout = xout; fa.M = M;
+    fa.xmid = sc.xmid; fa.lnf_g = Lw.ln_ffn_g; fa.lnf_b = Lw.ln_ffn_b; fa.w0f = Lw.w0f; fa.w3f = Lw.w3f; fa.xout = xout; fa.M = M;
     fa.tile_rows = h->ffn_tile_rows ? h->ffn_tile_rows : 32;
     if (l + 1 < l_end) {
       const Layer& Ln = h->layer[l + 1];

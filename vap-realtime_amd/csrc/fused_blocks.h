@@ -3,8 +3,9 @@
 #include "common.h"
 
 struct FfnArgs {
-  const float* xn;     // [M][256] LN_ffn(xmid)
-  const float* xmid;   // [M][256] residual stream before the FFN
+  const float* xmid;   // [M][256] residual stream before the FFN (LayerNorm(ln_ffn) is applied on load)
+  const float* lnf_g;  // ln_ffnetwork weight / bias
+  const float* lnf_b;
   const float* w0f;    // W0 [768][256], fragment-major: 3 column chunks
   const float* w3f;    // W3 [256][768], fragment-major: 3 k chunks
   float* xout;         // [M][256] layer output
@@ -29,7 +30,8 @@ struct AttnBlockArgs {
   const float* ln_g;
   const float* ln_b;
   float* xmid;          // resid + att.Wproj^T
-  float* xn;            // LayerNorm(xmid), or null when only the fused cross-q projection consumes it
+  float* xn;            // LayerNorm(xmid) -> global, or null (the FFN block re-normalises xmid itself; only the
+                        // unfused cross-q GEMM of long windows needs this copy)
   const float* wqxf;    // optional: cross-attention query projection (fragment-major), null to skip
   float* qx;            // [B*2*T][256]
   const int* ring_rot;  // [B] or null.  Non-null: q/k/v/resid are per-stream RINGS (slab = slot*2+channel, logical

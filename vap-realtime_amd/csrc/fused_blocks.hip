@@ -41,11 +41,28 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
   const int l31 = lane & 31, hi = lane >> 5, kh = hi * 4;
   const int m0 = blockIdx.x * BM;
 
-  for (int i = tid; i < BM * 64; i += 256) {
-    int row = i >> 6, q = (i & 63) * 4;
-    int m = m0 + row;
-    m = m < g.M ? m : g.M - 1;
-    *(f32x4*)&sX[row * LDH + q] = *(const f32x4*)(g.xn + (long)m * 256 + q);
+  {  // A operand of FFN1 = LayerNorm(xmid; ln_ffn), normalised while the tile is staged: every wave
+     // loads whole rows (64 lanes x 16 B), so the row statistics are two wave reductions — the
+     // producer (attention block) no longer writes a normalised copy to HBM at all
+    const f32x4 lg = *(const f32x4*)(g.lnf_g + lane * 4), lb = *(const f32x4*)(g.lnf_b + lane * 4);
+    f32x4 xr[BM / 4];
+#pragma unroll
+    for (int k = 0; k < BM / 4; ++k) {
+      int m = m0 + (tid >> 6) + 4 * k;
+      m = m < g.M ? m : g.M - 1;
+      xr[k] = *(const f32x4*)(g.xmid + (long)m * 256 + lane * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < BM / 4; ++k) {
+      float sm = half_sum(xr[k][0] + xr[k][1] + xr[k][2] + xr[k][3]);
+      sm += __shfl_xor(sm, 32);
+      const float mean = sm * (1.0f / 256.0f);
+      f32x4 d = xr[k] - mean;
+      float sv = half_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]);
+      sv += __shfl_xor(sv, 32);
+      const float rstd = rsqrtf(sv * (1.0f / 256.0f) + 1e-5f);
+      *(f32x4*)&sX[((tid >> 6) + 4 * k) * LDH + lane * 4] = d * rstd * lg + lb;
+    }
   }
   __syncthreads();
 
@@ -417,18 +434,28 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   fetch(a.wprojf);
   mm(acc, a.wprojf, a.wqxf);
-  // residual
+  // residual: all 64 loads of a lane are issued back to back (the weight ring is dead here, so the
+  // registers are free) and then added — one memory latency instead of one per 8 rows
+  {
+    float rv[2][32];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int i = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      i = i < T ? i : T - 1;
-      const float* rp = a.resid + (slab_q * T + prow(i)) * 256 + ccol;
-      acc[mt * 2][r] += rp[0];
-      acc[mt * 2 + 1][r] += rp[32];
-      if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-    }
+      for (int r = 0; r < 16; ++r) {
+        int i = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        i = i < T ? i : T - 1;
+        const float* rp = a.resid + (slab_q * T + prow(i)) * 256 + ccol;
+        rv[0][mt * 16 + r] = rp[0];
+        rv[1][mt * 16 + r] = rp[32];
+      }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[mt * 2][r] += rv[0][mt * 16 + r];
+        acc[mt * 2 + 1][r] += rv[1][mt * 16 + r];
+      }
+  }
   // LayerNorm over the 256 columns of each row (two-pass), partials across the 4 waves via LDS
   float s[32], mean[32];
 #pragma unroll
