@@ -80,32 +80,36 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
     const float* pa = A + l31 * LDH + kh;
     const f32x4* wf = wbase(wfrag);
     const f32x4* wnext = next_wfrag ? wbase(next_wfrag) : wf;   // no successor: harmless re-read
-    f32x4 a[MT];
+    // A fragments ping-pong between two register sets (even / odd k-step) so that the LDS read of
+    // step k+1 is in flight during the MFMAs of step k (with one set hipcc issues the read and
+    // waits for it right away); sched_group_barrier fixes the order: 1 LDS read, 8 MFMAs, 2 loads.
+    f32x4 a0[MT], a1[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[mt] = *(const f32x4*)(pa + mt * 32 * LDH);
+    for (int mt = 0; mt < MT; ++mt) a0[mt] = *(const f32x4*)(pa + mt * 32 * LDH);
 #pragma unroll 1
     for (int blk = 0; blk < 4; ++blk) {
       const f32x4* nx = blk < 3 ? wf + (blk + 1) * 16 * 64 : wnext;
 #pragma unroll
       for (int k8 = 0; k8 < 8; ++k8) {
-        // A fragment of the NEXT k-step is requested before this step's MFMAs (LDS latency hidden)
-        f32x4 an[MT];
         const int kn = (blk * 8 + k8 + 1) & 31;
+        f32x4(&ac)[MT] = (k8 & 1) ? a1 : a0;
+        f32x4(&an)[MT] = (k8 & 1) ? a0 : a1;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) an[mt] = *(const f32x4*)(pa + mt * 32 * LDH + kn * 8);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
-            acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], ring[k8 * 2][s], acc[mt][0], 0, 0, 0);
-            acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], ring[k8 * 2 + 1][s], acc[mt][1], 0, 0, 0);
+            acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[mt][s], ring[k8 * 2][s], acc[mt][0], 0, 0, 0);
+            acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[mt][s], ring[k8 * 2 + 1][s], acc[mt][1], 0, 0, 0);
           }
         ring[k8 * 2] = nx[(k8 * 2) * 64 + lane];
         ring[k8 * 2 + 1] = nx[(k8 * 2 + 1) * 64 + lane];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = an[mt];
-        // pin the refill right behind the MFMAs that consumed the slot: left alone, hipcc sinks all 16
-        // loads to the end of the block and waits for them at the top of the next one (zero prefetch)
+        __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);       // DS read(s) of the next A fragment first
+        __builtin_amdgcn_sched_group_barrier(0x008, 8 * MT, 0);   // then this step's MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);        // then the two ring refills
+        // pin the step: left alone, hipcc sinks all 16 refills to the end of the block and waits for
+        // them at the top of the next one (zero prefetch)
         __builtin_amdgcn_sched_barrier(0);
       }
     }
