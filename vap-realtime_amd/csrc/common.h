@@ -36,6 +36,20 @@ static inline RowMap contiguous_rows(long ld) {
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// Branch-free GELU for the FFN hot loop (98 k evaluations per stream-frame): erf by Abramowitz-Stegun
+// 7.1.26 (|error| <= 1.5e-7, i.e. fp32-rounding level; multiplied by x it is a 1.5e-7 RELATIVE error
+// of gelu for small x) with v_rcp / v_exp instead of libm's two-branch erff (~4x fewer instructions,
+// no divergence).  gelu(x) = 0.5 x (1 + erf(x / sqrt 2)).
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = 1.0f - p * t * __expf(-z * z);     // erf(|x| / sqrt 2)
+  return 0.5f * x * (1.0f + copysignf(e, x));
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 // branch-free gate non-linearities for the LSTM recurrence (40 evaluations per lane per step): v_exp +
 // v_rcp (1 ulp) instead of libm's branchy tanhf and IEEE division.  Absolute error ~1e-7.

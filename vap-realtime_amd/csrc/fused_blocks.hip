@@ -160,8 +160,8 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        hacc[mt][0][r] = gelu_erf(hacc[mt][0][r]);
-        hacc[mt][1][r] = gelu_erf(hacc[mt][1][r]);
+        hacc[mt][0][r] = gelu_fast(hacc[mt][0][r]);
+        hacc[mt][1][r] = gelu_fast(hacc[mt][1][r]);
         if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     __syncthreads();          // every wave is done reading the previous chunk from sH
