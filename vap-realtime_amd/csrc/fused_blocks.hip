@@ -409,22 +409,33 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
     const float* pa = sAtt + l31 * 260 + kh;
     const f32x4* wf = wbase(wfrag);
     const f32x4* wnext = next_wfrag ? wbase(next_wfrag) : wf;
+    // A fragments ping-pong between two register sets so the LDS reads of step k+1 fly under the
+    // MFMAs of step k (see ffn_block_kernel)
+    f32x4 p0[2], p1[2];
+    p0[0] = *(const f32x4*)(pa);
+    p0[1] = *(const f32x4*)(pa + 32 * 260);
 #pragma unroll 1
     for (int blk = 0; blk < 4; ++blk) {
       const f32x4* nx = blk < 3 ? wf + (blk + 1) * 16 * 64 : wnext;
 #pragma unroll
       for (int k8 = 0; k8 < 8; ++k8) {
-        f32x4 a0 = *(const f32x4*)(pa + (blk * 8 + k8) * 8);
-        f32x4 a1 = *(const f32x4*)(pa + 32 * 260 + (blk * 8 + k8) * 8);
+        const int kn = (blk * 8 + k8 + 1) & 31;
+        f32x4(&ac)[2] = (k8 & 1) ? p1 : p0;
+        f32x4(&an)[2] = (k8 & 1) ? p0 : p1;
+        an[0] = *(const f32x4*)(pa + kn * 8);
+        an[1] = *(const f32x4*)(pa + 32 * 260 + kn * 8);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], ring[k8 * 2][s], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], ring[k8 * 2 + 1][s], acc[1], 0, 0, 0);
-          acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], ring[k8 * 2][s], acc[2], 0, 0, 0);
-          acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], ring[k8 * 2 + 1][s], acc[3], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[0][s], ring[k8 * 2][s], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[0][s], ring[k8 * 2 + 1][s], acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[1][s], ring[k8 * 2][s], acc[2], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[1][s], ring[k8 * 2 + 1][s], acc[3], 0, 0, 0);
         }
         ring[k8 * 2] = nx[(k8 * 2) * 64 + lane];
         ring[k8 * 2 + 1] = nx[(k8 * 2 + 1) * 64 + lane];
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
         __builtin_amdgcn_sched_barrier(0);   // keep the refill behind its MFMAs (see ffn_block_kernel)
       }
     }
@@ -565,19 +576,26 @@ __global__ __launch_bounds__(256, 1) void conv_tail_kernel(const ConvTailArgs g)
     const float* pa = arow + kh;
     const f32x4* wf = wbase(wfrag);
     const f32x4* wnext = next_wfrag ? wbase(next_wfrag) : wf;
+    f32x4 p0 = *(const f32x4*)(pa), p1;      // ping-pong A fragments (see ffn_block_kernel)
 #pragma unroll 1
     for (int blk = 0; blk < 4; ++blk) {
       const f32x4* nx = blk < 3 ? wf + (blk + 1) * 16 * 64 : wnext;
 #pragma unroll
       for (int k8 = 0; k8 < 8; ++k8) {
-        f32x4 a = *(const f32x4*)(pa + (blk * 8 + k8) * 8);
+        const int kn = (blk * 8 + k8 + 1) & 31;
+        f32x4& ac = (k8 & 1) ? p1 : p0;
+        f32x4& an = (k8 & 1) ? p0 : p1;
+        an = *(const f32x4*)(pa + kn * 8);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], ring[k8 * 2][s], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], ring[k8 * 2 + 1][s], acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[s], ring[k8 * 2][s], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[s], ring[k8 * 2 + 1][s], acc[1], 0, 0, 0);
         }
         ring[k8 * 2] = nx[(k8 * 2) * 64 + lane];
         ring[k8 * 2 + 1] = nx[(k8 * 2 + 1) * 64 + lane];
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
         __builtin_amdgcn_sched_barrier(0);   // keep the refill behind its MFMAs (see ffn_block_kernel)
       }
     }
