@@ -28,19 +28,8 @@ BINS_PFUTURE = [2, 3]     # vap_main.py:188
 
 def _load_state_dicts(vap_model, cpc_model):
     """Accept paths (torch.load like vap_main.py:199 / encoder_components.py:372) or ready dicts."""
-    if isinstance(vap_model, (str, bytes)) or hasattr(vap_model, "__fspath__"):
-        import torch
-        vap_sd = torch.load(vap_model, map_location="cpu")
-    else:
-        vap_sd = vap_model
-    if isinstance(cpc_model, (str, bytes)) or hasattr(cpc_model, "__fspath__"):
-        import torch
-        cpc_sd = torch.load(cpc_model, map_location="cpu")
-    else:
-        cpc_sd = cpc_model
-    if "weights" in cpc_sd:                      # load_CPC uses checkpoint["weights"]
-        cpc_sd = cpc_sd["weights"]
-    return cpc_sd, vap_sd
+    from . import checkpoints
+    return checkpoints.load_state_dicts(vap_model, cpc_model)
 
 
 class VAPRealTime:
