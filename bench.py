@@ -68,7 +68,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--groups", type=int, default=0, help="intra-tick overlap groups (0 = engine default)")
-    ap.add_argument("--mode", default="vap", choices=["vap", "bc", "nod"], help="model variant (config 5: bc / nod)")
+    ap.add_argument("--mode", default="vap", choices=["vap", "bc", "nod", "bc+nod", "vap+bc+nod"],
+                    help="model variant (config 5: bc / nod); a+b = weight sets served on one shared CPC trunk "
+                         "(one stream-frame = one audio frame through the shared encoder and every listed model)")
     ap.add_argument("--subtick-streams", type=int, default=1024,
                     help="sub-tick size for the <=10 ms latency leg (0 = skip)")
     args = ap.parse_args()
@@ -85,9 +87,16 @@ def main():
     T = int(args.ctx_sec * hz)
     hop = 16000 // hz
     my_streams = shard_streams(S * world, world, rank)           # global stream ids of this rank
-    cpc, vap = W.synthetic_weights(0, hz, args.mode)
-    eng = engine.Engine(W.pack_blob(cpc, vap, args.mode), hz, args.ctx_sec, max_streams=S, device_id=local_rank,
-                        groups=args.groups, mode=args.mode)
+    modes = args.mode.split("+")
+    cpc, vap = W.synthetic_weights(0, hz, modes[0])
+    eng = engine.Engine(W.pack_blob(cpc, vap, modes[0]), hz, args.ctx_sec, max_streams=S, device_id=local_rank,
+                        groups=args.groups, mode=modes[0])
+    followers = []
+    for k, m in enumerate(modes[1:]):                            # same cpc_model "file", own VAP state dict
+        f = engine.Engine(W.pack_blob(cpc, W.synthetic_weights(1 + k, hz, m)[1], m), hz, args.ctx_sec, max_streams=S,
+                          device_id=local_rank, groups=args.groups, mode=m)
+        f.attach_trunk(eng)
+        followers.append(f)
 
     NF = 32                                                      # distinct audio frames, cycled
     base = synth.dialogue_batch(my_streams[:min(S, 64)], hop * NF)   # [<=64,2,hop*NF]
@@ -96,10 +105,25 @@ def main():
     audio = np.ascontiguousarray(audio.reshape(S, 2, NF, hop).transpose(2, 0, 1, 3))   # [NF,S,2,hop]
     d_audio = torch.from_numpy(audio).cuda()
     d_out = torch.zeros(S, engine.OUT_STRIDE, device="cuda")
+    d_out_f = [torch.zeros(S, engine.OUT_STRIDE, device="cuda") for _ in followers]
     stream = torch.cuda.current_stream().cuda_stream
 
     def step(i):
         eng.step_device(S, d_audio[i % NF].data_ptr(), hop, d_out.data_ptr(), stream=stream)
+        for f, o in zip(followers, d_out_f):
+            f.step_follow_device(S, o.data_ptr(), stream=stream)
+
+    def profile_enable(classes):
+        for e in [eng] + followers:
+            e.profile_enable(classes)
+
+    def profile_read():
+        tot = {}
+        for e in [eng] + followers:
+            for k, (ms, cnt) in e.profile_read().items():
+                a = tot.get(k, (0.0, 0))
+                tot[k] = (a[0] + ms, a[1] + cnt)
+        return tot
 
     def barrier():
         dist_util.barrier(dist, torch.cuda.synchronize)
@@ -109,35 +133,38 @@ def main():
     for i in range(T):
         step(i)
     torch.cuda.synchronize()
-    eng.profile_enable(range(13))
-    eng.profile_read()
+    profile_enable(range(13))
+    profile_read()
     NP = 5
     for i in range(NP):
         step(i)
-    prof_all = eng.profile_read()
+    prof_all = profile_read()
     breakdown = {k: v[0] / NP for k, v in prof_all.items()}
     dominant = max(breakdown, key=breakdown.get)
     dom_id = [k for k, v in engine.PROF_CLASSES.items() if v == dominant][0]
-    eng.profile_enable([dom_id])
-    eng.profile_read()
+    profile_enable([dom_id])
+    profile_read()
 
     for i in range(args.warmup):
         step(i)
     barrier()
-    eng.profile_read()
+    profile_read()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     barrier()
     dt = time.perf_counter() - t0
-    dom_ms, dom_launches = eng.profile_read()[dominant]
-    eng.profile_enable([])
+    dom_ms, dom_launches = profile_read()[dominant]
+    profile_enable([])
     dt = dist_util.max_over_ranks(dist, dt, "cuda")
     assert torch.isfinite(d_out[:, :6]).all(), "non-finite outputs"
 
     frames = S * world * args.steps
     value = frames / dt
     macs = macs_per_stream_frame(hz, T)
+    if len(modes) > 1:   # every model runs its own downsample + transformer; the encoder classes run once
+        shared = ("conv0", "gemm_cn_relu", "conv_tail", "lstm")
+        macs = {k: v * (1 if k in shared else len(modes)) for k, v in macs.items()}
     launches_per_step = dom_launches / args.steps
     flop_per_launch = 2.0 * macs[dominant] * S / launches_per_step
     avg_launch_s = dom_ms * 1e-3 / dom_launches
@@ -178,7 +205,7 @@ def main():
         "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1])},
     }
 
-    if rank == 0 and not args.no_latency:
+    if rank == 0 and not args.no_latency and not followers:
         # host-inclusive tick latency: host audio -> results on host (H2D + kernels + D2H + sync)
         lat = []
         for i in range(60):
@@ -230,6 +257,8 @@ def main():
         result["cpu_baseline"] = {"value": n / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
                                   "sample": f"{n} frames of 1 stream (batch 1, window full, torch-CPU fp32, 1 thread) in {cdt:.1f} s; host has {os.cpu_count()} logical cores",
                                   "ms_per_frame": cdt / n * 1e3}
+    for f in followers:
+        f.close()
     eng.close()
     if dist is not None:
         dist.barrier()

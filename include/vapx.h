@@ -111,6 +111,19 @@ void vapx_destroy(vapx_handle h);
 int vapx_step(vapx_handle h, int32_t n, const int32_t* stream_ids, const float* audio,
               int32_t samples_per_ch, float* out, int32_t flags, void* hip_stream);
 
+/* Multi-model serving on one shared CPC trunk.  The bc / nod / vap programs of the reference
+ * (rvap/vap_bc/vap_bc_main.py, rvap/vap_nod/vap_nod_main.py, rvap/vap_main/vap_main.py) each load the SAME cpc_model
+ * file for the CNN + LSTM (vap_main.py:199-201 skips the state dict's encoder.* keys) and differ only in the
+ * downsample, the transformer and the heads.  After vapx_attach_trunk(follower, leader) the follower never runs the
+ * encoder: each tick, step the leader with the audio, then step every follower with audio == NULL (same n, same
+ * hip_stream; stream_ids is ignored, the leader's are used).  The follower applies its own downsample to the
+ * leader's LSTM outputs and runs its own rings / transformer / heads.  Requirements: both engines freshly created
+ * (no step yet), same device, frame_hz, ctx_frames, max_streams, max_batch, and bit-identical CPC weights in the two
+ * blobs.  A leader can have several followers; vapx_reset_stream on the leader resets them too (and is refused on
+ * a follower); LSTM / carry state import / export goes through the leader, ring state through each engine.
+ * Destroy followers before their leader. */
+int vapx_attach_trunk(vapx_handle follower, vapx_handle leader);
+
 /* Zero one stream's state (context ring fill, LSTM h/c, carry).  The reference never resets
  * model state on reconnect (vap_main.py:368-369 re-zeroes only the carry); this is the explicit
  * equivalent of constructing a fresh VAPRealTime for that stream. */

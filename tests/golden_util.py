@@ -24,6 +24,8 @@ class Case:
         self.L = self.hop + 320
         self.T = int(self.ctx_sec * self.frame_hz)
         self.cpc_sd, self.vap_sd = W.synthetic_weights(self.seed, self.frame_hz, self.mode)
+        if "meta.cpc_seed" in z and int(z["meta.cpc_seed"]) != self.seed:      # models sharing one cpc_model file
+            self.cpc_sd = W.synthetic_weights(int(z["meta.cpc_seed"]), self.frame_hz, "vap")[0]
         fp = W.weights_fingerprint(self.cpc_sd, self.vap_sd)
         assert np.array_equal(fp, z["meta.weights_fp"]), "seeded weights differ from the ones the golden was made with"
         self.audio = synth.dialogue_batch(self.streams, self.hop * self.n_frames + 320)

@@ -70,6 +70,24 @@ def test_oracle_nod_heads():
         np.testing.assert_allclose(out["p_bc"][:, :n], c.z["p_bc"][f][:, :n], rtol=0, atol=TOL_P)
 
 
+def test_oracle_models_sharing_one_cpc_file():
+    """trunk_* goldens: three reference programs (vap, bc, nod) loaded from ONE cpc_model file, same audio."""
+    cv, cb, cn = Case("trunk_vap20"), Case("trunk_bc20"), Case("trunk_nod20")
+    for k in cv.cpc_sd:
+        assert np.array_equal(cv.cpc_sd[k], cb.cpc_sd[k]) and np.array_equal(cv.cpc_sd[k], cn.cpc_sd[k])
+    assert not np.array_equal(cv.vap_sd["ar.layers.0.mha.key.weight"], cb.vap_sd["ar.layers.0.mha.key.weight"])
+    ov, _ = run_oracle(cv)
+    ob, _ = run_oracle(cb)
+    on, _ = run_oracle(cn)
+    for f in range(cv.n_frames):
+        np.testing.assert_allclose(ov[f]["logits"], cv.z["logits"][f], rtol=0, atol=TOL)
+        np.testing.assert_allclose(ov[f]["p_now"], cv.z["p_now"][f], rtol=0, atol=TOL_P)
+        np.testing.assert_allclose(ob[f]["p_bc_react"], cb.z["p_bc_react"][f].reshape(-1), rtol=0, atol=TOL_P)
+        np.testing.assert_allclose(ob[f]["p_bc_emo"], cb.z["p_bc_emo"][f].reshape(-1), rtol=0, atol=TOL_P)
+        for k in ("p_nod_short", "p_nod_long", "p_nod_long_p"):
+            np.testing.assert_allclose(on[f][k], cn.z[k][f].reshape(-1), rtol=0, atol=TOL_P)
+
+
 def test_batched_oracle_equals_independent_runs():
     """multi3 golden = three independent reference processes; the oracle runs them as one batch."""
     c = Case("multi3")

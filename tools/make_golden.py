@@ -35,6 +35,11 @@ CASES = {
     "multi3": dict(mode="vap", frame_hz=20, ctx=2.5, streams=[10, 11, 12], n_frames=55, framing="server", seed=3, inter=[], e_stride=6),
     "bc20": dict(mode="bc", frame_hz=20, ctx=2.5, streams=[4], n_frames=56, framing="server", seed=4, inter=[]),
     "nod20": dict(mode="nod", frame_hz=20, ctx=2.5, streams=[5], n_frames=56, framing="server", seed=5, inter=[]),
+    # three models on ONE cpc_model file (cpc_seed) and the same audio, as the reference deploys them side by side:
+    # pins the shared-trunk serving path (vapx_attach_trunk)
+    "trunk_vap20": dict(mode="vap", frame_hz=20, ctx=2.5, streams=[6, 7], n_frames=54, framing="server", seed=7, cpc_seed=6, inter=[], e_stride=6),
+    "trunk_bc20": dict(mode="bc", frame_hz=20, ctx=2.5, streams=[6, 7], n_frames=54, framing="server", seed=8, cpc_seed=6, inter=[], e_stride=6),
+    "trunk_nod20": dict(mode="nod", frame_hz=20, ctx=2.5, streams=[6, 7], n_frames=54, framing="server", seed=9, cpc_seed=6, inter=[], e_stride=6),
 }
 ROW_SUBSET_AT = 8  # intermediates with more rows than this keep rows [0, n//3, n-1] only
 
@@ -58,6 +63,8 @@ def run_case(name: str) -> None:
         import rvap.vap_nod.vap_nod_main as ref
 
     cpc_sd, vap_sd = W.synthetic_weights(cfg["seed"], hz, mode)
+    if "cpc_seed" in cfg:
+        cpc_sd = W.synthetic_weights(cfg["cpc_seed"], hz, "vap")[0]
     tmp = tempfile.mkdtemp(prefix="vapgold_")
     cpc_pt, vap_pt = os.path.join(tmp, "cpc.pt"), os.path.join(tmp, "vap.pt")
     torch.save({"weights": {k: torch.from_numpy(v.copy()) for k, v in cpc_sd.items()}}, cpc_pt)
@@ -158,6 +165,7 @@ def run_case(name: str) -> None:
     out["meta.n_frames"] = np.array(F_)
     out["meta.framing"] = np.array(cfg["framing"])
     out["meta.seed"] = np.array(cfg["seed"])
+    out["meta.cpc_seed"] = np.array(cfg.get("cpc_seed", cfg["seed"]))
     out["meta.weights_fp"] = W.weights_fingerprint(cpc_sd, vap_sd)
     out["meta.audio_fp"] = np.array([audio.astype(np.float64).sum(), np.abs(audio.astype(np.float64)).sum()])
     path = os.path.join(REPO, "tests", "golden", f"{name}.npz")

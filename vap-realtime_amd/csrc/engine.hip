@@ -92,6 +92,13 @@ struct vapx_engine {
   hipEvent_t ids_evt = nullptr;
   int last_B = 0;
 
+  // shared trunk (vapx_attach_trunk): followers take the leader's LSTM outputs instead of running the CPC encoder
+  vapx_engine* trunk = nullptr;           // set on a follower
+  std::vector<vapx_engine*> followers;    // set on the leader
+  bool orphaned = false;                  // follower whose leader was destroyed
+  uint64_t tick = 0, followed_tick = 0;
+  const int* last_ids = nullptr;          // device ids of the latest step (null = identity)
+
   // optional per-kernel-class HIP-event timing (vapx_profile_*): events are recorded on the launch
   // stream around the launches whose class bit is set in prof_mask
   uint32_t prof_mask = 0;
@@ -425,14 +432,26 @@ int run_combinator_all_rows(vapx_engine* h, const Scratch& sc, int n, hipStream_
 
 // one sub-batch of a tick: encoder -> ring -> transformer -> heads.  `b0` is the offset of the
 // group inside the caller's batch (identity stream ids when ids == nullptr start at b0).
-int step_group(vapx_engine* h, const Scratch& sc, int nb, int b0, const int* ids, const float* audio, int spc,
-               float* out, hipStream_t st) {
+int step_group(vapx_engine* h, const Scratch& sc_own, int nb, int b0, const int* ids, const float* audio, int spc,
+               float* out, hipStream_t st, const Scratch* lead = nullptr) {
+  Scratch sc = sc_own;
+  if (lead) { sc.bn = lead->bn; sc.bhead = lead->bhead; }   // window fill / ring slot: decided by the leader's conv0
   // identity ids: kernels index state by batch slot, so advance the state bases by b0 streams
   const size_t s0 = ids ? 0 : (size_t)b0;
   const StateView sv{h->ring + s0 * 2 * h->T * 256, h->ring_qkv + s0 * 2 * h->T * 768, h->h_state + s0 * 512, h->c_state + s0 * 512,
                      h->carry + s0 * 2 * VAPX_PAD, h->frames_seen + s0};
-  int rc = run_encoder(h, sc, sv, nb, ids, audio, spc, true, st);
-  if (rc) return rc;
+  int rc = VAPX_OK;
+  if (!lead) {
+    rc = run_encoder(h, sc, sv, nb, ids, audio, spc, true, st);
+    if (rc) return rc;
+  } else {
+    // this weight set's own downsample on the shared LSTM outputs: e = gelu(LN(Conv1d_K(lstm_out))), en = LN0(e)
+    GemmArgs g = gemm_args(lead->lstm_out, contiguous_rows(h->ncpc * 256), h->W("down.w"), nb * 2, 256, h->ncpc * 256, sc.e,
+                           contiguous_rows(256));
+    g.bias = h->W("down.b"); g.gamma = h->W("down.g"); g.beta = h->W("down.beta");
+    HIPCHK(h, gemm(h, g, EPI_BIAS_LN_GELU, st));
+    HIPCHK(h, launch_ln_rows(sc.e, sc.en, h->layer[0].ln_self_g, h->layer[0].ln_self_b, nb * 2, st));
+  }
   {  // layer-0 Q|K|V of the NEW row only: they are per-row functions of the embedding, so the other
      // rows' values are cached next to the ring (exact; saves the [rows x 768] GEMM every tick)
     GemmArgs g = gemm_args(sc.en, contiguous_rows(256), h->layer[0].wqkv, nb * 2, 768, 256, sc.qkv_new, contiguous_rows(768));
@@ -491,6 +510,12 @@ const char* vapx_last_error(vapx_handle h) { return h ? h->err.c_str() : g_creat
 
 void vapx_destroy(vapx_handle h) {
   if (!h) return;
+  if (h->trunk) {
+    auto& fl = h->trunk->followers;
+    for (size_t i = 0; i < fl.size(); ++i)
+      if (fl[i] == h) { fl.erase(fl.begin() + i); break; }
+  }
+  for (vapx_engine* f : h->followers) { f->trunk = nullptr; f->orphaned = true; }
   (void)hipSetDevice(h->cfg.device_id);
   (void)hipDeviceSynchronize();
   float* fp[] = {h->w, h->ring, h->ring_qkv, h->h_state, h->c_state, h->carry, h->audio_dev, h->out_dev, h->sc.h0, h->sc.h1, h->sc.h2, h->sc.h3,
@@ -624,16 +649,28 @@ int vapx_step(vapx_handle h, int32_t n, const int32_t* stream_ids, const float* 
               int32_t flags, void* hip_stream) {
   if (!h) return VAPX_E_INVAL;
   if (n < 1 || n > h->cfg.max_batch) return fail(h, VAPX_E_RANGE, "n=%d outside [1,%d]", n, h->cfg.max_batch);
-  if (!audio || !out) return fail(h, VAPX_E_INVAL, "null audio/out");
-  if (spc != h->hop && spc != h->L) return fail(h, VAPX_E_INVAL, "samples_per_ch must be %d (hop) or %d (full frame)", h->hop, h->L);
+  if (!out) return fail(h, VAPX_E_INVAL, "null out");
+  vapx_engine* lead = h->trunk;
+  if (h->orphaned) return fail(h, VAPX_E_INVAL, "the trunk leader of this engine was destroyed");
+  if (lead) {
+    if (audio) return fail(h, VAPX_E_INVAL, "a trunk follower takes no audio (pass NULL): it consumes its leader's encoder output");
+    if (lead->tick == 0 || lead->tick == h->followed_tick)
+      return fail(h, VAPX_E_INVAL, "step the trunk leader first: no new encoder output since this follower's last step");
+    if (n != lead->last_B) return fail(h, VAPX_E_INVAL, "n=%d differs from the leader's latest step (%d streams)", n, lead->last_B);
+  } else {
+    if (!audio) return fail(h, VAPX_E_INVAL, "null audio");
+    if (spc != h->hop && spc != h->L) return fail(h, VAPX_E_INVAL, "samples_per_ch must be %d (hop) or %d (full frame)", h->hop, h->L);
+  }
   if (!stream_ids && n > h->cfg.max_streams) return fail(h, VAPX_E_RANGE, "n exceeds max_streams");
   hipStream_t st = (hipStream_t)hip_stream;
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   const int* ids = nullptr;
-  int rc = upload_ids(h, n, stream_ids, flags, st, &ids);
+  int rc = VAPX_OK;
+  if (lead) ids = lead->last_ids;   // same streams, same order as the leader's step (stream_ids is ignored)
+  else rc = upload_ids(h, n, stream_ids, flags, st, &ids);
   if (rc) return rc;
   const float* ad = audio;
-  if (!(flags & VAPX_AUDIO_DEVICE)) {
+  if (!lead && !(flags & VAPX_AUDIO_DEVICE)) {
     HIPCHK(h, hipMemcpyAsync(h->audio_dev, audio, (size_t)n * 2 * spc * sizeof(float), hipMemcpyHostToDevice, st));
     ad = h->audio_dev;
   }
@@ -651,13 +688,18 @@ int vapx_step(vapx_handle h, int32_t n, const int32_t* stream_ids, const float* 
     hipStream_t gs = G > 1 ? h->gstream[g] : st;
     const Scratch sc = h->sc.slice(b0, h->P, h->ncpc, h->T);
     const int* gids = ids ? ids + b0 : nullptr;
-    rc = step_group(h, sc, nb, b0, gids, ad + (size_t)b0 * 2 * spc, spc, od + (size_t)b0 * VAPX_OUT_STRIDE, gs);
+    Scratch lsc;
+    if (lead) lsc = lead->sc.slice(b0, h->P, h->ncpc, h->T);
+    rc = step_group(h, sc, nb, b0, gids, lead ? nullptr : ad + (size_t)b0 * 2 * spc, spc, od + (size_t)b0 * VAPX_OUT_STRIDE, gs,
+                    lead ? &lsc : nullptr);
     if (rc) return rc;
     if (G > 1) HIPCHK(h, hipEventRecord(h->gdone[g], gs));
   }
   if (G > 1)
     for (int g = 0; g < G; ++g) HIPCHK(h, hipStreamWaitEvent(st, h->gdone[g], 0));
   h->last_B = n;
+  h->last_ids = ids;
+  if (lead) h->followed_tick = lead->tick; else ++h->tick;
   if (!(flags & VAPX_OUT_DEVICE)) {
     HIPCHK(h, hipMemcpyAsync(h->out_pinned, h->out_dev, (size_t)n * VAPX_OUT_STRIDE * sizeof(float), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
@@ -666,15 +708,46 @@ int vapx_step(vapx_handle h, int32_t n, const int32_t* stream_ids, const float* 
   return VAPX_OK;
 }
 
+int vapx_attach_trunk(vapx_handle f, vapx_handle lead) {
+  if (!f || !lead) return VAPX_E_INVAL;
+  if (f == lead || lead->trunk || f->trunk || !f->followers.empty())
+    return fail(f, VAPX_E_INVAL, "attach a stand-alone engine to a leader that is not itself a follower");
+  if (f->tick != 0 || lead->tick != 0) return fail(f, VAPX_E_INVAL, "attach before the first step of either engine");
+  if (f->cfg.device_id != lead->cfg.device_id || f->cfg.frame_hz != lead->cfg.frame_hz || f->T != lead->T ||
+      f->cfg.max_streams != lead->cfg.max_streams || f->cfg.max_batch != lead->cfg.max_batch)
+    return fail(f, VAPX_E_INVAL, "device, frame_hz, ctx_frames, max_streams and max_batch must match the leader's");
+  HIPCHK(f, hipSetDevice(f->cfg.device_id));
+  HIPCHK(f, hipDeviceSynchronize());
+  {  // the CPC CNN + LSTM weights must be the same tensors (they come from the common cpc_model file, vap_main.py:199-201)
+    const float* a0 = f->W("conv0.w"); const float* a1 = f->W("down.w");
+    const float* b0 = lead->W("conv0.w");
+    const size_t nfl = (size_t)(a1 - a0);
+    std::vector<float> ha(nfl), hb(nfl);
+    HIPCHK(f, hipMemcpy(ha.data(), a0, nfl * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(f, hipMemcpy(hb.data(), b0, nfl * sizeof(float), hipMemcpyDeviceToHost));
+    if (memcmp(ha.data(), hb.data(), nfl * sizeof(float)) != 0)
+      return fail(f, VAPX_E_INVAL, "CPC encoder weights differ from the leader's: nothing to share");
+  }
+  // a follower never runs the encoder: release its encoder scratch and LSTM / carry state
+  float** drop[] = {&f->sc.h0, &f->sc.h1, &f->sc.h2, &f->sc.h3, &f->sc.z, &f->sc.gx, &f->sc.lstm_out, &f->audio_dev,
+                    &f->h_state, &f->c_state, &f->carry};
+  for (float** p : drop) { if (*p) (void)hipFree(*p); *p = nullptr; }
+  f->trunk = lead;
+  lead->followers.push_back(f);
+  return VAPX_OK;
+}
+
 int vapx_reset_stream(vapx_handle h, int32_t sid) {
   if (!h) return VAPX_E_INVAL;
   if (sid < 0 || sid >= h->cfg.max_streams) return fail(h, VAPX_E_RANGE, "stream id out of range");
+  if (h->trunk) return fail(h, VAPX_E_INVAL, "reset the trunk leader: it resets its followers too");
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   HIPCHK(h, hipDeviceSynchronize());
   HIPCHK(h, hipMemset(h->h_state + (size_t)sid * 512, 0, 512 * sizeof(float)));
   HIPCHK(h, hipMemset(h->c_state + (size_t)sid * 512, 0, 512 * sizeof(float)));
   HIPCHK(h, hipMemset(h->carry + (size_t)sid * 2 * VAPX_PAD, 0, 2 * VAPX_PAD * sizeof(float)));
   HIPCHK(h, hipMemset(h->frames_seen + sid, 0, sizeof(int)));
+  for (vapx_engine* f : h->followers) HIPCHK(h, hipMemset(f->frames_seen + sid, 0, sizeof(int)));
   return VAPX_OK;
 }
 
@@ -696,6 +769,7 @@ int vapx_get_state(vapx_handle h, int32_t sid, float* ring, int32_t* n_frames, f
         memcpy(ring + ((size_t)c * T + t) * 256, tmp.data() + ((size_t)c * T + slot) * 256, 256 * sizeof(float));
       }
   }
+  if (h->trunk && (lstm || carry)) return fail(h, VAPX_E_INVAL, "LSTM / carry state lives in the trunk leader");
   if (lstm) {
     for (int c = 0; c < 2; ++c) {
       HIPCHK(h, hipMemcpy(lstm + (c * 2 + 0) * 256, h->h_state + ((size_t)sid * 2 + c) * 256, 256 * sizeof(float), hipMemcpyDeviceToHost));
@@ -710,6 +784,7 @@ int vapx_set_state(vapx_handle h, int32_t sid, const float* ring, int32_t n_fram
   if (!h) return VAPX_E_INVAL;
   if (sid < 0 || sid >= h->cfg.max_streams) return fail(h, VAPX_E_RANGE, "stream id out of range");
   if (n_frames < 0 || n_frames > h->T) return fail(h, VAPX_E_INVAL, "n_frames outside [0,T]");
+  if (h->trunk && (lstm || carry)) return fail(h, VAPX_E_INVAL, "LSTM / carry state lives in the trunk leader");
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   HIPCHK(h, hipDeviceSynchronize());
   const int T = h->T;
@@ -745,6 +820,7 @@ int vapx_set_state(vapx_handle h, int32_t sid, const float* ring, int32_t n_fram
 
 int vapx_encode_audio(vapx_handle h, int32_t n, const int32_t* stream_ids, const float* frames, float* e, void* hip_stream) {
   if (!h) return VAPX_E_INVAL;
+  if (h->trunk || h->orphaned) return fail(h, VAPX_E_INVAL, "a trunk follower has no encoder; call the leader");
   if (n < 1 || n > h->cfg.max_batch) return fail(h, VAPX_E_RANGE, "n=%d outside [1,%d]", n, h->cfg.max_batch);
   if (!frames || !e) return fail(h, VAPX_E_INVAL, "null frames/e");
   hipStream_t st = (hipStream_t)hip_stream;

@@ -99,5 +99,6 @@ hipError_t launch_ring_append(const GatherArgs& a, hipStream_t st);
 hipError_t launch_gather_ln(const GatherArgs& a, hipStream_t st);
 hipError_t launch_attention(const AttnArgs& a, int B, hipStream_t st);
 hipError_t launch_gather_last_ln(const LastRowArgs& a, hipStream_t st);
+hipError_t launch_ln_rows(const float* x, float* y, const float* gamma, const float* beta, int rows, hipStream_t st);
 hipError_t launch_attention_last(const AttnArgs& a, int B, hipStream_t st);
 hipError_t launch_head(const HeadArgs& a, hipStream_t st);

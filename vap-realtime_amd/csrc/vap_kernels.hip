@@ -564,6 +564,21 @@ __global__ __launch_bounds__(256) void gather_last_ln_kernel(LastRowArgs a) {
   *(f32x4*)(a.xnlast + (long)bc * 256 + lane * 4) = d * rstd * g + be;
 }
 
+// LayerNorm of plain [rows][256] rows, one wave per row (trunk followers: en = LN0(e))
+__global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta, int rows) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  f32x4 v = *(const f32x4*)(x + (long)r * 256 + lane * 4);
+  float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+  f32x4 d = v - mean;
+  float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.0f / 256.0f);
+  float rstd = rsqrtf(var + 1e-5f);
+  f32x4 g = *(const f32x4*)(gamma + lane * 4), be = *(const f32x4*)(beta + lane * 4);
+  *(f32x4*)(y + (long)r * 256 + lane * 4) = d * rstd * g + be;
+}
+
 // single-query attention: query = newest row (index n-1, so every key j < n is causal-visible),
 // one workgroup per (stream, channel), one wave per head.  Phase 1: lane = key j computes the
 // score; softmax across lanes; phase 2: lane = feature d accumulates sum_j p_j V[j][d].
@@ -833,6 +848,10 @@ hipError_t launch_attention(const AttnArgs& a, int B, hipStream_t st) {
 }
 hipError_t launch_gather_last_ln(const LastRowArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(gather_last_ln_kernel, dim3((a.B * 2 + 3) / 4), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_ln_rows(const float* x, float* y, const float* gamma, const float* beta, int rows, hipStream_t st) {
+  hipLaunchKernelGGL(ln_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, y, gamma, beta, rows);
   return hipGetLastError();
 }
 hipError_t launch_attention_last(const AttnArgs& a, int B, hipStream_t st) {

@@ -21,7 +21,7 @@ AUDIO_DEVICE, OUT_DEVICE, IDS_DEVICE = 1, 2, 4
 MODE = {"vap": 0, "bc": 1, "nod": 2}
 
 EXPORTS = ("vapx_abi_version", "vapx_blob_floats", "vapx_create", "vapx_destroy", "vapx_step",
-           "vapx_reset_stream", "vapx_get_state", "vapx_set_state", "vapx_encode_audio",
+           "vapx_attach_trunk", "vapx_reset_stream", "vapx_get_state", "vapx_set_state", "vapx_encode_audio",
            "vapx_transformer", "vapx_peek", "vapx_gemm", "vapx_last_error", "vapx_profile_enable",
            "vapx_profile_read")
 PROF_CLASSES = {0: "gemm_store", 1: "gemm_gelu", 2: "gemm_resid", 3: "gemm_resid_ln", 4: "gemm_cn_relu",
@@ -66,6 +66,8 @@ def load_library(path: Optional[str] = None):
     lib.vapx_destroy.argtypes = [vp]
     lib.vapx_step.restype = i32
     lib.vapx_step.argtypes = [vp, i32, i32p, f32p, i32, f32p, i32, vp]
+    lib.vapx_attach_trunk.restype = i32
+    lib.vapx_attach_trunk.argtypes = [vp, vp]
     lib.vapx_reset_stream.restype = i32
     lib.vapx_reset_stream.argtypes = [vp, i32]
     lib.vapx_get_state.restype = i32
@@ -152,6 +154,20 @@ class Engine:
         self._check(self.lib.vapx_step(self._h, n, _np_ptr(ids), _np_ptr(audio), spc, _np_ptr(out), 0, None), "vapx_step")
         return out
 
+    def attach_trunk(self, leader: "Engine"):
+        """Make this engine a follower of ``leader``: it shares the leader's CPC CNN + LSTM (vapx.h, vapx_attach_trunk)."""
+        self._check(self.lib.vapx_attach_trunk(self._h, leader._h), "vapx_attach_trunk")
+        self._leader = leader                                # keeps the leader alive as long as the follower
+
+    def step_follow(self, n: int) -> np.ndarray:
+        """Follower step on the host path: consumes the encoder output of the leader's latest ``step``."""
+        out = np.empty((n, OUT_STRIDE), dtype=np.float32)
+        self._check(self.lib.vapx_step(self._h, n, None, None, 0, _np_ptr(out), 0, None), "vapx_step")
+        return out
+
+    def step_follow_device(self, n: int, out_ptr: int, stream: int = 0):
+        self._check(self.lib.vapx_step(self._h, n, None, None, 0, out_ptr, OUT_DEVICE, stream or None), "vapx_step")
+
     def step_device(self, n: int, audio_ptr: int, spc: int, out_ptr: int, ids_ptr: int = 0, stream: int = 0):
         """Device path: raw device pointers (e.g. ``tensor.data_ptr()``), work enqueued on ``stream``
         (a hipStream_t as int, 0 = default); returns immediately."""
@@ -166,13 +182,15 @@ class Engine:
         lstm = np.zeros((2, 2, 256), np.float32)
         carry = np.zeros((2, 320), np.float32)
         n = C.c_int32(0)
+        if getattr(self, "_leader", None) is not None:       # follower: LSTM / carry live in the leader
+            lstm = carry = None
         self._check(self.lib.vapx_get_state(self._h, sid, _np_ptr(ring), C.byref(n), _np_ptr(lstm), _np_ptr(carry)), "vapx_get_state")
         return {"ring": ring, "n_frames": n.value, "lstm": lstm, "carry": carry}
 
     def set_state(self, sid: int, state: dict):
         ring = np.ascontiguousarray(state["ring"], np.float32)
-        lstm = np.ascontiguousarray(state["lstm"], np.float32)
-        carry = np.ascontiguousarray(state["carry"], np.float32)
+        lstm = None if state.get("lstm") is None else np.ascontiguousarray(state["lstm"], np.float32)
+        carry = None if state.get("carry") is None else np.ascontiguousarray(state["carry"], np.float32)
         self._check(self.lib.vapx_set_state(self._h, sid, _np_ptr(ring), int(state["n_frames"]), _np_ptr(lstm), _np_ptr(carry)), "vapx_set_state")
 
     def profile_enable(self, classes=()):
@@ -203,6 +221,43 @@ class Engine:
                            stage: int = 0, stream: int = 0):
         self._check(self.lib.vapx_transformer(self._h, n, rows, x_ptr, o_ptr or None, x12_ptr or None, comb_ptr or None,
                                               stage, stream or None), "vapx_transformer")
+
+
+class TrunkGroup:
+    """Several weight sets (vap / bc / nod) served from ONE pass of the CPC CNN + LSTM per tick.
+
+    The reference runs one process per model, each re-encoding the same audio with the same ``cpc_model``
+    weights (vap_main.py:199-201, vap_bc_main.py, vap_nod_main.py).  Here ``blobs`` is ``{mode: blob}``; the first
+    entry leads (runs the encoder), the others follow.  ``step`` returns ``{mode: out[n, OUT_STRIDE]}``."""
+
+    def __init__(self, blobs: dict, frame_hz: int = 20, context_len_sec: float = 2.5, max_streams: int = 1,
+                 max_batch: Optional[int] = None, device_id: int = 0):
+        self.modes = list(blobs)
+        self.engines = {}
+        for m in self.modes:
+            self.engines[m] = Engine(blobs[m], frame_hz, context_len_sec, max_streams, max_batch, m, device_id)
+        self.leader = self.engines[self.modes[0]]
+        for m in self.modes[1:]:
+            self.engines[m].attach_trunk(self.leader)
+        self.hop, self.L, self.T = self.leader.hop, self.leader.L, self.leader.T
+
+    def step(self, audio: np.ndarray, stream_ids: Optional[Sequence[int]] = None) -> dict:
+        res = {self.modes[0]: self.leader.step(audio, stream_ids)}
+        for m in self.modes[1:]:
+            res[m] = self.engines[m].step_follow(len(audio))
+        return res
+
+    def step_device(self, n: int, audio_ptr: int, spc: int, out_ptrs: dict, ids_ptr: int = 0, stream: int = 0):
+        self.leader.step_device(n, audio_ptr, spc, out_ptrs[self.modes[0]], ids_ptr, stream)
+        for m in self.modes[1:]:
+            self.engines[m].step_follow_device(n, out_ptrs[m], stream)
+
+    def reset_stream(self, sid: int):
+        self.leader.reset_stream(sid)                      # cascades to the followers
+
+    def close(self):
+        for m in reversed(self.modes):                     # followers before their leader
+            self.engines[m].close()
 
 
 def split_outputs(out: np.ndarray) -> dict:
