@@ -54,6 +54,9 @@ extern "C" {
 #define VAPX_OUT_HOST 0
 #define VAPX_OUT_DEVICE 2
 #define VAPX_IDS_DEVICE 4 /* stream_ids points to device memory (default: host) */
+#define VAPX_DEFER_JOIN 8 /* with overlap groups > 1 and VAPX_OUT_DEVICE: do not make hip_stream wait for the groups at the
+                             end of the step; the caller orders consumers of `out` with vapx_join.  Lets group g's next tick
+                             start while other groups still finish this one (phase-staggered sub-ticks). */
 
 /* vapx_config.flags */
 #define VAPX_FLAG_GROUPS_MASK 0xF     /* bits 0-3: intra-tick overlap groups (0 = default 1 = none, max 8) */
@@ -110,6 +113,9 @@ void vapx_destroy(vapx_handle h);
  *   hip_stream : hipStream_t to order the work on (NULL = default stream). */
 int vapx_step(vapx_handle h, int32_t n, const int32_t* stream_ids, const float* audio,
               int32_t samples_per_ch, float* out, int32_t flags, void* hip_stream);
+
+/* Make hip_stream wait for every overlap group of the latest vapx_step (see VAPX_DEFER_JOIN). */
+int vapx_join(vapx_handle h, void* hip_stream);
 
 /* Multi-model serving on one shared CPC trunk.  The bc / nod / vap programs of the reference
  * (rvap/vap_bc/vap_bc_main.py, rvap/vap_nod/vap_nod_main.py, rvap/vap_main/vap_main.py) each load the SAME cpc_model

@@ -203,6 +203,32 @@ def test_device_path_equals_host_path():
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("defer", [False, True])
+def test_overlap_groups_equal_single_stream_path(defer):
+    """Intra-tick overlap groups (vapx_config.flags bits 0-3) split the batch over HIP streams; with VAPX_DEFER_JOIN the
+    groups free-run across ticks and vapx_join orders the consumer.  Outputs must be bit-identical to groups = 1."""
+    import torch
+    from vap_realtime_amd import engine, synth, weights as W
+    cpc, vap = W.synthetic_weights(5, 20, "vap")
+    blob = W.pack_blob(cpc, vap)
+    S, F_ = 96, 6
+    audio = synth.noise_batch(S, 800 * F_, seed=3)
+    one = engine.Engine(blob, 20, 2.5, max_streams=S)
+    grp = engine.Engine(blob, 20, 2.5, max_streams=S, groups=3)
+    d_out = [torch.zeros(S, engine.OUT_STRIDE, device="cuda") for _ in range(F_)]
+    d_audio = [torch.from_numpy(np.ascontiguousarray(audio[:, :, f * 800:(f + 1) * 800])).cuda() for f in range(F_)]
+    want = [one.step(audio[:, :, f * 800:(f + 1) * 800]) for f in range(F_)]
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for f in range(F_):          # all ticks enqueued back to back, no host sync in between
+        grp.step_device(S, d_audio[f].data_ptr(), 800, d_out[f].data_ptr(), stream=side.cuda_stream, defer_join=defer)
+    grp.join(side.cuda_stream)
+    side.synchronize()
+    for f in range(F_):
+        np.testing.assert_array_equal(d_out[f].cpu().numpy(), want[f])
+    one.close(); grp.close()
+
+
 def test_error_paths():
     from vap_realtime_amd import engine
     c = Case("vap20")

@@ -90,7 +90,7 @@ struct vapx_engine {
   float* out_pinned = nullptr;
   int* ids_pinned = nullptr;
   hipEvent_t ids_evt = nullptr;
-  int last_B = 0;
+  int last_B = 0, last_G = 1;
 
   // shared trunk (vapx_attach_trunk): followers take the leader's LSTM outputs instead of running the CPC encoder
   vapx_engine* trunk = nullptr;           // set on a follower
@@ -679,6 +679,7 @@ int vapx_step(vapx_handle h, int32_t n, const int32_t* stream_ids, const float* 
   // group's kernels fill the prologue / epilogue / tail bubbles of the first group's kernels
   int G = h->n_groups;
   while (G > 1 && n / G < 32) --G;
+  const bool defer_join = G > 1 && (flags & VAPX_DEFER_JOIN) && (flags & VAPX_OUT_DEVICE);
   if (G > 1) {
     HIPCHK(h, hipEventRecord(h->gstart, st));
     for (int g = 0; g < G; ++g) HIPCHK(h, hipStreamWaitEvent(h->gstream[g], h->gstart, 0));
@@ -695,8 +696,9 @@ int vapx_step(vapx_handle h, int32_t n, const int32_t* stream_ids, const float* 
     if (rc) return rc;
     if (G > 1) HIPCHK(h, hipEventRecord(h->gdone[g], gs));
   }
-  if (G > 1)
+  if (G > 1 && !defer_join)
     for (int g = 0; g < G; ++g) HIPCHK(h, hipStreamWaitEvent(st, h->gdone[g], 0));
+  h->last_G = G;
   h->last_B = n;
   h->last_ids = ids;
   if (lead) h->followed_tick = lead->tick; else ++h->tick;
@@ -705,6 +707,13 @@ int vapx_step(vapx_handle h, int32_t n, const int32_t* stream_ids, const float* 
     HIPCHK(h, hipStreamSynchronize(st));
     memcpy(out, h->out_pinned, (size_t)n * VAPX_OUT_STRIDE * sizeof(float));
   }
+  return VAPX_OK;
+}
+
+int vapx_join(vapx_handle h, void* hip_stream) {
+  if (!h) return VAPX_E_INVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  for (int g = 0; g < h->last_G && h->last_G > 1; ++g) HIPCHK(h, hipStreamWaitEvent((hipStream_t)hip_stream, h->gdone[g], 0));
   return VAPX_OK;
 }
 

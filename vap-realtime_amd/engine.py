@@ -21,7 +21,7 @@ AUDIO_DEVICE, OUT_DEVICE, IDS_DEVICE = 1, 2, 4
 MODE = {"vap": 0, "bc": 1, "nod": 2}
 
 EXPORTS = ("vapx_abi_version", "vapx_blob_floats", "vapx_create", "vapx_destroy", "vapx_step",
-           "vapx_attach_trunk", "vapx_reset_stream", "vapx_get_state", "vapx_set_state", "vapx_encode_audio",
+           "vapx_attach_trunk", "vapx_join", "vapx_reset_stream", "vapx_get_state", "vapx_set_state", "vapx_encode_audio",
            "vapx_transformer", "vapx_peek", "vapx_gemm", "vapx_last_error", "vapx_profile_enable",
            "vapx_profile_read")
 PROF_CLASSES = {0: "gemm_store", 1: "gemm_gelu", 2: "gemm_resid", 3: "gemm_resid_ln", 4: "gemm_cn_relu",
@@ -66,6 +66,8 @@ def load_library(path: Optional[str] = None):
     lib.vapx_destroy.argtypes = [vp]
     lib.vapx_step.restype = i32
     lib.vapx_step.argtypes = [vp, i32, i32p, f32p, i32, f32p, i32, vp]
+    lib.vapx_join.restype = i32
+    lib.vapx_join.argtypes = [vp, vp]
     lib.vapx_attach_trunk.restype = i32
     lib.vapx_attach_trunk.argtypes = [vp, vp]
     lib.vapx_reset_stream.restype = i32
@@ -168,10 +170,13 @@ class Engine:
     def step_follow_device(self, n: int, out_ptr: int, stream: int = 0):
         self._check(self.lib.vapx_step(self._h, n, None, None, 0, out_ptr, OUT_DEVICE, stream or None), "vapx_step")
 
-    def step_device(self, n: int, audio_ptr: int, spc: int, out_ptr: int, ids_ptr: int = 0, stream: int = 0):
+    def join(self, stream: int = 0):
+        self._check(self.lib.vapx_join(self._h, stream or None), "vapx_join")
+
+    def step_device(self, n: int, audio_ptr: int, spc: int, out_ptr: int, ids_ptr: int = 0, stream: int = 0, defer_join: bool = False):
         """Device path: raw device pointers (e.g. ``tensor.data_ptr()``), work enqueued on ``stream``
         (a hipStream_t as int, 0 = default); returns immediately."""
-        flags = AUDIO_DEVICE | OUT_DEVICE | (IDS_DEVICE if ids_ptr else 0)
+        flags = AUDIO_DEVICE | OUT_DEVICE | (IDS_DEVICE if ids_ptr else 0) | (8 if defer_join else 0)
         self._check(self.lib.vapx_step(self._h, n, ids_ptr or None, audio_ptr, spc, out_ptr, flags, stream or None), "vapx_step")
 
     def reset_stream(self, sid: int):
