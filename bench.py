@@ -44,8 +44,10 @@ def macs_per_stream_frame(hz: int, T: int) -> dict:
         # executed work with exact last-layer pruning (only the newest row of layer 3 is consumed):
         "gemm_store": 2 * ncpc * D * 4 * D + 2 * D * 768,               # LSTM input projection + layer-0 QKV of the NEW row (others cached)
         "gemm_resid_ln": 0,
-        "ffn_block": rows * D * (3 * 2 * 768 + 2 * 768 + 512 + 3 * 512),  # FFN x3 + next QKV (x2 full, 1 K/V only) + next cross-KV x3
-        "last_row": 2 * (4 * D * D + 2 * D * 768),                      # layer 3 on one row per channel
+        "ffn_block": rows * D * (3 * 2 * 768 + 2 * 768 + 2 * 512),      # FFN x3 + QKV and cross-KV of layers 1, 2 (layer 3: absorbed)
+        # layer 3 on one row per channel: 14 contractions (q, Wk^T q, Wv, proj, their cross twins, FFN) + two
+        # 4-head single-query attentions over T rows of 256 (score + weighted sum)
+        "last_row": 2 * (14 * D * D + 2 * 4 * T * D * 2),
         "gemm_gelu": 0, "gemm_resid": 0,
         # fused attention block: dense T x T attention (as SURVEY counts it) of layers 0-2 + output
         # projections (x5) + cross-attention query projections (x2)

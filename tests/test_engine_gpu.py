@@ -203,6 +203,28 @@ def test_device_path_equals_host_path():
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("hz,ctx,S", [(20, 2.5, 21), (50, 5.0, 3)])
+def test_fused_last_row_block_equals_the_ten_launch_path(hz, ctx, S):
+    """last_block_kernel (whole last layer on the newest row, one launch) vs the unfused gathers / GEMMs / single-query
+    attentions; windows still filling, an odd batch (partial 16-row tile) and T = 250 (keys beyond one wave)."""
+    from vap_realtime_amd import engine, synth, weights as W
+    cpc, vap = W.synthetic_weights(21, hz, "vap")
+    blob = W.pack_blob(cpc, vap)
+    hop = 16000 // hz
+    F_ = 7 if hz == 20 else 70
+    audio = synth.noise_batch(S, hop * F_, seed=9) * np.linspace(0.3, 2.0, S, dtype=np.float32)[:, None, None]
+    fused = engine.Engine(blob, hz, ctx, max_streams=S)
+    plain = engine.Engine(blob, hz, ctx, max_streams=S, unfused_last_row=True)
+    worst = 0.0
+    for f in range(F_):
+        a = audio[:, :, f * hop:(f + 1) * hop]
+        got, want = fused.step(a), plain.step(a)
+        worst = max(worst, float(np.abs(got[:, :272] - want[:, :272]).max()))
+    print("fused vs unfused last row: worst |diff| =", worst)
+    assert worst <= 2e-5
+    fused.close(); plain.close()
+
+
 @pytest.mark.parametrize("defer", [False, True])
 def test_overlap_groups_equal_single_stream_path(defer):
     """Intra-tick overlap groups (vapx_config.flags bits 0-3) split the batch over HIP streams; with VAPX_DEFER_JOIN the

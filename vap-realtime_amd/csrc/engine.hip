@@ -324,8 +324,13 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
       const Layer& Ln = h->layer[l + 1];
       fa.ln_g = Ln.ln_self_g; fa.ln_b = Ln.ln_self_b; fa.wqkvf = Ln.wqkvf; fa.qkv = sc.qkv; fa.n_qkv_chunks = 3;
       fa.wkvxf = Ln.wkvxf; fa.kvx = sc.kvx;
-      if (prune_last && l + 1 == 3) {   // the pruned layer needs K,V of every row but Q of one row only
-        fa.wqkvf = Ln.wqkvf + 65536; fa.n_qkv_chunks = 2;
+      if (prune_last && l + 1 == 3) {
+        if (h->cfg.flags & VAPX_FLAG_UNFUSED_LAST_ROW) {   // the pruned layer needs K,V of every row but Q of one row only
+          fa.wqkvf = Ln.wqkvf + 65536; fa.n_qkv_chunks = 2;
+        } else {   // fused last-row block: K / V projections are absorbed into the single query (csrc/last_block.hip);
+                   // it only needs LN_self(x) of every row next to the raw rows
+          fa.wqkvf = nullptr; fa.n_qkv_chunks = 0; fa.wkvxf = nullptr; fa.xn_out = sc.xn;
+        }
       }
     }
     { ProfScope ps(h, CLS_FFN, st); HIPCHK(h, launch_ffn_block(fa, st)); }
@@ -335,6 +340,15 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
     //      previous layer's FFN block: sc.qkv = [K | V] [M][512], sc.kvx = cross [K | V] [M][512] ----
     const Layer& Lw = h->layer[3];
     const int Ml = B * 2;
+    if (!(h->cfg.flags & VAPX_FLAG_UNFUSED_LAST_ROW)) {
+      LastBlockArgs lb;
+      lb.x = sc.xl[3]; lb.xn = sc.xn; lb.bn = sc.bn; lb.wf = h->W("L3.last16");
+      lb.ln_src_g = Lw.ln_src_g; lb.ln_src_b = Lw.ln_src_b;
+      lb.ln_ffn_g = Lw.ln_ffn_g; lb.ln_ffn_b = Lw.ln_ffn_b; lb.out = sc.last[5]; lb.B = B; lb.T = T;
+      ProfScope ps(h, CLS_LASTROW, st);
+      HIPCHK(h, launch_last_block(lb, st));
+      return VAPX_OK;
+    }
     float *lx = sc.last[0], *lxn = sc.last[1], *lq = sc.last[2], *latt = sc.last[3], *lxmid = sc.last[4], *lout = sc.last[5];
     ProfScope ps(h, CLS_LASTROW, st);
     LastRowArgs lr{sc.xl[3], sc.bn, lx, lxn, Lw.ln_self_g, Lw.ln_self_b, B, T};

@@ -9,8 +9,9 @@ struct FfnArgs {
   const float* w0f;    // W0 [768][256], fragment-major: 3 column chunks
   const float* w3f;    // W3 [256][768], fragment-major: 3 k chunks
   float* xout;         // [M][256] layer output
-  const float* ln_g;   // next layer's ln_self (used when wqkv != null)
+  const float* ln_g;   // next layer's ln_self (used when wqkvf or xn_out is set)
   const float* ln_b;
+  float* xn_out;       // [M][256] LayerNorm(x_out; ln_g, ln_b) rows, or null (the fused last-row block consumes these)
   const float* wqkvf;  // next layer's self projections, fragment-major chunks (null: skip)
   float* qkv;          // [M][256 * n_qkv_chunks]
   const float* wkvxf;  // next layer's cross K,V projections, 2 fragment-major chunks (null: skip)
@@ -52,7 +53,18 @@ struct ConvTailArgs {
   int P1, ncpc;
 };
 
+struct LastBlockArgs {
+  const float* x;      // [B*2][T][256] raw input rows of the last layer (residual of row n-1; cross-attention keys / values)
+  const float* xn;     // [B*2][T][256] LN_self(last layer)(x) of every row (emitted by the previous layer's FFN block)
+  const int* bn;       // [B] valid rows
+  const float* wf;     // "L3.last16": Wq, Wk^T (per head), Wv, Wproj, Wq_x, Wk_x^T, Wv_x, Wproj_x, W0 x3, W3 x3; 16x16x4 fragment-major
+  const float *ln_src_g, *ln_src_b, *ln_ffn_g, *ln_ffn_b;
+  float* out;          // [B*2][256] layer output at the newest row
+  int B, T;
+};
+
 bool conv_tail_supported(int P1, int ncpc);
+hipError_t launch_last_block(const LastBlockArgs& a, hipStream_t st);
 hipError_t launch_conv_tail(const ConvTailArgs& a, int B, hipStream_t st);
 hipError_t launch_attn_block(const AttnBlockArgs& a, int B, hipStream_t st);   // T <= 64 only
 hipError_t launch_ffn_block(const FfnArgs& a, hipStream_t st);

@@ -193,8 +193,8 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
       store_global(acc, g.kvx, 512, nc * 256);
     }
   }
-  // ---- next layer's self Q,K,V from LayerNorm(x) ----
-  if (nq) {
+  // ---- next layer's self Q,K,V from LayerNorm(x) (or just the normalised rows) ----
+  if (nq || g.xn_out) {
     float s[MT][16], mean[MT][16];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -236,8 +236,14 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
         int lr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         float var = (red[lr] + red[BM + lr] + red[2 * BM + lr] + red[3 * BM + lr]) * (1.0f / 256.0f);
         float rstd = rsqrtf(var + 1e-5f);
-        sH[lr * LDH + ccol] = (out[mt][0][r] - mean[mt][r]) * rstd * g0 + b0;
-        sH[lr * LDH + ccol + 32] = (out[mt][1][r] - mean[mt][r]) * rstd * g1 + b1;
+        const float y0 = (out[mt][0][r] - mean[mt][r]) * rstd * g0 + b0;
+        const float y1 = (out[mt][1][r] - mean[mt][r]) * rstd * g1 + b1;
+        sH[lr * LDH + ccol] = y0;
+        sH[lr * LDH + ccol + 32] = y1;
+        if (g.xn_out && m0 + lr < g.M) {
+          g.xn_out[(long)(m0 + lr) * 256 + ccol] = y0;
+          g.xn_out[(long)(m0 + lr) * 256 + ccol + 32] = y1;
+        }
       }
     __syncthreads();
     for (int nc = 0; nc < nq; ++nc) {

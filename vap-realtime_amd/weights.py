@@ -247,6 +247,10 @@ def blob_entries(K: int, mode: str) -> List[Tuple[str, int]]:
             e.append((f"{p}.wkvxf", 2 * DIM * DIM))  # 2 column chunks [Wk_x;Wv_x]
             e.append((f"{p}.wqxf", DIM * DIM))
             e.append((f"{p}.wprojxf", DIM * DIM))
+    # fused last-row block (csrc/last_block.hip): fourteen 256x256 units of layer 3, 16x16x4-MFMA fragment-major
+    # [unit][8 w][16 kc][2 ns][64 lane][4]: Wq, Wk^T per head, Wv, Wproj, Wq_x, Wk_x^T per head, Wv_x, Wproj_x,
+    # W0 column chunks 0-2, W3 k-chunks 0-2
+    e.append(("L3.last16", 14 * DIM * DIM))
     e.append(("comb.wa", DIM * DIM)); e.append(("comb.wb", DIM * DIM))      # [N][K] (GEMM path)
     e.append(("comb.waT", DIM * DIM)); e.append(("comb.wbT", DIM * DIM))    # [K][N] (head kernel)
     e.append(("comb.g", DIM)); e.append(("comb.b", DIM))
@@ -272,6 +276,21 @@ def frag_pack(W: np.ndarray, n0: int, k0: int) -> np.ndarray:
     [4 wave][32 kc][2 ns][64 lane][4 u] with value = W[n0 + 64w + 32ns + (lane&31)][k0 + 8kc + 4(lane>>5) + u]."""
     sub = np.ascontiguousarray(W[n0:n0 + 256, k0:k0 + 256], dtype=np.float32)
     return sub.reshape(4, 2, 32, 32, 2, 4).transpose(0, 3, 1, 4, 2, 5).reshape(-1)
+
+
+def frag_pack16(W: np.ndarray) -> np.ndarray:
+    """256x256 block [out][in] -> v_mfma_f32_16x16x4_f32 B fragments for 8 waves x 32 output columns:
+    out = w*32 + ns*16 + l15, in = kc*16 + kq*4 + u  ->  [w][kc][ns][lane = kq*16 + l15][u]."""
+    assert W.shape == (256, 256)
+    return np.ascontiguousarray(W.reshape(8, 2, 16, 16, 4, 4).transpose(0, 3, 1, 4, 2, 5)).reshape(-1)
+
+
+def frag_pack16_keyT(Wk: np.ndarray) -> np.ndarray:
+    """Key projection [256 out = (head, d)][256 in] as the B operand of  qk_h = Wk_h^T q_h  (output = input index of
+    Wk, contraction over the 64 features d of head h; k-chunk 4h + kc4 of the unit):
+    value[w][h][kc4][ns][kq][l15][u] = Wk[h*64 + kc4*16 + kq*4 + u][w*32 + ns*16 + l15]."""
+    assert Wk.shape == (256, 256)
+    return np.ascontiguousarray(Wk.reshape(4, 4, 4, 4, 8, 2, 16).transpose(4, 0, 1, 5, 2, 6, 3)).reshape(-1)
 
 
 def pack_blob(cpc_sd: Dict[str, np.ndarray], vap_sd: Dict[str, np.ndarray], mode: str = "vap") -> np.ndarray:
@@ -352,6 +371,15 @@ def pack_blob(cpc_sd: Dict[str, np.ndarray], vap_sd: Dict[str, np.ndarray], mode
             put(f"{p}.wkvxf", np.concatenate([frag_pack(wkvx, c * 256, 0) for c in range(2)]))
             put(f"{p}.wqxf", frag_pack(A(vap_sd[f"{src}.mha_cross.query.weight"]), 0, 0))
             put(f"{p}.wprojxf", frag_pack(A(vap_sd[f"{src}.mha_cross.proj.weight"]), 0, 0))
+    s3 = "ar.layers.2"
+    w0_3, w3_3 = A(vap_sd[f"{s3}.ffnetwork.0.weight"]), A(vap_sd[f"{s3}.ffnetwork.3.weight"])
+    put("L3.last16", np.concatenate(
+        [frag_pack16(A(vap_sd[f"{s3}.mha.query.weight"])), frag_pack16_keyT(A(vap_sd[f"{s3}.mha.key.weight"])),
+         frag_pack16(A(vap_sd[f"{s3}.mha.value.weight"])), frag_pack16(A(vap_sd[f"{s3}.mha.proj.weight"])),
+         frag_pack16(A(vap_sd[f"{s3}.mha_cross.query.weight"])), frag_pack16_keyT(A(vap_sd[f"{s3}.mha_cross.key.weight"])),
+         frag_pack16(A(vap_sd[f"{s3}.mha_cross.value.weight"])), frag_pack16(A(vap_sd[f"{s3}.mha_cross.proj.weight"]))]
+        + [frag_pack16(w0_3[c * 256:(c + 1) * 256]) for c in range(3)]
+        + [frag_pack16(w3_3[:, c * 256:(c + 1) * 256]) for c in range(3)]))
     put("comb.wa", A(vap_sd["ar.combinator.h0_a.weight"]))
     put("comb.wb", A(vap_sd["ar.combinator.h0_b.weight"]))
     put("comb.waT", A(vap_sd["ar.combinator.h0_a.weight"]).T)
