@@ -290,7 +290,12 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
   auto prow = [&](int i) { int r = i + rot; return r >= T ? r - T : r; };
   const float* vp = a.v + slab_kv * T * a.ldkv + h * 64;
   const float* kp = a.k + slab_kv * T * a.ldkv + h * 64;
-  {  // this head's V tile -> LDS: all 16 loads in flight first (rows >= n clamp to a valid row, then zeroed)
+  const bool two = n > 32;                  // second query/key tile holds valid rows
+  // All global loads of the first query tile are issued before anything waits: this head's V tile (-> LDS), the
+  // K fragments (A operand of S^T = K.Q^T: key row j, k-slots kc*8 + 4*hi ..+3; rows >= n are clamped, their
+  // scores are masked below) and the Q fragments of tile 0 — one memory latency instead of three.
+  f32x4 kf0[8], qf0[8];
+  {
     f32x4 vv[16];
     const int q4 = (lane & 15) * 4, jb = lane >> 4;
 #pragma unroll
@@ -299,21 +304,21 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
       int jc = j < n ? j : n - 1;
       vv[u] = *(const f32x4*)(vp + (long)prow(jc) * a.ldkv + q4);
     }
+    {
+      int j0 = l31 < n ? l31 : n - 1;
+      const float* k0 = kp + (long)prow(j0) * a.ldkv + kh;
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc) kf0[kc] = *(const f32x4*)(k0 + kc * 8);
+      const float* qp = a.q + (slab_q * T + prow(j0)) * a.ldq + h * 64 + kh;
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc) qf0[kc] = *(const f32x4*)(qp + kc * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);      // keep the K / Q loads above the LDS stores that wait for V
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       int j = u * 4 + jb;
       *(f32x4*)&Vs[j * KV_LD2 + q4] = j < n ? vv[u] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-  }
-  const bool two = n > 32;                  // second query/key tile holds valid rows
-  // K fragments (A operand of S^T = K.Q^T): key row j, k-slots kc*8 + 4*hi ..+3; rows >= n are
-  // clamped (their scores are masked below)
-  f32x4 kf0[8];
-  {
-    int j0 = l31 < n ? l31 : n - 1;
-    const float* k0 = kp + (long)prow(j0) * a.ldkv + kh;
-#pragma unroll
-    for (int kc = 0; kc < 8; ++kc) kf0[kc] = *(const f32x4*)(k0 + kc * 8);
   }
   const float slope = exp2f(-2.0f * (float)(h + 1));
 
@@ -321,10 +326,15 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
   auto qtile = [&](int it, bool use_j1, f32x16& o0, f32x16& o1) {
     const int i = it * 32 + l31;
     const int iq = i < n ? i : n - 1;
-    const float* qp = a.q + (slab_q * T + prow(iq)) * a.ldq + h * 64 + kh;
     f32x4 qf[8];
+    if (it == 0) {
 #pragma unroll
-    for (int kc = 0; kc < 8; ++kc) qf[kc] = *(const f32x4*)(qp + kc * 8) * 0.0625f;
+      for (int kc = 0; kc < 8; ++kc) qf[kc] = qf0[kc] * 0.0625f;
+    } else {
+      const float* qp = a.q + (slab_q * T + prow(iq)) * a.ldq + h * 64 + kh;
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc) qf[kc] = *(const f32x4*)(qp + kc * 8) * 0.0625f;
+    }
     f32x16 s0, s1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
@@ -391,6 +401,15 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
 #pragma unroll
   for (int r = 0; r < 16; ++r) { ob0[r] = 0.f; ob1[r] = 0.f; }
   if (two) qtile(1, true, ob0, ob1);
+  // projection weights: start the ring fill now, it flies under the barrier and the sAtt stores
+  const int w = h;
+  f32x4 ring[16];
+  auto wbase = [&](const float* wfrag) { return (const f32x4*)wfrag + (long)w * 32 * 2 * 64; };   // wave-uniform
+  {
+    const f32x4* wf = wbase(a.wprojf);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ring[i] = wf[i * 64 + lane];
+  }
   __syncthreads();             // every head is done with its V tile: the bytes become sAtt
   // O^T accumulator r <-> feature d = dt*32 + (r&3) + 8*(r>>2) + 4*hi, query i = it*32 + l31
 #pragma unroll
@@ -403,14 +422,6 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
   __syncthreads();
 
   // ---- projection(s): [64 x 256] (LDS) . W^T, wave h owns columns 64h..64h+63 ----
-  const int w = h;
-  f32x4 ring[16];
-  auto wbase = [&](const float* wfrag) { return (const f32x4*)wfrag + (long)w * 32 * 2 * 64; };   // wave-uniform
-  auto fetch = [&](const float* wfrag) {
-    const f32x4* wf = wbase(wfrag);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) ring[i] = wf[i * 64 + lane];
-  };
   auto mm = [&](f32x16(&acc)[4], const float* wfrag, const float* next_wfrag) {
     const float* pa = sAtt + l31 * 260 + kh;
     const f32x4* wf = wbase(wfrag);
@@ -453,7 +464,6 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  fetch(a.wprojf);
   mm(acc, a.wprojf, a.wqxf);
   // residual: all 64 loads of a lane are issued back to back (the weight ring is dead here, so the
   // registers are free) and then added — one memory latency instead of one per 8 rows
