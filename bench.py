@@ -232,6 +232,26 @@ def main():
         "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1])},
     }
 
+    if rank == 0 and world == 1 and not args.no_latency and not followers and args.groups <= 1:
+        # the same workload with the tick split into two overlap groups that free-run across ticks (VAPX_DEFER_JOIN):
+        # reported next to `value`, not as `value`, because co-running kernels stretch each other's launch time and the
+        # per-kernel roofline above would stop meaning anything
+        eng_g = engine.Engine(W.pack_blob(cpc, vap, modes[0]), hz, args.ctx_sec, max_streams=S, device_id=local_rank,
+                              groups=2, mode=modes[0])
+        for i in range(T + 5):
+            eng_g.step_device(S, d_audio[i % NF].data_ptr(), hop, d_out.data_ptr(), stream=stream, defer_join=True)
+        eng_g.join(stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            eng_g.step_device(S, d_audio[i % NF].data_ptr(), hop, d_out.data_ptr(), stream=stream, defer_join=True)
+        eng_g.join(stream)
+        torch.cuda.synchronize()
+        dtg = time.perf_counter() - t1
+        result["overlap_groups"] = {"groups": 2, "defer_join": True, "value": S * args.steps / dtg, "unit": "frames/s",
+                                    "ms_per_step": dtg / args.steps * 1e3}
+        eng_g.close()
+
     if rank == 0 and not args.no_latency and not followers:
         # host-inclusive tick latency: host audio -> results on host (H2D + kernels + D2H + sync)
         lat = []
