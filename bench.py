@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--mode", default="vap", choices=["vap", "bc", "nod", "bc+nod", "vap+bc+nod"],
                     help="model variant (config 5: bc / nod); a+b = weight sets served on one shared CPC trunk "
                          "(one stream-frame = one audio frame through the shared encoder and every listed model)")
+    ap.add_argument("--split-f16", action="store_true",
+                    help="opt-in: FFN-block contractions as fp32-accurate 3-term f16 split products (VAPX_FLAG_SPLIT_F16)")
     ap.add_argument("--defer-join", action="store_true", help="with --groups > 1: let overlap groups free-run across ticks")
     ap.add_argument("--subtick-streams", type=int, default=1024,
                     help="sub-tick size for the <=10 ms latency leg (0 = skip)")
@@ -117,7 +119,7 @@ def main():
     modes = args.mode.split("+")
     cpc, vap = W.synthetic_weights(0, hz, modes[0])
     eng = engine.Engine(W.pack_blob(cpc, vap, modes[0]), hz, args.ctx_sec, max_streams=S, device_id=local_rank,
-                        groups=args.groups, mode=modes[0])
+                        groups=args.groups, mode=modes[0], split_f16=args.split_f16)
     followers = []
     for k, m in enumerate(modes[1:]):                            # same cpc_model "file", own VAP state dict
         f = engine.Engine(W.pack_blob(cpc, W.synthetic_weights(1 + k, hz, m)[1], m), hz, args.ctx_sec, max_streams=S,
@@ -221,7 +223,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic (seeded two-speaker dialogue audio, seeded random weights)",
         "config": {"workload": f"{S} concurrent synthetic stereo streams per GPU, {args.ctx_sec} s / {hz} Hz (T={T}), 1 MI355X per rank",
-                   "streams_per_gpu": S, "frame_hz": hz, "ctx_frames": T, "mode": args.mode, "parallelism": f"stream-sharded x{world}, no collective"},
+                   "streams_per_gpu": S, "frame_hz": hz, "ctx_frames": T, "mode": args.mode, "gemm_arithmetic": ("fp32 MFMA; FFN block: f16x3 split products, fp32 accumulate" if args.split_f16 else "fp32 MFMA"), "parallelism": f"stream-sharded x{world}, no collective"},
         "realtime_streams_sustained": value / hz,
         "step_tflops": value * gflop_sf / 1e3,
         "step_frac_of_fp32_mfma_peak": value * gflop_sf / 1e3 / (FP32_MFMA_PEAK_TF * world),

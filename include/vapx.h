@@ -62,6 +62,8 @@ extern "C" {
 #define VAPX_FLAG_GROUPS_MASK 0xF     /* bits 0-3: intra-tick overlap groups (0 = default 1 = none, max 8) */
 #define VAPX_FLAG_MATERIALIZE_X0 64   /* copy the context window chronologically each tick ("x0" peekable); default for T <= 64:
                                          layer 0 reads the rings in place */
+#define VAPX_FLAG_SPLIT_F16 512        /* opt-in: the FFN block's contractions as fp32-accurate 3-term split products on the f16
+                                         matrix cores (x = hi + lo; hi.hi + lo.hi + hi.lo, fp32 accumulate); default: fp32 MFMA */
 #define VAPX_FLAG_UNFUSED_LAST_ROW 256 /* last layer's newest-row path as ten launches (gathers, M = 2B GEMMs, single-query
                                          attention) instead of the fused last_block_kernel; kept for A/B parity tests */
 #define VAPX_FLAG_UNFUSED_CONV 32     /* conv2-4 as three GEMM launches (materialises "h2","h3" for vapx_peek) */

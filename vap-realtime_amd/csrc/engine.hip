@@ -26,6 +26,7 @@ struct Layer {
   const float *ln_src_g, *ln_src_b, *wq_x, *wkv_x, *wproj_x;
   const float *ln_ffn_g, *ln_ffn_b, *w0, *w3;
   const float *w0f, *w3f, *wqkvf, *wkvxf, *wprojf, *wqxf, *wprojxf;   // fragment-major copies (fused blocks)
+  const float *w0h, *w3h, *wqkvh, *wkvxh;                             // split-precision (f16 hi/lo) fragment copies
 };
 
 }  // namespace
@@ -316,23 +317,28 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
       }
     }
     // feed-forward (+ next layer's projections)
+    const bool split = (h->cfg.flags & VAPX_FLAG_SPLIT_F16) != 0;   // fp32-accurate products on the f16 matrix cores
     FfnArgs fa;
     memset(&fa, 0, sizeof fa);
-    fa.xmid = sc.xmid; fa.lnf_g = Lw.ln_ffn_g; fa.lnf_b = Lw.ln_ffn_b; fa.w0f = Lw.w0f; fa.w3f = Lw.w3f; fa.xout = xout; fa.M = M;
+    fa.xmid = sc.xmid; fa.lnf_g = Lw.ln_ffn_g; fa.lnf_b = Lw.ln_ffn_b; fa.xout = xout; fa.M = M;
+    fa.w0f = split ? Lw.w0h : Lw.w0f; fa.w3f = split ? Lw.w3h : Lw.w3f;
     fa.tile_rows = h->ffn_tile_rows ? h->ffn_tile_rows : 32;
     if (l + 1 < l_end) {
       const Layer& Ln = h->layer[l + 1];
-      fa.ln_g = Ln.ln_self_g; fa.ln_b = Ln.ln_self_b; fa.wqkvf = Ln.wqkvf; fa.qkv = sc.qkv; fa.n_qkv_chunks = 3;
-      fa.wkvxf = Ln.wkvxf; fa.kvx = sc.kvx;
+      const float* nqkv = split ? Ln.wqkvh : Ln.wqkvf;
+      fa.ln_g = Ln.ln_self_g; fa.ln_b = Ln.ln_self_b; fa.wqkvf = nqkv; fa.qkv = sc.qkv; fa.n_qkv_chunks = 3;
+      fa.wkvxf = split ? Ln.wkvxh : Ln.wkvxf; fa.kvx = sc.kvx;
       if (prune_last && l + 1 == 3) {
         if (h->cfg.flags & VAPX_FLAG_UNFUSED_LAST_ROW) {   // the pruned layer needs K,V of every row but Q of one row only
-          fa.wqkvf = Ln.wqkvf + 65536; fa.n_qkv_chunks = 2;
+          fa.wqkvf = nqkv + 65536; fa.n_qkv_chunks = 2;
         } else {   // fused last-row block: K / V projections are absorbed into the single query (csrc/last_block.hip);
                    // it only needs LN_self(x) of every row next to the raw rows
           fa.wqkvf = nullptr; fa.n_qkv_chunks = 0; fa.wkvxf = nullptr; fa.xn_out = sc.xn;
         }
       }
     }
+    if (split) { ProfScope ps(h, CLS_FFN, st); HIPCHK(h, launch_ffn_block_f16x3(fa, st)); }
+    else
     { ProfScope ps(h, CLS_FFN, st); HIPCHK(h, launch_ffn_block(fa, st)); }
   }
   if (prune_last) {
@@ -604,6 +610,7 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
     Lw.wproj_x = get("wproj_x"); Lw.ln_ffn_g = get("ln_ffn.g"); Lw.ln_ffn_b = get("ln_ffn.b"); Lw.w0 = get("w0"); Lw.w3 = get("w3");
     Lw.w0f = get("w0f"); Lw.w3f = get("w3f"); Lw.wqkvf = get("wqkvf"); Lw.wkvxf = get("wkvxf");
     Lw.wprojf = get("wprojf"); Lw.wqxf = get("wqxf"); Lw.wprojxf = get("wprojxf");
+    Lw.w0h = get("w0h"); Lw.w3h = get("w3h"); Lw.wqkvh = get("wqkvh"); Lw.wkvxh = get("wkvxh");
   }
   const size_t S = cfg->max_streams, B = cfg->max_batch, T = h->T;
   const int* P = h->P;

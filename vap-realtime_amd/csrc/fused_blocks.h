@@ -68,3 +68,4 @@ hipError_t launch_last_block(const LastBlockArgs& a, hipStream_t st);
 hipError_t launch_conv_tail(const ConvTailArgs& a, int B, hipStream_t st);
 hipError_t launch_attn_block(const AttnBlockArgs& a, int B, hipStream_t st);   // T <= 64 only
 hipError_t launch_ffn_block(const FfnArgs& a, hipStream_t st);
+hipError_t launch_ffn_block_f16x3(const FfnArgs& a, hipStream_t st);   // w0f/w3f/wqkvf/wkvxf point to the *h (f16 hi/lo) copies
