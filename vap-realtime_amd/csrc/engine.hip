@@ -178,6 +178,11 @@ struct ProfScope {
 
 hipError_t gemm(vapx_engine* h, const GemmArgs& g, int epi, hipStream_t st) {
   ProfScope ps(h, epi, st);
+  if (h->cfg.flags & VAPX_FLAG_SPLIT_F16) {
+    GemmArgs gs = g;
+    gs.split = 1;
+    return launch_gemm_f32(gs, epi, 0, st);
+  }
   return launch_gemm_f32(g, epi, 0, st);
 }
 

@@ -25,6 +25,7 @@ struct GemmArgs {
   RowMap rm;
   float* C2;
   RowMap c2m;
+  int split;   // 1: fp32-accurate 3-term split products on the f16 matrix cores (operands split while staged), see gemm_f32.hip
 };
 
 // tile_rows: 0 = choose from M, else 32 / 64 / 128 rows per workgroup.

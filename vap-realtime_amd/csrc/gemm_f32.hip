@@ -22,15 +22,26 @@
 namespace {
 
 constexpr int LDT = 36;  // LDS row stride in floats (32 + 4 pad)
+// SPLIT variant (opt-in, GemmArgs::split): both operands are split into f16 (hi, lo) pairs while they are staged
+// (x = hi + lo; weights as 2^8 w so that lo stays a normal f16, undone exactly in the epilogue) and every 16-wide
+// k-chunk becomes three v_mfma_f32_32x32x16_f16: hi.hi + lo.hi + hi.lo, fp32 accumulate — fp32-accurate (dropped
+// term 2^-22 relative), 3/16 of the MFMA time.  Tiles are [rows][32 k] halves with a 40-half (80 B) row stride.
+constexpr int LDT16 = 40;
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-template <int WM, int WN, int EPI>
+template <int WM, int WN, int EPI, bool SPLIT = false>
 __global__ __launch_bounds__(256, (WM == 4 ? 2 : 2)) void gemm_f32_kernel(const GemmArgs g) {
   constexpr int BM = 32 * WM;
   constexpr int NS = 8 / WN;    // 32-column sub-tiles per wave
   constexpr int NW = 256 / WN;  // columns per wave
-  __shared__ __attribute__((aligned(16))) float lds[(BM + 256) * LDT];
+  __shared__ __attribute__((aligned(16))) float lds[(BM + 256) * (SPLIT ? LDT16 : LDT)];
   float* sA = lds;
   float* sB = lds + BM * LDT;
+  _Float16* sAh = (_Float16*)lds;             // SPLIT: hi / lo tiles of A, then of W
+  _Float16* sAl = sAh + BM * LDT16;
+  _Float16* sBh = sAl + BM * LDT16;
+  _Float16* sBl = sBh + 256 * LDT16;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -58,10 +69,28 @@ __global__ __launch_bounds__(256, (WM == 4 ? 2 : 2)) void gemm_f32_kernel(const 
     for (int i = 0; i < 8; ++i) rb[i] = *(const f32x4*)(bptr + i * bstep + k0);
   };
   auto sstore = [&]() {
+    if constexpr (SPLIT) {
 #pragma unroll
-    for (int i = 0; i < WM; ++i) *(f32x4*)&sA[(i * 32 + srow) * LDT + skq] = ra[i];
+      for (int i = 0; i < WM; ++i) {
+        const f16x4 hi = __builtin_convertvector(ra[i], f16x4);
+        const f16x4 lo = __builtin_convertvector(ra[i] - __builtin_convertvector(hi, f32x4), f16x4);
+        *(f16x4*)&sAh[(i * 32 + srow) * LDT16 + skq] = hi;
+        *(f16x4*)&sAl[(i * 32 + srow) * LDT16 + skq] = lo;
+      }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *(f32x4*)&sB[(i * 32 + srow) * LDT + skq] = rb[i];
+      for (int i = 0; i < 8; ++i) {
+        const f32x4 wv = rb[i] * 256.0f;
+        const f16x4 hi = __builtin_convertvector(wv, f16x4);
+        const f16x4 lo = __builtin_convertvector(wv - __builtin_convertvector(hi, f32x4), f16x4);
+        *(f16x4*)&sBh[(i * 32 + srow) * LDT16 + skq] = hi;
+        *(f16x4*)&sBl[(i * 32 + srow) * LDT16 + skq] = lo;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < WM; ++i) *(f32x4*)&sA[(i * 32 + srow) * LDT + skq] = ra[i];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *(f32x4*)&sB[(i * 32 + srow) * LDT + skq] = rb[i];
+    }
   };
 
   f32x16 acc[NS];
@@ -78,8 +107,31 @@ __global__ __launch_bounds__(256, (WM == 4 ? 2 : 2)) void gemm_f32_kernel(const 
   gload(0);
   sstore();
   __syncthreads();
+  const int k8 = (lane >> 5) * 8;
+  const _Float16* pah = &sAh[(wm * 32 + l31) * LDT16 + k8];
+  const _Float16* pal = &sAl[(wm * 32 + l31) * LDT16 + k8];
+  const _Float16* pbh = &sBh[(wn * NW + l31) * LDT16 + k8];
+  const _Float16* pbl = &sBl[(wn * NW + l31) * LDT16 + k8];
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) gload((kt + 1) << 5);
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const f16x8 ah = *(const f16x8*)(pah + ks * 16), al = *(const f16x8*)(pal + ks * 16);
+        f16x8 bh[NS], bl[NS];
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) {
+          bh[ns] = *(const f16x8*)(pbh + ns * 32 * LDT16 + ks * 16);
+          bl[ns] = *(const f16x8*)(pbl + ns * 32 * LDT16 + ks * 16);
+        }
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) acc[ns] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ns], acc[ns], 0, 0, 0);
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) acc[ns] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ns], acc[ns], 0, 0, 0);
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) acc[ns] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ns], acc[ns], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) {
       f32x4 a = *(const f32x4*)(pa + kc * 8);
@@ -92,6 +144,7 @@ __global__ __launch_bounds__(256, (WM == 4 ? 2 : 2)) void gemm_f32_kernel(const 
         for (int ns = 0; ns < NS; ++ns)
           acc[ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[ns][s], acc[ns], 0, 0, 0);
     }
+    }
     __syncthreads();
     if (kt + 1 < nk) {
       sstore();
@@ -100,6 +153,12 @@ __global__ __launch_bounds__(256, (WM == 4 ? 2 : 2)) void gemm_f32_kernel(const 
   }
 
   // ---- epilogue ----
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ns][r] *= (1.0f / 256.0f);
+  }
   // accumulator element (ns, r): row lr = (r&3) + 8*(r>>2) + 4*(lane>>5), col = ns*32 + (lane&31)
   const int cbase = n0 + wn * NW + l31;
   const int rbase = m0 + wm * 32 + 4 * (lane >> 5);
@@ -216,17 +275,17 @@ __global__ __launch_bounds__(256, (WM == 4 ? 2 : 2)) void gemm_f32_kernel(const 
   }
 }
 
-template <int WM, int WN>
+template <int WM, int WN, bool SPLIT>
 hipError_t launch_wm(const GemmArgs& g, int epi, hipStream_t st) {
   constexpr int BM = 32 * WM;
   dim3 grid(((g.M + BM - 1) / BM) * (g.N >> 8)), block(256);
   switch (epi) {
-    case EPI_STORE: hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, EPI_STORE>), grid, block, 0, st, g); break;
-    case EPI_GELU: hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, EPI_GELU>), grid, block, 0, st, g); break;
-    case EPI_RESID: hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, EPI_RESID>), grid, block, 0, st, g); break;
-    case EPI_RESID_LN: hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, EPI_RESID_LN>), grid, block, 0, st, g); break;
-    case EPI_CN_RELU: hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, EPI_CN_RELU>), grid, block, 0, st, g); break;
-    case EPI_BIAS_LN_GELU: hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, EPI_BIAS_LN_GELU>), grid, block, 0, st, g); break;
+    case EPI_STORE: hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, EPI_STORE, SPLIT>), grid, block, 0, st, g); break;
+    case EPI_GELU: hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, EPI_GELU, SPLIT>), grid, block, 0, st, g); break;
+    case EPI_RESID: hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, EPI_RESID, SPLIT>), grid, block, 0, st, g); break;
+    case EPI_RESID_LN: hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, EPI_RESID_LN, SPLIT>), grid, block, 0, st, g); break;
+    case EPI_CN_RELU: hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, EPI_CN_RELU, SPLIT>), grid, block, 0, st, g); break;
+    case EPI_BIAS_LN_GELU: hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, EPI_BIAS_LN_GELU, SPLIT>), grid, block, 0, st, g); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -247,10 +306,18 @@ hipError_t launch_gemm_f32(const GemmArgs& g, int epi, int tile_rows, hipStream_
     else if (g.K >= 2048 && g.M >= 200000) tile_rows = 128;
     else tile_rows = 64;
   }
+  if (g.split) {
+    switch (tile_rows) {
+      case 128: return launch_wm<4, 1, true>(g, epi, stream);
+      case 64: return launch_wm<2, 2, true>(g, epi, stream);
+      case 32: return launch_wm<1, 4, true>(g, epi, stream);
+      default: return hipErrorInvalidValue;
+    }
+  }
   switch (tile_rows) {
-    case 128: return launch_wm<4, 1>(g, epi, stream);
-    case 64: return launch_wm<2, 2>(g, epi, stream);
-    case 32: return launch_wm<1, 4>(g, epi, stream);
+    case 128: return launch_wm<4, 1, false>(g, epi, stream);
+    case 64: return launch_wm<2, 2, false>(g, epi, stream);
+    case 32: return launch_wm<1, 4, false>(g, epi, stream);
     default: return hipErrorInvalidValue;
   }
 }
