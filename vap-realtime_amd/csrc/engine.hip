@@ -26,7 +26,7 @@ struct Layer {
   const float *ln_src_g, *ln_src_b, *wq_x, *wkv_x, *wproj_x;
   const float *ln_ffn_g, *ln_ffn_b, *w0, *w3;
   const float *w0f, *w3f, *wqkvf, *wkvxf, *wprojf, *wqxf, *wprojxf;   // fragment-major copies (fused blocks)
-  const float *w0h, *w3h, *wqkvh, *wkvxh;                             // split-precision (f16 hi/lo) fragment copies
+  const float *w0h, *w3h, *wqkvh, *wkvxh, *wprojh, *wqxh, *wprojxh;                             // split-precision (f16 hi/lo) fragment copies
 };
 
 }  // namespace
@@ -287,17 +287,19 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
       AttnBlockArgs ab;
       memset(&ab, 0, sizeof ab);
       ab.q = sc.qkv; ab.k = sc.qkv + 256; ab.v = sc.qkv + 512; ab.ldq = 768; ab.ldkv = 768; ab.swap_kv = 0;
-      ab.bn = sc.bn; ab.T = T; ab.wprojf = Lw.wprojf; ab.resid = xin; ab.xmid = sc.xmid; ab.xn = nullptr;
+      const bool asplit = (h->cfg.flags & VAPX_FLAG_SPLIT_F16) != 0;
+      ab.split = asplit ? 1 : 0;
+      ab.bn = sc.bn; ab.T = T; ab.wprojf = asplit ? Lw.wprojh : Lw.wprojf; ab.resid = xin; ab.xmid = sc.xmid; ab.xn = nullptr;
       if (l == 0 && rv && rv->ring) {   // Q|K|V and the residual straight from the per-stream rings
         ab.q = rv->ring_qkv; ab.k = rv->ring_qkv + 256; ab.v = rv->ring_qkv + 512; ab.resid = rv->ring;
         ab.ring_rot = sc.rot; ab.ids = rv->ids;
       }
       if (l == 0) { ab.ln_g = Lw.ln_ffn_g; ab.ln_b = Lw.ln_ffn_b; }
-      else { ab.ln_g = Lw.ln_src_g; ab.ln_b = Lw.ln_src_b; ab.wqxf = Lw.wqxf; ab.qx = sc.qx; ab.xn = nullptr; }
+      else { ab.ln_g = Lw.ln_src_g; ab.ln_b = Lw.ln_src_b; ab.wqxf = asplit ? Lw.wqxh : Lw.wqxf; ab.qx = sc.qx; ab.xn = nullptr; }
       { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attn_block(ab, B, st)); }
       if (l > 0) {
         ab.q = sc.qx; ab.k = sc.kvx; ab.v = sc.kvx + 256; ab.ldq = 256; ab.ldkv = 512; ab.swap_kv = 1;
-        ab.wprojf = Lw.wprojxf; ab.resid = sc.xmid; ab.ln_g = Lw.ln_ffn_g; ab.ln_b = Lw.ln_ffn_b;
+        ab.wprojf = asplit ? Lw.wprojxh : Lw.wprojxf; ab.resid = sc.xmid; ab.ln_g = Lw.ln_ffn_g; ab.ln_b = Lw.ln_ffn_b;
         ab.wqxf = nullptr; ab.qx = nullptr; ab.xn = nullptr; ab.ring_rot = nullptr; ab.ids = nullptr;
         { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attn_block(ab, B, st)); }
       }
@@ -616,6 +618,7 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
     Lw.w0f = get("w0f"); Lw.w3f = get("w3f"); Lw.wqkvf = get("wqkvf"); Lw.wkvxf = get("wkvxf");
     Lw.wprojf = get("wprojf"); Lw.wqxf = get("wqxf"); Lw.wprojxf = get("wprojxf");
     Lw.w0h = get("w0h"); Lw.w3h = get("w3h"); Lw.wqkvh = get("wqkvh"); Lw.wkvxh = get("wkvxh");
+    Lw.wprojh = get("wprojh"); Lw.wqxh = get("wqxh"); Lw.wprojxh = get("wprojxh");
   }
   const size_t S = cfg->max_streams, B = cfg->max_batch, T = h->T;
   const int* P = h->P;

@@ -39,6 +39,7 @@ struct AttnBlockArgs {
                         // row i in ring slot (i + ring_rot[b]) % T) instead of chronological batch buffers
   const int* ids;       // [B] stream slots (null: identity); only used with ring_rot
   int T, ldq, ldkv, swap_kv;
+  int split;            // 1: wprojf / wqxf are f16 hi/lo fragment copies, projections run as 3-term split products
 };
 
 struct ConvTailArgs {

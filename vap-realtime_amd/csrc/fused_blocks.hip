@@ -270,9 +270,19 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
 // ------------------------------------------------------------------------------------------------
 constexpr int KV_LD2 = 68;
 
+// SPLIT (opt-in, VAPX_FLAG_SPLIT_F16): the two projections run as fp32-accurate 3-term split products on the f16 matrix
+// cores (see ffn_block_f16x3.hip): the attention output / LN rows are kept in LDS as f16 (hi, lo) pairs, the weights
+// arrive as pre-split f16 fragments (weights.frag_pack_f16x3).  The attention itself (S, softmax, P.V) stays fp32 MFMA.
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+constexpr int ALD16 = 264;   // halves per sAtt row in SPLIT mode
+
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[4 * 64 * KV_LD2 + 256];
   float* sAtt = lds;                        // [64][260] (aliases the V tiles after a barrier)
+  _Float16* sAh = (_Float16*)lds;           // SPLIT: [64][264] halves, hi then lo
+  _Float16* sAl = sAh + 64 * ALD16;
   float* red = lds + 4 * 64 * KV_LD2;       // [4][64]
   const int tid = threadIdx.x, lane = tid & 63;
   const int h = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar wave / head index (see ffn_block_kernel)
@@ -414,10 +424,27 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
   // O^T accumulator r <-> feature d = dt*32 + (r&3) + 8*(r>>2) + 4*hi, query i = it*32 + l31
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
-    *(f32x4*)&sAtt[l31 * 260 + h * 64 + rr * 8 + kh] = f32x4{oa0[rr * 4], oa0[rr * 4 + 1], oa0[rr * 4 + 2], oa0[rr * 4 + 3]};
-    *(f32x4*)&sAtt[l31 * 260 + h * 64 + 32 + rr * 8 + kh] = f32x4{oa1[rr * 4], oa1[rr * 4 + 1], oa1[rr * 4 + 2], oa1[rr * 4 + 3]};
-    *(f32x4*)&sAtt[(32 + l31) * 260 + h * 64 + rr * 8 + kh] = f32x4{ob0[rr * 4], ob0[rr * 4 + 1], ob0[rr * 4 + 2], ob0[rr * 4 + 3]};
-    *(f32x4*)&sAtt[(32 + l31) * 260 + h * 64 + 32 + rr * 8 + kh] = f32x4{ob1[rr * 4], ob1[rr * 4 + 1], ob1[rr * 4 + 2], ob1[rr * 4 + 3]};
+    const f32x4 v00 = f32x4{oa0[rr * 4], oa0[rr * 4 + 1], oa0[rr * 4 + 2], oa0[rr * 4 + 3]};
+    const f32x4 v01 = f32x4{oa1[rr * 4], oa1[rr * 4 + 1], oa1[rr * 4 + 2], oa1[rr * 4 + 3]};
+    const f32x4 v10 = f32x4{ob0[rr * 4], ob0[rr * 4 + 1], ob0[rr * 4 + 2], ob0[rr * 4 + 3]};
+    const f32x4 v11 = f32x4{ob1[rr * 4], ob1[rr * 4 + 1], ob1[rr * 4 + 2], ob1[rr * 4 + 3]};
+    if constexpr (SPLIT) {
+      auto put = [&](int row, int col, f32x4 v) {
+        const h16x4 hh = __builtin_convertvector(v, h16x4);
+        const h16x4 ll = __builtin_convertvector(v - __builtin_convertvector(hh, f32x4), h16x4);
+        *(h16x4*)&sAh[row * ALD16 + col] = hh;
+        *(h16x4*)&sAl[row * ALD16 + col] = ll;
+      };
+      put(l31, h * 64 + rr * 8 + kh, v00);
+      put(l31, h * 64 + 32 + rr * 8 + kh, v01);
+      put(32 + l31, h * 64 + rr * 8 + kh, v10);
+      put(32 + l31, h * 64 + 32 + rr * 8 + kh, v11);
+    } else {
+      *(f32x4*)&sAtt[l31 * 260 + h * 64 + rr * 8 + kh] = v00;
+      *(f32x4*)&sAtt[l31 * 260 + h * 64 + 32 + rr * 8 + kh] = v01;
+      *(f32x4*)&sAtt[(32 + l31) * 260 + h * 64 + rr * 8 + kh] = v10;
+      *(f32x4*)&sAtt[(32 + l31) * 260 + h * 64 + 32 + rr * 8 + kh] = v11;
+    }
   }
   __syncthreads();
 
@@ -426,6 +453,43 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
     const float* pa = sAtt + l31 * 260 + kh;
     const f32x4* wf = wbase(wfrag);
     const f32x4* wnext = next_wfrag ? wbase(next_wfrag) : wf;
+    if constexpr (SPLIT) {
+      // fragments [16 kc][2 ns][2 hi/lo][64 lane] x 16 B; ring slot k4 holds (ns0 hi, ns0 lo, ns1 hi, ns1 lo) of a k-chunk
+      const _Float16* pah = sAh + l31 * ALD16 + hi * 8;
+      const _Float16* pal = sAl + l31 * ALD16 + hi * 8;
+#pragma unroll 1
+      for (int blk = 0; blk < 4; ++blk) {
+        const f32x4* nx = blk < 3 ? wf + (blk + 1) * 16 * 64 : wnext;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+          const int kc = blk * 4 + k4;
+          const h16x8 a0h = *(const h16x8*)(pah + kc * 16), a0l = *(const h16x8*)(pal + kc * 16);
+          const h16x8 a1h = *(const h16x8*)(pah + 32 * ALD16 + kc * 16), a1l = *(const h16x8*)(pal + 32 * ALD16 + kc * 16);
+          const h16x8 b0h = __builtin_bit_cast(h16x8, ring[k4 * 4 + 0]), b0l = __builtin_bit_cast(h16x8, ring[k4 * 4 + 1]);
+          const h16x8 b1h = __builtin_bit_cast(h16x8, ring[k4 * 4 + 2]), b1l = __builtin_bit_cast(h16x8, ring[k4 * 4 + 3]);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b0h, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b1h, acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0h, acc[2], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1h, acc[3], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b0h, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b1h, acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b0h, acc[2], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b1h, acc[3], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b0l, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b1l, acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0l, acc[2], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1l, acc[3], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ring[k4 * 4 + i] = nx[(k4 * 4 + i) * 64 + lane];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] *= (1.0f / 256.0f);   // weights are packed as 2^8 w
+      return;
+    }
     // A fragments ping-pong between two register sets so the LDS reads of step k+1 fly under the
     // MFMAs of step k (see ffn_block_kernel)
     f32x4 p0[2], p1[2];
@@ -533,7 +597,13 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
           xo[0] = y0; xo[32] = y1;
         }
       }
-      if (a.wqxf) { sAtt[i * 260 + ccol] = y0; sAtt[i * 260 + ccol + 32] = y1; }
+      if (a.wqxf) {
+        if constexpr (SPLIT) {
+          const _Float16 h0 = (_Float16)y0, h1 = (_Float16)y1;
+          sAh[i * ALD16 + ccol] = h0; sAl[i * ALD16 + ccol] = (_Float16)(y0 - (float)h0);
+          sAh[i * ALD16 + ccol + 32] = h1; sAl[i * ALD16 + ccol + 32] = (_Float16)(y1 - (float)h1);
+        } else { sAtt[i * 260 + ccol] = y0; sAtt[i * 260 + ccol + 32] = y1; }
+      }
     }
   if (a.wqxf) {
     __syncthreads();
@@ -759,7 +829,8 @@ hipError_t launch_conv_tail(const ConvTailArgs& a, int B, hipStream_t st) {
 
 hipError_t launch_attn_block(const AttnBlockArgs& a, int B, hipStream_t st) {
   if (a.T > 64) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(attn_block_kernel, dim3(B * 2), dim3(256), 0, st, a);
+  if (a.split) hipLaunchKernelGGL(attn_block_kernel<true>, dim3(B * 2), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(attn_block_kernel<false>, dim3(B * 2), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

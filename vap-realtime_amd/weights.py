@@ -249,8 +249,9 @@ def blob_entries(K: int, mode: str) -> List[Tuple[str, int]]:
             e.append((f"{p}.wprojxf", DIM * DIM))
         # split-precision (f16 hi/lo) fragment copies for the opt-in f16x3 FFN block, same chunking as the *f entries
         e.append((f"{p}.w0h", FFN * DIM)); e.append((f"{p}.w3h", DIM * FFN)); e.append((f"{p}.wqkvh", 3 * DIM * DIM))
+        e.append((f"{p}.wprojh", DIM * DIM))
         if l > 0:
-            e.append((f"{p}.wkvxh", 2 * DIM * DIM))
+            e.append((f"{p}.wkvxh", 2 * DIM * DIM)); e.append((f"{p}.wqxh", DIM * DIM)); e.append((f"{p}.wprojxh", DIM * DIM))
     # fused last-row block (csrc/last_block.hip): fourteen 256x256 units of layer 3, 16x16x4-MFMA fragment-major
     # [unit][8 w][16 kc][2 ns][64 lane][4]: Wq, Wk^T per head, Wv, Wproj, Wq_x, Wk_x^T per head, Wv_x, Wproj_x,
     # W0 column chunks 0-2, W3 k-chunks 0-2
@@ -392,10 +393,13 @@ def pack_blob(cpc_sd: Dict[str, np.ndarray], vap_sd: Dict[str, np.ndarray], mode
         put(f"{p}.w0h", np.concatenate([frag_pack_f16x3(w0, c * 256, 0) for c in range(3)]))
         put(f"{p}.w3h", np.concatenate([frag_pack_f16x3(w3, 0, c * 256) for c in range(3)]))
         put(f"{p}.wqkvh", np.concatenate([frag_pack_f16x3(wqkv, c * 256, 0) for c in range(3)]))
+        put(f"{p}.wprojh", frag_pack_f16x3(A(vap_sd[f"{src}.mha.proj.weight"]), 0, 0))
         if l > 0:
             wkvx = np.concatenate([A(vap_sd[f"{src}.mha_cross.key.weight"]), A(vap_sd[f"{src}.mha_cross.value.weight"])], axis=0)
             put(f"{p}.wkvxf", np.concatenate([frag_pack(wkvx, c * 256, 0) for c in range(2)]))
             put(f"{p}.wkvxh", np.concatenate([frag_pack_f16x3(wkvx, c * 256, 0) for c in range(2)]))
+            put(f"{p}.wqxh", frag_pack_f16x3(A(vap_sd[f"{src}.mha_cross.query.weight"]), 0, 0))
+            put(f"{p}.wprojxh", frag_pack_f16x3(A(vap_sd[f"{src}.mha_cross.proj.weight"]), 0, 0))
             put(f"{p}.wqxf", frag_pack(A(vap_sd[f"{src}.mha_cross.query.weight"]), 0, 0))
             put(f"{p}.wprojxf", frag_pack(A(vap_sd[f"{src}.mha_cross.proj.weight"]), 0, 0))
     s3 = "ar.layers.2"
