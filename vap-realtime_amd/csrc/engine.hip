@@ -329,7 +329,7 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
     memset(&fa, 0, sizeof fa);
     fa.xmid = sc.xmid; fa.lnf_g = Lw.ln_ffn_g; fa.lnf_b = Lw.ln_ffn_b; fa.xout = xout; fa.M = M;
     fa.w0f = split ? Lw.w0h : Lw.w0f; fa.w3f = split ? Lw.w3h : Lw.w3f;
-    fa.tile_rows = h->ffn_tile_rows ? h->ffn_tile_rows : 32;
+    fa.tile_rows = h->ffn_tile_rows ? h->ffn_tile_rows : (split ? 0 : 32);
     if (l + 1 < l_end) {
       const Layer& Ln = h->layer[l + 1];
       const float* nqkv = split ? Ln.wqkvh : Ln.wqkvf;

@@ -30,9 +30,12 @@ __device__ __forceinline__ void split_store(_Float16* hi, _Float16* lo, int idx,
   lo[idx] = (_Float16)(v - (float)h);
 }
 
-__global__ __launch_bounds__(256, 2) void ffn_block_f16x3_kernel(const FfnArgs g) {
+// MT = 32-row sub-tiles per workgroup: 1 (2 workgroups / CU, default) or 2 (64 rows, 1 workgroup / CU, every weight
+// fragment feeds two row tiles)
+template <int MT>
+__global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_f16x3_kernel(const FfnArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  constexpr int BM = 32;
+  constexpr int BM = 32 * MT;
   _Float16* sXh = (_Float16*)lds_raw;     // LN_ffn(x) tile, hi / lo
   _Float16* sXl = sXh + BM * LD16;
   _Float16* sHh = sXl + BM * LD16;        // gelu chunk / raw x / LN_self(x), hi / lo
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void ffn_block_f16x3_kernel(const FfnArgs g
 #pragma unroll
     for (int i = 0; i < 16; ++i) ring[i] = wf[i * 64 + lane];
   };
-  auto mm = [&](f32x16(&acc)[2], const _Float16* Ah, const _Float16* Al, const float* wfrag, const float* next_wfrag) {
+  auto mm = [&](f32x16(&acc)[MT][2], const _Float16* Ah, const _Float16* Al, const float* wfrag, const float* next_wfrag) {
     const _Float16* pah = Ah + l31 * LD16 + hi * 8;
     const _Float16* pal = Al + l31 * LD16 + hi * 8;
     const f32x4* wf = wbase(wfrag);
@@ -88,81 +91,106 @@ __global__ __launch_bounds__(256, 2) void ffn_block_f16x3_kernel(const FfnArgs g
 #pragma unroll
       for (int k4 = 0; k4 < 4; ++k4) {
         const int kc = blk * 4 + k4;
-        const f16x8 ah = *(const f16x8*)(pah + kc * 16);
-        const f16x8 al = *(const f16x8*)(pal + kc * 16);
+        f16x8 ah[MT], al[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          ah[mt] = *(const f16x8*)(pah + mt * 32 * LD16 + kc * 16);
+          al[mt] = *(const f16x8*)(pal + mt * 32 * LD16 + kc * 16);
+        }
         const f16x8 b0h = __builtin_bit_cast(f16x8, ring[k4 * 4 + 0]), b0l = __builtin_bit_cast(f16x8, ring[k4 * 4 + 1]);
         const f16x8 b1h = __builtin_bit_cast(f16x8, ring[k4 * 4 + 2]), b1l = __builtin_bit_cast(f16x8, ring[k4 * 4 + 3]);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0h, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1h, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b0h, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b1h, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0l, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1l, acc[1], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], b0h, acc[mt][0], 0, 0, 0);
+          acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], b1h, acc[mt][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], b0h, acc[mt][0], 0, 0, 0);
+          acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], b1h, acc[mt][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], b0l, acc[mt][0], 0, 0, 0);
+          acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], b1l, acc[mt][1], 0, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) ring[k4 * 4 + i] = nx[(k4 * 4 + i) * 64 + lane];
         __builtin_amdgcn_sched_barrier(0);   // keep the refills behind their MFMAs
       }
     }
   };
-  auto zero = [](f32x16(&acc)[2]) {
+  auto zero = [](f32x16(&acc)[MT][2]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[mt][0][r] = 0.f; acc[mt][1][r] = 0.f; }
   };
-  auto scale = [](f32x16(&acc)[2]) {
+  auto scale = [](f32x16(&acc)[MT][2]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[0][r] *= kWScaleInv; acc[1][r] *= kWScaleInv; }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[mt][0][r] *= kWScaleInv; acc[mt][1][r] *= kWScaleInv; }
   };
   // accumulator (ns, r) <-> tile row lr = (r&3) + 8*(r>>2) + 4*hi, chunk column w*64 + ns*32 + l31
   const int ccol = w * 64 + l31;
-  auto store_global = [&](const f32x16(&acc)[2], float* base, int ld, int col0) {
+  auto store_global = [&](const f32x16(&acc)[MT][2], float* base, int ld, int col0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (m < g.M) {
-        float* p = base + (long)m * ld + col0 + ccol;
-        p[0] = acc[0][r];
-        p[32] = acc[1][r];
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (m < g.M) {
+          float* p = base + (long)m * ld + col0 + ccol;
+          p[0] = acc[mt][0][r];
+          p[32] = acc[mt][1][r];
+        }
       }
-    }
   };
-  auto to_sH = [&](const f32x16(&acc)[2]) {
+  auto to_sH = [&](const f32x16(&acc)[MT][2]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      split_store(sHh, sHl, lr * LD16 + ccol, acc[0][r]);
-      split_store(sHh, sHl, lr * LD16 + ccol + 32, acc[1][r]);
-    }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int lr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        split_store(sHh, sHl, lr * LD16 + ccol, acc[mt][0][r]);
+        split_store(sHh, sHl, lr * LD16 + ccol + 32, acc[mt][1][r]);
+      }
   };
 
   // ---- feed-forward: x = xmid + gelu(xn W0^T) W3^T, hidden processed in 3 chunks of 256 ----
   const int nq = g.wqkvf ? g.n_qkv_chunks : 0;
   const float* after_ffn = g.wkvxf ? g.wkvxf : (nq ? g.wqkvf : nullptr);
-  f32x16 out[2];
+  f32x16 out[MT][2];
   zero(out);
   fetch(g.w0f);
   for (int c = 0; c < 3; ++c) {
-    f32x16 hacc[2];
+    f32x16 hacc[MT][2];
     zero(hacc);
     mm(hacc, sXh, sXl, g.w0f + (long)c * 65536, g.w3f + (long)c * 65536);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      hacc[0][r] = gelu_fast(hacc[0][r] * kWScaleInv);
-      hacc[1][r] = gelu_fast(hacc[1][r] * kWScaleInv);
-      if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        hacc[mt][0][r] = gelu_fast(hacc[mt][0][r] * kWScaleInv);
+        hacc[mt][1][r] = gelu_fast(hacc[mt][1][r] * kWScaleInv);
+        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
     __syncthreads();          // every wave is done reading the previous chunk from sH
     to_sH(hacc);
     __syncthreads();
     mm(out, sHh, sHl, g.w3f + (long)c * 65536, c < 2 ? g.w0f + (long)(c + 1) * 65536 : after_ffn);
   }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-    m = m < g.M ? m : g.M - 1;
-    const float* rp = g.xmid + (long)m * 256 + ccol;
-    out[0][r] = out[0][r] * kWScaleInv + rp[0];
-    out[1][r] = out[1][r] * kWScaleInv + rp[32];
-  }
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      m = m < g.M ? m : g.M - 1;
+      const float* rp = g.xmid + (long)m * 256 + ccol;
+      out[mt][0][r] = out[mt][0][r] * kWScaleInv + rp[0];
+      out[mt][1][r] = out[mt][1][r] * kWScaleInv + rp[32];
+    }
   store_global(out, g.xout, 256, 0);
 
   // ---- next layer's cross K,V from the RAW layer output ----
@@ -171,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void ffn_block_f16x3_kernel(const FfnArgs g
     to_sH(out);
     __syncthreads();
     for (int nc = 0; nc < 2; ++nc) {
-      f32x16 acc[2];
+      f32x16 acc[MT][2];
       zero(acc);
       mm(acc, sHh, sHl, g.wkvxf + (long)nc * 65536, nc == 0 ? g.wkvxf + 65536 : (nq ? g.wqkvf : nullptr));
       scale(acc);
@@ -180,47 +208,59 @@ __global__ __launch_bounds__(256, 2) void ffn_block_f16x3_kernel(const FfnArgs g
   }
   // ---- next layer's self Q,K,V from LayerNorm(x) (or just the normalised rows) ----
   if (nq || g.xn_out) {
-    float s[16], mean[16];
+    float s[MT][16], mean[MT][16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = half_sum(out[0][r] + out[1][r]);
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[mt][r] = half_sum(out[mt][0][r] + out[mt][1][r]);
     __syncthreads();          // also: every wave is done reading sH (cross K,V)
     if (l31 == 0)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) red[w * BM + (r & 3) + 8 * (r >> 2) + 4 * hi] = s[r];
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[w * BM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = s[mt][r];
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      mean[r] = (red[lr] + red[BM + lr] + red[2 * BM + lr] + red[3 * BM + lr]) * (1.0f / 256.0f);
-    }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int lr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        mean[mt][r] = (red[lr] + red[BM + lr] + red[2 * BM + lr] + red[3 * BM + lr]) * (1.0f / 256.0f);
+      }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float d0 = out[0][r] - mean[r], d1 = out[1][r] - mean[r];
-      s[r] = half_sum(d0 * d0 + d1 * d1);
-    }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float d0 = out[mt][0][r] - mean[mt][r], d1 = out[mt][1][r] - mean[mt][r];
+        s[mt][r] = half_sum(d0 * d0 + d1 * d1);
+      }
     if (l31 == 0)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) red[w * BM + (r & 3) + 8 * (r >> 2) + 4 * hi] = s[r];
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[w * BM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = s[mt][r];
     __syncthreads();
     const float g0 = g.ln_g[ccol], g1 = g.ln_g[ccol + 32], b0 = g.ln_b[ccol], b1 = g.ln_b[ccol + 32];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      float var = (red[lr] + red[BM + lr] + red[2 * BM + lr] + red[3 * BM + lr]) * (1.0f / 256.0f);
-      float rstd = rsqrtf(var + 1e-5f);
-      const float y0 = (out[0][r] - mean[r]) * rstd * g0 + b0;
-      const float y1 = (out[1][r] - mean[r]) * rstd * g1 + b1;
-      split_store(sHh, sHl, lr * LD16 + ccol, y0);
-      split_store(sHh, sHl, lr * LD16 + ccol + 32, y1);
-      if (g.xn_out && m0 + lr < g.M) {
-        g.xn_out[(long)(m0 + lr) * 256 + ccol] = y0;
-        g.xn_out[(long)(m0 + lr) * 256 + ccol + 32] = y1;
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int lr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float var = (red[lr] + red[BM + lr] + red[2 * BM + lr] + red[3 * BM + lr]) * (1.0f / 256.0f);
+        float rstd = rsqrtf(var + 1e-5f);
+        const float y0 = (out[mt][0][r] - mean[mt][r]) * rstd * g0 + b0;
+        const float y1 = (out[mt][1][r] - mean[mt][r]) * rstd * g1 + b1;
+        split_store(sHh, sHl, lr * LD16 + ccol, y0);
+        split_store(sHh, sHl, lr * LD16 + ccol + 32, y1);
+        if (g.xn_out && m0 + lr < g.M) {
+          g.xn_out[(long)(m0 + lr) * 256 + ccol] = y0;
+          g.xn_out[(long)(m0 + lr) * 256 + ccol + 32] = y1;
+        }
       }
-    }
     __syncthreads();
     for (int nc = 0; nc < nq; ++nc) {
-      f32x16 acc[2];
+      f32x16 acc[MT][2];
       zero(acc);
       mm(acc, sHh, sHl, g.wqkvf + (long)nc * 65536, nc + 1 < nq ? g.wqkvf + (long)(nc + 1) * 65536 : nullptr);
       scale(acc);
@@ -235,10 +275,14 @@ hipError_t launch_ffn_block_f16x3(const FfnArgs& a, hipStream_t st) {
   if (a.M <= 0) return hipSuccess;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)ffn_block_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_block_f16x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_block_f16x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  const size_t lds = (size_t)4 * 32 * LD16 * sizeof(_Float16) + 4 * 32 * sizeof(float);
-  hipLaunchKernelGGL(ffn_block_f16x3_kernel, dim3((a.M + 31) / 32), dim3(256), lds, st, a);
+  // 64-row tiles (VAPX_FFN_TILE=64) halve the weight stream but leave one wave per SIMD: measured 8 % slower at 4096 streams
+  const int mt = a.tile_rows == 64 ? 2 : 1;
+  const size_t lds = (size_t)4 * 32 * mt * LD16 * sizeof(_Float16) + 4 * 32 * mt * sizeof(float);
+  if (mt == 2) hipLaunchKernelGGL(ffn_block_f16x3_kernel<2>, dim3((a.M + 63) / 64), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL(ffn_block_f16x3_kernel<1>, dim3((a.M + 31) / 32), dim3(256), lds, st, a);
   return hipGetLastError();
 }
