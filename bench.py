@@ -254,6 +254,26 @@ def main():
                                     "ms_per_step": dtg / args.steps * 1e3}
         eng_g.close()
 
+    if rank == 0 and world == 1 and not args.no_latency and not followers and not args.split_f16:
+        # the same workload on the opt-in split-precision path (VAPX_FLAG_SPLIT_F16): every GEMM-shaped contraction as
+        # three f16 MFMA products with fp32 accumulation — same deviation from the reference as the fp32-MFMA path
+        # (tests/test_split_precision_gpu.py).  Reported next to `value`, never as `value`.
+        eng_s = engine.Engine(W.pack_blob(cpc, vap, modes[0]), hz, args.ctx_sec, max_streams=S, device_id=local_rank,
+                              mode=modes[0], split_f16=True)
+        for i in range(T + 5):
+            eng_s.step_device(S, d_audio[i % NF].data_ptr(), hop, d_out.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            eng_s.step_device(S, d_audio[i % NF].data_ptr(), hop, d_out.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - t1
+        assert torch.isfinite(d_out[:, :6]).all(), "non-finite outputs on the split-precision path"
+        result["split_f16"] = {"value": S * args.steps / dts, "unit": "frames/s", "ms_per_step": dts / args.steps * 1e3,
+                               "arithmetic": "x = hi + lo (f16); hi.hi + lo.hi + hi.lo on v_mfma_f32_32x32x16_f16, fp32 accumulate; "
+                                             "FFN block, attention projections, conv / projection GEMMs; opt-in, not the default"}
+        eng_s.close()
+
     if rank == 0 and not args.no_latency and not followers:
         # host-inclusive tick latency: host audio -> results on host (H2D + kernels + D2H + sync)
         lat = []
