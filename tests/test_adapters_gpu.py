@@ -115,3 +115,36 @@ def test_tcp_front_end_end_to_end_on_gpu():
                 np.testing.assert_array_equal(r["x1"], new[s, 0])
     finally:
         srv.stop()
+
+
+def test_level3_functional_step_matches_the_reference_static_module():
+    """VAPRealTimeStatic.forward (tools/vap_static.py:235-304, the module the reference exports to ONNX): caller-held
+    embedding context, first call with a zero row — against a golden produced by the reference class itself."""
+    import os
+    import torch
+    from golden_util import GOLDEN
+    from vap_realtime_amd import realtime, synth, weights as W
+    z = np.load(os.path.join(GOLDEN, "static20.npz"))
+    hz, ctx, F_ = int(z["meta.frame_hz"]), float(z["meta.ctx_sec"]), int(z["meta.n_frames"])
+    cpc, vap = W.synthetic_weights(int(z["meta.seed"]), hz, "vap")
+    assert np.array_equal(W.weights_fingerprint(cpc, vap), z["meta.weights_fp"])
+    hop, T = 16000 // hz, int(ctx * hz)
+    audio = synth.dialogue_batch([int(z["meta.stream"])], hop * F_ + 320)
+    m = realtime.VAPRealTimeStatic(vap, cpc, torch.device("cuda", 0), hz, ctx)
+    e1c = torch.zeros(1, 1, 256)
+    e2c = torch.zeros(1, 1, 256)
+    worst = 0.0
+    for f in range(F_):
+        win = torch.from_numpy(audio[:, :, f * hop:f * hop + hop + 320].copy())
+        p_now, p_future, v1, v2, e1, e2 = m(win[:, 0:1], win[:, 1:2], e1c, e2c)
+        assert p_now.shape == (1, 2) and v1.shape == (1, 1) and e1.shape == (1, 1, 256)
+        got = {"p_now": p_now[0].cpu().numpy(), "p_future": p_future[0].cpu().numpy(),
+               "vad": np.array([float(v1), float(v2)], np.float32), "e": torch.stack([e1[0, 0], e2[0, 0]]).cpu().numpy()}
+        for k, v in got.items():
+            worst = max(worst, float(np.abs(v - z[k][f]).max()))
+        e1c = e1 if f == 0 else torch.cat([e1c.to(e1.device), e1], dim=1)[:, -(T - 1):]
+        e2c = e2 if f == 0 else torch.cat([e2c.to(e2.device), e2], dim=1)[:, -(T - 1):]
+    print("static forward worst |diff| =", worst)
+    assert worst <= TOL
+    with pytest.raises(Exception, match="exceeds"):
+        m(win[:, 0:1], win[:, 1:2], torch.zeros(1, T, 256), torch.zeros(1, T, 256))

@@ -204,3 +204,50 @@ class VapGPT:
 
     def va_classifier(self, t):
         return self._torch.nn.functional.linear(t, self._va_w, self._va_b)
+
+
+# ------------------------------------------------------------------------------------------------
+# level-3 surface: the functional step the reference wraps for ONNX export (tools/vap_static.py:235-304)
+# ------------------------------------------------------------------------------------------------
+class VAPRealTimeStatic:
+    """``forward(x1_, x2_, e1_context, e2_context) -> (p_now[B,2], p_future[B,2], vad1[B,1], vad2[B,1], e1[B,1,256],
+    e2[B,1,256])`` with the caller holding the embedding context (first call: zeros ``[B,1,256]``, afterwards the returned
+    embeddings, at most T-1 rows).  Only the LSTM state lives inside, as in the reference (``encode_audio`` is stateful).
+    Same constructor as the reference class (tools/vap_static.py:177); torch CUDA tensors in and out."""
+
+    BINS_P_NOW = BINS_P_NOW
+    BINS_PFUTURE = BINS_PFUTURE
+
+    def __init__(self, vap_model, cpc_model, device=None, frame_rate: int = 20, context_len_sec: float = 2.5, max_batch: int = 1):
+        import torch
+        cpc_sd, vap_sd = _load_state_dicts(vap_model, cpc_model)
+        if device is not None and str(device).startswith("cpu"):
+            raise _engine.VapxError("vap-realtime_amd has no CPU path; pass a cuda device (MI355X)")
+        dev_id = int(device.index) if device is not None and getattr(device, "index", None) is not None else 0
+        self.vap_gpt = VapGPT(cpc_sd, vap_sd, frame_rate, context_len_sec, max_batch=max_batch, device_id=dev_id)
+        self.device = torch.device("cuda", dev_id)
+        self.frame_rate = frame_rate
+        self.audio_contenxt_lim_sec = context_len_sec
+        self.audio_context_len = int(context_len_sec * frame_rate)
+        self.sampling_rate = 16000
+        self.frame_contxt_padding = 320
+        self.audio_frame_size = self.sampling_rate // frame_rate + self.frame_contxt_padding
+
+    def forward(self, x1_, x2_, e1_context, e2_context):
+        import torch
+        vg, dev = self.vap_gpt, self.device
+        e1, e2 = vg.encode_audio(x1_.to(dev), x2_.to(dev))
+        x1 = torch.cat([e1_context.to(dev).float(), e1], dim=1)
+        x2 = torch.cat([e2_context.to(dev).float(), e2], dim=1)
+        if x1.shape[1] > self.audio_context_len:
+            raise _engine.VapxError(f"context of {x1.shape[1] - 1} rows exceeds T-1 = {self.audio_context_len - 1}")
+        o1, o2 = vg.ar_channel(x1), vg.ar_channel(x2)
+        out = vg.ar(o1["x"], o2["x"])
+        probs = vg.vap_head(out["x"]).softmax(dim=-1)
+        p_now = vg.objective.probs_next_speaker_aggregate(probs, self.BINS_P_NOW[0], self.BINS_P_NOW[-1])
+        p_future = vg.objective.probs_next_speaker_aggregate(probs, self.BINS_PFUTURE[0], self.BINS_PFUTURE[1])
+        vad1 = vg.va_classifier(o1["x"]).sigmoid()[::, -1]
+        vad2 = vg.va_classifier(o2["x"]).sigmoid()[::, -1]
+        return p_now[:, -1, :], p_future[:, -1, :], vad1, vad2, e1, e2
+
+    __call__ = forward
