@@ -76,6 +76,7 @@ extern "C" {
 #define VAPX_OUT_VAD 4       /* [2]  result_vad          vap_main.py:313-320 */
 #define VAPX_OUT_AUX 6       /* [4]  bc: {-, p_bc_react, p_bc_emo, -}; nod: {-, short, long, long_p} */
 #define VAPX_OUT_NVALID 10   /* [1]  n = rows in the context window this frame (as float) */
+#define VAPX_OUT_VAD_LOGIT 11 /* [2] va_classifier outputs before the sigmoid (what the training-style forward() returns) */
 #define VAPX_OUT_LOGITS 16   /* [256] vap_head logits of the newest row  vap_main.py:290;
                                       nod mode: p_bc of rows 0..n-1 instead (vap_nod_main.py:276 quirk) */
 #define VAPX_OUT_E 272       /* [2*256] this frame's embeddings e1,e2   vap_main.py:272 */

@@ -148,3 +148,24 @@ def test_level3_functional_step_matches_the_reference_static_module():
     assert worst <= TOL
     with pytest.raises(Exception, match="exceeds"):
         m(win[:, 0:1], win[:, 1:2], torch.zeros(1, T, 256), torch.zeros(1, T, 256))
+
+
+def test_vapgpt_forward_signature_with_realtime_semantics():
+    """VapGPT.forward(waveform[B,2,N]) -> {"logits": [B,n,256], "vad": [B,n,2]} (train/model.py:292-319 signature) run
+    with the realtime framing: must reproduce the per-frame logits / VAD of the reference's process_vap goldens, for a
+    batch of independent dialogues in one call, and be repeatable (state is reset per call)."""
+    import torch
+    from vap_realtime_amd import realtime
+    c = Case("multi3")
+    m = realtime.VapGPT(c.cpc_sd, c.vap_sd, c.frame_hz, c.ctx_sec, max_batch=3)
+    wav = torch.from_numpy(c.audio[:, :, :c.hop * c.n_frames].copy())
+    for _ in range(2):
+        ret = m(wav)
+        assert set(ret) == {"logits", "vad"}
+        assert ret["logits"].shape == (3, c.n_frames, 256) and ret["vad"].shape == (3, c.n_frames, 2)
+        got_l = ret["logits"].cpu().numpy().transpose(1, 0, 2)           # [F,S,256] like the golden
+        got_v = torch.sigmoid(ret["vad"]).cpu().numpy().transpose(1, 0, 2)
+        assert np.abs(got_l - c.z["logits"]).max() <= TOL
+        assert np.abs(got_v - c.z["vad"]).max() <= TOL
+    with pytest.raises(NotImplementedError):
+        m(wav, attention=True)

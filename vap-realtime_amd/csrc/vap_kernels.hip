@@ -796,6 +796,8 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
       out[2] = pf0[s] / df; out[3] = pf1[s] / df;
       out[4] = sigmoidf_(vd[2 * s] + a.vb[0]);
       out[5] = sigmoidf_(vd[2 * s + 1] + a.vb[0]);
+      out[11] = vd[2 * s] + a.vb[0];          // va_classifier outputs before the sigmoid (VapGPT.forward returns these)
+      out[12] = vd[2 * s + 1] + a.vb[0];
       out[10] = (float)nb[s];
       if (a.mode != 0) {
         int nr = a.mode == 1 ? 3 : 4;

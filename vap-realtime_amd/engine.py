@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libvapx.so")
 
 OUT_STRIDE = 784
 OUT_P_NOW, OUT_P_FUTURE, OUT_VAD, OUT_AUX, OUT_NVALID, OUT_LOGITS, OUT_E = 0, 2, 4, 6, 10, 16, 272
+OUT_VAD_LOGIT = 11
 AUDIO_DEVICE, OUT_DEVICE, IDS_DEVICE = 1, 2, 4
 MODE = {"vap": 0, "bc": 1, "nod": 2}
 
@@ -275,5 +276,6 @@ def split_outputs(out: np.ndarray) -> dict:
         "p_now": out[:, OUT_P_NOW:OUT_P_NOW + 2], "p_future": out[:, OUT_P_FUTURE:OUT_P_FUTURE + 2],
         "vad": out[:, OUT_VAD:OUT_VAD + 2], "aux": out[:, OUT_AUX:OUT_AUX + 4],
         "n": out[:, OUT_NVALID].astype(np.int32), "logits": out[:, OUT_LOGITS:OUT_LOGITS + 256],
+        "vad_logit": out[:, OUT_VAD_LOGIT:OUT_VAD_LOGIT + 2],
         "e": out[:, OUT_E:OUT_E + 512].reshape(-1, 2, 256),
     }

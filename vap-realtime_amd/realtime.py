@@ -199,6 +199,38 @@ class VapGPT:
                                        stream=self._stream())
         return {"x": comb, "x1": x12[:, 0].contiguous(), "x2": x12[:, 1].contiguous()}
 
+    def forward(self, waveform, attention: bool = False, lang_info: list = None):
+        """The training module's call signature (train/model.py:292-319): ``waveform [B,2,N] -> {"logits": [B,n,256],
+        "vad": [B,n,2]}`` (vad = classifier outputs BEFORE the sigmoid, as there).  Semantics are the REALTIME ones
+        ("follow realtime"): the waveform is cut into hop-sized frames exactly like ``proc_serv_in`` does
+        (zero carry before the first frame, vap_main.py:368-409), each frame sees the last T frames, the LSTM state
+        runs through the whole call and starts from zero, VAD reads the ar_channel output (vap_main.py:292-293).
+        n = N // hop.  Attention maps are not materialised by the fused kernels."""
+        if attention:
+            raise NotImplementedError("attention maps are never materialised by the fused attention block")
+        torch = self._torch
+        B, two, N = waveform.shape
+        assert two == 2
+        eng = self.engine
+        if B > eng.max_batch:
+            raise _engine.VapxError(f"batch {B} exceeds max_batch {eng.max_batch}")
+        for b in range(B):
+            eng.reset_stream(b)
+        hop = eng.hop
+        n = N // hop
+        wav = waveform.to(self.device).float()
+        out = torch.empty(B, _engine.OUT_STRIDE, device=self.device)
+        logits = torch.empty(B, n, 256, device=self.device)
+        vad = torch.empty(B, n, 2, device=self.device)
+        for f in range(n):
+            x = wav[:, :, f * hop:(f + 1) * hop].contiguous()
+            eng.step_device(B, x.data_ptr(), hop, out.data_ptr(), stream=self._stream())
+            logits[:, f] = out[:, _engine.OUT_LOGITS:_engine.OUT_LOGITS + 256]
+            vad[:, f] = out[:, _engine.OUT_VAD_LOGIT:_engine.OUT_VAD_LOGIT + 2]
+        return {"logits": logits, "vad": vad}
+
+    __call__ = forward
+
     def vap_head(self, t):
         return self._torch.nn.functional.linear(t, self._head_w, self._head_b)
 
