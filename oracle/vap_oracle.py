@@ -40,10 +40,10 @@ HEADS = 4
 PAD = 320  # frame_contxt_padding, vap_main.py:224
 
 
-def _t(x) -> torch.Tensor:
+def _t(x, dtype=torch.float32) -> torch.Tensor:
     if isinstance(x, torch.Tensor):
-        return x.detach().to(torch.float32).cpu()
-    return torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float32)))
+        return x.detach().to(dtype).cpu()
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float32))).to(dtype)
 
 
 @dataclass
@@ -64,9 +64,12 @@ class OracleState:
 
 class VapOracle:
     def __init__(self, cpc_sd: Dict[str, np.ndarray], vap_sd: Dict[str, np.ndarray],
-                 frame_hz: int = 20, context_len_sec: float = 2.5, mode: str = "vap"):
-        self.w = {k: _t(v) for k, v in cpc_sd.items()}
-        self.v = {k: _t(v) for k, v in vap_sd.items()}
+                 frame_hz: int = 20, context_len_sec: float = 2.5, mode: str = "vap", dtype=torch.float32):
+        # dtype = torch.float64 turns the restatement into a ground truth for rounding-error comparisons between the
+        # HIP arithmetic variants (tests/test_split_precision_gpu.py); the reference itself computes in float32
+        self.dtype = dtype
+        self.w = {k: _t(v, dtype) for k, v in cpc_sd.items()}
+        self.v = {k: _t(v, dtype) for k, v in vap_sd.items()}
         self.frame_hz = frame_hz
         self.T = int(context_len_sec * frame_hz)                 # vap_main.py:221
         self.hop = 16000 // frame_hz
@@ -74,7 +77,7 @@ class VapOracle:
         self.mode = mode
         # aggregation tables, objective.py:93-110,141-143,196-201: states[i,c,b] = bit(4c+b)
         idx = torch.arange(256)
-        bits = ((idx[:, None] >> torch.arange(8)[None, :]) & 1).to(torch.float32).view(256, 2, 4)
+        bits = ((idx[:, None] >> torch.arange(8)[None, :]) & 1).to(dtype).view(256, 2, 4)
         self.abp_now = bits[:, :, 0:2].sum(-1)                   # BINS_P_NOW = [0,1]  vap_main.py:187
         self.abp_fut = bits[:, :, 2:4].sum(-1)                   # BINS_PFUTURE = [2,3]
 
@@ -126,8 +129,8 @@ class VapOracle:
         z = self.cnn(x, collect)                                  # [S*2,256,P4]
         z = z.transpose(1, 2)[:, 1:-1, :]                         # encoder.py:75-76
         if st.h is None:
-            st.h = torch.zeros(S, 2, DIM)
-            st.c = torch.zeros(S, 2, DIM)
+            st.h = torch.zeros(S, 2, DIM, dtype=self.dtype)
+            st.c = torch.zeros(S, 2, DIM, dtype=self.dtype)
         y, h, c = self.lstm(z, st.h.reshape(S * 2, DIM), st.c.reshape(S * 2, DIM))
         st.h, st.c = h.reshape(S, 2, DIM), c.reshape(S, 2, DIM)
         e = self.downsample(y).reshape(S, 2, DIM)
@@ -147,7 +150,7 @@ class VapOracle:
         val = (kv_in @ v[f"{pre}.value.weight"].T).view(B, n, HEADS, 64).transpose(1, 2)
         att = torch.einsum("bhid,bhjd->bhij", q, k) * (1.0 / math.sqrt(DIM))   # scale 1/16, :52
         m = v[f"{pre}.m"].view(1, HEADS, 1, 1)
-        j = torch.arange(n, dtype=torch.float32).view(1, 1, 1, n)
+        j = torch.arange(n, dtype=self.dtype).view(1, 1, 1, n)
         causal = torch.full((n, n), float("-inf")).triu(1)
         att = att + (m * j + causal)
         att = att.softmax(dim=-1)
@@ -192,7 +195,7 @@ class VapOracle:
     def step(self, audio, st: OracleState, collect: Optional[dict] = None) -> Dict[str, np.ndarray]:
         """One VAP frame for S streams.  audio: float [S,2,L] (carry + new samples, exactly what
         ``process_vap`` receives as x1/x2).  Returns numpy arrays."""
-        audio = _t(audio)
+        audio = _t(audio, self.dtype)
         with torch.no_grad():
             e = self.encode(audio, st, collect)
             st.ring.append(e)

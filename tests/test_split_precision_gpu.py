@@ -55,3 +55,40 @@ def test_split_f16_with_full_last_layer_and_unfused_variants():
             np.testing.assert_allclose(e.step(a)[:, :272], want[:, :272], rtol=0, atol=3e-5)
     for e in var + [ref]:
         e.close()
+
+
+def test_rounding_error_against_a_float64_ground_truth():
+    """Both arithmetic variants against the float64 restatement of the step (the same algorithm in double precision):
+    the split path's error must not exceed the fp32-MFMA path's by more than a small factor — it is a different
+    summation, not a lower precision.  The torch-CPU fp32 oracle is measured alongside for scale."""
+    import torch
+    from oracle.vap_oracle import ServerFramer, VapOracle
+    from vap_realtime_amd import engine, synth, weights as W
+    cpc, vap = W.synthetic_weights(31, 20, "vap")
+    S, F_ = 2, 56
+    audio = synth.dialogue_batch([40, 41], 800 * F_)
+    o64 = VapOracle(cpc, vap, 20, 2.5, dtype=torch.float64)
+    o32 = VapOracle(cpc, vap, 20, 2.5)
+    s64, s32 = o64.new_state(S), o32.new_state(S)
+    f64, f32 = ServerFramer(S, 800), ServerFramer(S, 800)
+    blob = W.pack_blob(cpc, vap)
+    e32 = engine.Engine(blob, 20, 2.5, max_streams=S)
+    e16 = engine.Engine(blob, 20, 2.5, max_streams=S, split_f16=True)
+    err = {"hip fp32 MFMA": 0.0, "hip f16x3 split": 0.0, "torch-cpu fp32": 0.0}
+    rms = dict.fromkeys(err, 0.0)
+    for f in range(F_):
+        new = audio[:, :, f * 800:(f + 1) * 800]
+        truth = o64.step(f64.frame(new), s64)["logits"]
+        cand = {"hip fp32 MFMA": engine.split_outputs(e32.step(new))["logits"],
+                "hip f16x3 split": engine.split_outputs(e16.step(new))["logits"],
+                "torch-cpu fp32": o32.step(f32.frame(new), s32)["logits"]}
+        for k, v in cand.items():
+            d = np.abs(v.astype(np.float64) - truth)
+            err[k] = max(err[k], float(d.max()))
+            rms[k] += float((d ** 2).mean()) / F_
+    print("max |logits - float64 truth|:", {k: f"{v:.2e}" for k, v in err.items()},
+          "rms:", {k: f"{np.sqrt(v):.2e}" for k, v in rms.items()})
+    assert err["hip fp32 MFMA"] <= 1e-4 and err["hip f16x3 split"] <= 1e-4
+    assert err["hip f16x3 split"] <= 2.0 * err["hip fp32 MFMA"] + 2e-6
+    assert np.sqrt(rms["hip f16x3 split"]) <= 2.0 * np.sqrt(rms["hip fp32 MFMA"]) + 5e-7
+    e32.close(); e16.close()
