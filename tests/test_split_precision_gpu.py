@@ -92,3 +92,41 @@ def test_rounding_error_against_a_float64_ground_truth():
     assert err["hip f16x3 split"] <= 2.0 * err["hip fp32 MFMA"] + 2e-6
     assert np.sqrt(rms["hip f16x3 split"]) <= 2.0 * np.sqrt(rms["hip fp32 MFMA"]) + 5e-7
     e32.close(); e16.close()
+
+
+@pytest.mark.parametrize("name", ["bc20", "nod20"])
+def test_split_f16_aux_heads(name):
+    """bc / nod weight sets on the split path (nod runs the full last layer: every FFN-block variant is exercised)."""
+    from vap_realtime_amd import engine, weights as W
+    c = Case(name)
+    eng = engine.Engine(W.pack_blob(c.cpc_sd, c.vap_sd, c.mode), c.frame_hz, c.ctx_sec, max_streams=1, mode=c.mode, split_f16=True)
+    for f in range(c.n_frames):
+        o = engine.split_outputs(eng.step(c.new_samples(f)))
+        if name == "bc20":
+            np.testing.assert_allclose(o["aux"][:, 1], c.z["p_bc_react"][f].reshape(-1), rtol=0, atol=TOL)
+            np.testing.assert_allclose(o["aux"][:, 2], c.z["p_bc_emo"][f].reshape(-1), rtol=0, atol=TOL)
+        else:
+            for col, key in ((1, "p_nod_short"), (2, "p_nod_long"), (3, "p_nod_long_p")):
+                np.testing.assert_allclose(o["aux"][:, col], c.z[key][f].reshape(-1), rtol=0, atol=TOL)
+            n = min(f + 1, c.T)
+            np.testing.assert_allclose(o["logits"][:, :n], c.z["p_bc"][f][:, :n], rtol=0, atol=TOL)
+    eng.close()
+
+
+def test_split_f16_five_hz_and_odd_batch_against_the_oracle():
+    """5 Hz (K = 20 CPC frames per VAP frame, conv GEMMs with the unfused tail) and a batch that is no multiple of any tile."""
+    from oracle.vap_oracle import ServerFramer, VapOracle
+    from vap_realtime_amd import engine, synth, weights as W
+    cpc, vap = W.synthetic_weights(17, 5, "vap")
+    S, F_, hop = 37, 5, 3200
+    o = VapOracle(cpc, vap, 5, 4.0)
+    audio = synth.noise_batch(S, hop * F_, seed=4) * np.linspace(0.2, 2.5, S, dtype=np.float32)[:, None, None]
+    st, fr = o.new_state(S), ServerFramer(S, hop)
+    eng = engine.Engine(W.pack_blob(cpc, vap), 5, 4.0, max_streams=S, split_f16=True)
+    for f in range(F_):
+        new = audio[:, :, f * hop:(f + 1) * hop]
+        want = o.step(fr.frame(new), st)
+        got = engine.split_outputs(eng.step(new))
+        for k in ("p_now", "p_future", "vad", "logits"):
+            np.testing.assert_allclose(got[k], want[k], rtol=0, atol=TOL, err_msg=f"{k} frame {f}")
+    eng.close()
