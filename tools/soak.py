@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Soak run on the GPU: the same audio through three engines (default, two free-running overlap groups, split-precision)
+for many ticks with random resets; the first two must stay bit-identical while both batch sizes select the same kernel
+variants (<= 512 streams; beyond that tile heuristics differ and only the tolerance applies), the third within tolerance,
+nothing may go non-finite.  Usage: tools/soak.py [streams] [ticks]"""
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+from vap_realtime_amd import engine, synth, weights as W  # noqa: E402
+
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+TICKS = int(sys.argv[2]) if len(sys.argv) > 2 else 600
+cpc, vap = W.synthetic_weights(3, 20)
+blob = W.pack_blob(cpc, vap)
+a = engine.Engine(blob, 20, 2.5, max_streams=S)
+b = engine.Engine(blob, 20, 2.5, max_streams=S, groups=2)
+c = engine.Engine(blob, 20, 2.5, max_streams=S, split_f16=True)
+NF = 16
+audio = torch.from_numpy(np.concatenate([synth.dialogue_batch(list(range(64)), 800 * NF)] * ((S + 63) // 64))[:S]).cuda()
+oa, ob, oc = (torch.zeros(S, engine.OUT_STRIDE, device="cuda") for _ in range(3))
+rng = np.random.default_rng(0)
+st = torch.cuda.current_stream().cuda_stream
+worst = 0.0
+for t in range(TICKS):
+    x = audio[:, :, (t % NF) * 800:(t % NF + 1) * 800].contiguous()
+    if t % 37 == 5:
+        torch.cuda.synchronize()
+        for sid in rng.integers(0, S, 3):
+            for e in (a, b, c):
+                e.reset_stream(int(sid))
+    a.step_device(S, x.data_ptr(), 800, oa.data_ptr(), stream=st)
+    b.step_device(S, x.data_ptr(), 800, ob.data_ptr(), stream=st, defer_join=True)
+    c.step_device(S, x.data_ptr(), 800, oc.data_ptr(), stream=st)
+    if t % 25 == 24 or t == TICKS - 1:
+        b.join(st)
+        torch.cuda.synchronize()
+        assert torch.isfinite(oa).all() and torch.isfinite(oc).all(), f"non-finite output at tick {t}"
+        if S <= 512:
+            assert torch.equal(oa, ob), f"overlap groups diverged from the single-stream path at tick {t}"
+        dg = float((oa[:, :272] - ob[:, :272]).abs().max())
+        assert dg < 2e-5, f"overlap groups off by {dg} at tick {t}"
+        d = float((oa[:, :272] - oc[:, :272]).abs().max())
+        worst = max(worst, d)
+        assert d < 1e-4, f"split path off by {d} at tick {t}"
+print(f"soak ok: {S} streams x {TICKS} ticks; overlap groups " + ("bit-identical" if S <= 512 else "within 2e-5") + f"; max |split - fp32| = {worst:.2e}")
