@@ -625,11 +625,10 @@ __global__ __launch_bounds__(256) void attention_last_kernel(AttnArgs a) {
 //    reference: Combinator.forward modules.py:449-464; vap_head / va_classifier / softmax
 //    vap_main.py:290-295,313-314; probs_next_speaker_aggregate objective.py:186-206;
 //    bc / nod heads vap_bc_main.py:272-277, vap_nod_main.py:273-279.
-//    8 streams per workgroup; thread j owns output feature j (weights pre-transposed [k][j] so
+//    HB (2 or 4) streams per workgroup; thread j owns output feature j (weights pre-transposed [k][j] so
 //    the 256 threads read one coalesced row per k); row-wise reductions via wave butterflies +
 //    one LDS exchange.
 // ------------------------------------------------------------------------------------------------
-constexpr int HB = 8;
 
 template <int N>
 __device__ __forceinline__ void block_sum(float (&v)[N], float* red /* [4][N] */, int wave, int lane) {
@@ -659,7 +658,7 @@ __device__ __forceinline__ void block_max(float (&v)[N], float* red, int wave, i
 // y[s][j] = sum_k WT[k][j] * x[s][k] for the HB streams of the block: the k range is split over the 4
 // waves (64 k each), each lane accumulates 4 adjacent outputs with 16-byte weight loads (a 1 KiB
 // coalesced row per wave instruction), partials are combined through LDS.  Thread j returns y[.][j].
-template <int XS /* floats between consecutive streams in x */>
+template <int XS /* floats between consecutive streams in x */, int HB>
 __device__ __forceinline__ void block_matvec(const float* __restrict__ WT, const float* x, float* psum /* [4][HB][256] */,
                                              float (&y)[HB], int j) {
   const int lane = j & 63, w = j >> 6;
@@ -688,6 +687,7 @@ __device__ __forceinline__ void block_matvec(const float* __restrict__ WT, const
     y[s] = (psum[(0 * HB + s) * 256 + j] + psum[(1 * HB + s) * 256 + j]) + (psum[(2 * HB + s) * 256 + j] + psum[(3 * HB + s) * 256 + j]);
 }
 
+template <int HB>
 __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
   __shared__ __attribute__((aligned(16))) float xs[HB][2][256];  // newest rows of the two towers
   __shared__ __attribute__((aligned(16))) float hs[HB][256];
@@ -708,8 +708,8 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
   __syncthreads();
   // combinator projections
   float ha[HB], hb[HB];
-  block_matvec<512>(a.waT, &xs[0][0][0], psum, ha, j);
-  block_matvec<512>(a.wbT, &xs[0][1][0], psum, hb, j);
+  block_matvec<512, HB>(a.waT, &xs[0][0][0], psum, ha, j);
+  block_matvec<512, HB>(a.wbT, &xs[0][1][0], psum, hb, j);
   // shared LayerNorm on both, exact GELU, sum
   float v[2 * HB];
 #pragma unroll
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
   __syncthreads();
   // vap_head logits
   float lg[HB];
-  block_matvec<256>(a.hwT, &hs[0][0], psum, lg, j);
+  block_matvec<256, HB>(a.hwT, &hs[0][0], psum, lg, j);
   const float hbias = a.hb[j];
 #pragma unroll
   for (int s = 0; s < HB; ++s) lg[s] += hbias;
@@ -861,6 +861,9 @@ hipError_t launch_attention_last(const AttnArgs& a, int B, hipStream_t st) {
   return hipGetLastError();
 }
 hipError_t launch_head(const HeadArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(head_kernel, dim3((a.B + HB - 1) / HB), dim3(256), 0, st, a);
+  // streams per workgroup: every workgroup streams the same 0.8 MB of weights, so few streams per workgroup spread a small
+  // batch over more CUs (2: 30 us at 256 streams vs 56 us with 8), more amortise the stream at large batches
+  if (a.B <= 1024) hipLaunchKernelGGL(head_kernel<2>, dim3((a.B + 1) / 2), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(head_kernel<4>, dim3((a.B + 3) / 4), dim3(256), 0, st, a);
   return hipGetLastError();
 }
