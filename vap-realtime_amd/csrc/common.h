@@ -60,12 +60,7 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return copysignf(r, x);
 }
 
-// 64-lane butterfly all-reduce (sum / max)
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+// 64-lane butterfly all-reduce (max; the sum is below, built on the DPP half_sum)
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
@@ -82,4 +77,9 @@ __device__ __forceinline__ float half_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
   v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));                   // lane ^ 16
   return v;
+}
+// 64-lane all-reduce: five DPP / swizzle steps inside each half, one ds_bpermute across the halves
+__device__ __forceinline__ float wave_sum(float v) {
+  v = half_sum(v);
+  return v + __shfl_xor(v, 32);
 }
