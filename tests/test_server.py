@@ -109,3 +109,51 @@ def test_single_stream_broadcasts_like_reference():
             assert r["p_now"] == [1.0, 1.0]
     finally:
         srv.stop()
+
+
+def test_connection_burst_larger_than_the_default_backlog():
+    """A whole shard of clients connecting at once (more than the classic listen(128) backlog): every stream must get its
+    slot and its result route; one closed-loop round over all of them completes."""
+    import threading
+    S, hop = 400, 800
+    vap = FakeVap(S, hop)
+    srv = ManyStreamServer(vap, port_in=0, port_out=0, max_wait_s=0.01).start()
+    ins, outs, errs = [None] * S, [None] * S, []
+
+    def connect(lo, hi, port, dst):
+        try:
+            for i in range(lo, hi):
+                dst[i] = socket.create_connection(("127.0.0.1", port), timeout=10)
+        except Exception as e:          # noqa: BLE001
+            errs.append(e)
+
+    def burst(port, dst):
+        th = [threading.Thread(target=connect, args=(k * 50, (k + 1) * 50, port, dst)) for k in range(S // 50)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+
+    try:
+        burst(srv.port_in, ins)
+        deadline = time.time() + 10
+        while len(srv.in_conn) < S and time.time() < deadline:
+            time.sleep(0.01)
+        burst(srv.port_out, outs)
+        deadline = time.time() + 10
+        while sum(len(l) for l in srv.out_conns) < S and time.time() < deadline:
+            time.sleep(0.01)
+        assert not errs and len(srv.in_conn) == S and all(len(l) == 1 for l in srv.out_conns)
+        frame = wire.encode_input(np.full(hop, 0.25), np.full(hop, -0.5))
+        for s in ins:
+            s.sendall(frame)
+        for s in outs:
+            s.settimeout(10)
+            n = struct.unpack("<I", _recv_exact(s, 4))[0]
+            r = wire.decode_result(_recv_exact(s, n))
+            assert abs(r["p_now"][0] - 0.25) < 1e-6 and abs(r["p_now"][1] - 0.5) < 1e-6
+    finally:
+        for s in ins + outs:
+            if s is not None:
+                s.close()
+        srv.stop()

@@ -62,7 +62,7 @@ class ManyStreamServer:
         s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
         s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
         s.bind((host, port))
-        s.listen(128)
+        s.listen(4096)     # a whole shard of dialogue clients may connect at once (capped by net.core.somaxconn)
         s.setblocking(False)
         return s
 
