@@ -65,3 +65,16 @@ def test_packet_assembler_matches_server_framing():
     with pytest.raises(ValueError):
         for _ in range(6):
             pa.push(1, wire.encode_input(np.zeros(160), np.zeros(160)))
+
+
+def test_batched_result_packets_equal_the_per_stream_encoder():
+    rng = np.random.default_rng(3)
+    R, n = 5, 800
+    echo = rng.standard_normal((R, 2, n))
+    heads = [rng.random((R, 2)).astype(np.float32) for _ in range(3)]
+    t = 1727000000.123456
+    buf = wire.frame_results_batch(t, echo, *heads)
+    for k in range(R):
+        want = wire.frame_result({"t": t, "x1": echo[k, 0], "x2": echo[k, 1], "p_now": heads[0][k], "p_future": heads[1][k],
+                                  "vad": heads[2][k]})
+        assert buf[k].tobytes() == want

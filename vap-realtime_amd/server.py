@@ -144,12 +144,19 @@ class ManyStreamServer:
         echo = self.asm.last_echo
         res = self.vap.process(frames, ready.astype(np.int32))
         t = time.time()
+        batch = wire.frame_results_batch(t, echo, res["p_now"], res["p_future"], res["vad"]) if self.mode == "vap" else None
         for k, sid in enumerate(ready):
             sid = int(sid)
+            if batch is not None:
+                pkt = memoryview(batch[k])
+                for conn in list(self.out_all if self.broadcast else self.out_conns[sid]):
+                    try:
+                        conn.sendall(pkt)
+                    except OSError:
+                        (self.out_all if self.broadcast else self.out_conns[sid]).remove(conn)
+                continue
             r = {"t": t, "x1": echo[k, 0], "x2": echo[k, 1]}
-            if self.mode == "vap":
-                r.update(p_now=res["p_now"][k], p_future=res["p_future"][k], vad=res["vad"][k])
-            elif self.mode == "bc":
+            if self.mode == "bc":
                 r.update(p_bc_react=[res["aux"][k, 1]], p_bc_emo=[res["aux"][k, 2]])
             else:
                 r.update(p_bc=res.get("p_bc", np.zeros((len(ready), 0)))[k], p_nod_short=[res["aux"][k, 1]],

@@ -63,6 +63,38 @@ def frame_result(res: Dict, mode: str = "vap") -> bytes:
     return len(payload).to_bytes(4, "little") + payload
 
 
+def frame_results_batch(t: float, echo: np.ndarray, p_now: np.ndarray, p_future: np.ndarray, vad: np.ndarray) -> np.ndarray:
+    """All result packets of one tick at once (mode "vap"): ``echo`` float64 [R,2,n], the three heads float [R,2] ->
+    uint8 [R, 4 + payload]; row k is byte-identical to ``frame_result`` of stream k.  One vectorised fill instead of
+    R x 5 small encodes: the per-stream Python cost was the front-end's bottleneck."""
+    R, _, n = echo.shape
+    plen = 8 + 2 * (4 + 8 * n) + 3 * (4 + 16)
+    buf = np.empty((R, 4 + plen), dtype=np.uint8)
+    o = 0
+
+    def put(raw: bytes):
+        nonlocal o
+        buf[:, o:o + len(raw)] = np.frombuffer(raw, dtype=np.uint8)
+        o += len(raw)
+
+    def put_f64(a: np.ndarray):                     # a: [R, m] -> u32 count + m little-endian doubles per row
+        nonlocal o
+        m = a.shape[1]
+        put(struct.pack("<I", m))
+        buf[:, o:o + 8 * m] = np.ascontiguousarray(a, dtype="<f8").view(np.uint8).reshape(R, 8 * m)
+        o += 8 * m
+
+    put(plen.to_bytes(4, "little"))
+    put(struct.pack("<d", float(t)))
+    put_f64(echo[:, 0])
+    put_f64(echo[:, 1])
+    put_f64(np.asarray(p_now, dtype=np.float64))
+    put_f64(np.asarray(p_future, dtype=np.float64))
+    put_f64(np.asarray(vad, dtype=np.float64))
+    assert o == 4 + plen
+    return buf
+
+
 def decode_result(payload: bytes, mode: str = "vap") -> Dict:
     """== util.conv_bytearray_2_vapresult (/_bc/_nod)."""
     idx = 0
