@@ -40,7 +40,7 @@ class VAPRealTime:
     CALC_PROCESS_TIME_INTERVAL = 100
 
     def __init__(self, vap_model, cpc_model, device=None, frame_rate: int = 20, context_len_sec: float = 2.5,
-                 mode: str = "vap"):
+                 mode: str = "vap", **engine_options):
         cpc_sd, vap_sd = _load_state_dicts(vap_model, cpc_model)
         self.mode = mode
         self.device = device
@@ -50,7 +50,7 @@ class VAPRealTime:
         if device is not None and str(device).startswith("cpu"):
             raise _engine.VapxError("vap-realtime_amd has no CPU path; pass a cuda device (MI355X)")
         self.engine = _engine.Engine(_weights.pack_blob(cpc_sd, vap_sd, mode), frame_rate, context_len_sec,
-                                     max_streams=1, mode=mode, device_id=dev_id)
+                                     max_streams=1, mode=mode, device_id=dev_id, **engine_options)
         self.audio_contenxt_lim_sec = context_len_sec
         self.frame_rate = frame_rate
         self.audio_context_len = int(context_len_sec * frame_rate)
@@ -117,9 +117,11 @@ class ManyStreamVAP:
     """S independent streams on one GPU.  ``process(new_samples[, stream_ids])`` = one tick."""
 
     def __init__(self, cpc_sd, vap_sd, frame_rate: int = 20, context_len_sec: float = 2.5, n_streams: int = 256,
-                 max_batch: Optional[int] = None, mode: str = "vap", device_id: int = 0):
+                 max_batch: Optional[int] = None, mode: str = "vap", device_id: int = 0, **engine_options):
+        """``engine_options`` go to ``engine.Engine`` (e.g. ``split_f16=True``, ``groups=2``)."""
         self.engine = _engine.Engine(_weights.pack_blob(cpc_sd, vap_sd, mode), frame_rate, context_len_sec,
-                                     max_streams=n_streams, max_batch=max_batch, mode=mode, device_id=device_id)
+                                     max_streams=n_streams, max_batch=max_batch, mode=mode, device_id=device_id,
+                                     **engine_options)
         self.n_streams = n_streams
         self.hop = 16000 // frame_rate
         self.mode = mode
