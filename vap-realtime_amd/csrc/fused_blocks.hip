@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
     // A fragments ping-pong between two register sets (even / odd k-step) so that the LDS read of
     // step k+1 is in flight during the MFMAs of step k (with one set hipcc issues the read and
     // waits for it right away); sched_group_barrier fixes the order: 1 LDS read, 8 MFMAs, 2 loads.
+    __builtin_amdgcn_s_setprio(2);   // MFMA phases outrank the co-resident workgroup's epilogues (measured +0.7 %)
     f32x4 a0[MT], a1[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) a0[mt] = *(const f32x4*)(pa + mt * 32 * LDH);
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
   };
   auto zero = [](f32x16(&acc)[MT][2]) {
 #pragma unroll
