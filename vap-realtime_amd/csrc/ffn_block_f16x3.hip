@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_f16x3_kernel(c
     const _Float16* pal = Al + l31 * LD16 + hi * 8;
     const f32x4* wf = wbase(wfrag);
     const f32x4* wnext = next_wfrag ? wbase(next_wfrag) : wf;
+    __builtin_amdgcn_s_setprio(2);
 #pragma unroll 1
     for (int blk = 0; blk < 4; ++blk) {
       const f32x4* nx = blk < 3 ? wf + (blk + 1) * 16 * 64 : wnext;
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_f16x3_kernel(c
         __builtin_amdgcn_sched_barrier(0);   // keep the refills behind their MFMAs
       }
     }
+    __builtin_amdgcn_s_setprio(0);
   };
   auto zero = [](f32x16(&acc)[MT][2]) {
 #pragma unroll
