@@ -41,6 +41,17 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
   const int l31 = lane & 31, hi = lane >> 5, kh = hi * 4;
   const int m0 = blockIdx.x * BM;
 
+  // acc[mt][2] += A[BM x 256] (LDS) . Wsub^T for this wave's 64 columns; wfrag = 256x256 fragment
+  // block.  Weight fragments run through an in-place register ring one 8-kc block ahead (~4k MFMA
+  // cycles of cover for the L2 latency), including across contraction boundaries (next_wfrag).
+  f32x4 ring[16];
+  auto wbase = [&](const float* wfrag) { return (const f32x4*)wfrag + (long)w * 32 * 2 * 64; };   // wave-uniform
+  auto fetch = [&](const float* wfrag) {
+    const f32x4* wf = wbase(wfrag);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ring[i] = wf[i * 64 + lane];
+  };
+  fetch(g.w0f);   // the first weight fragments fly while the activation tile is loaded and normalised
   {  // A operand of FFN1 = LayerNorm(xmid; ln_ffn), normalised while the tile is staged: every wave
      // loads whole rows (64 lanes x 16 B), so the row statistics are two wave reductions — the
      // producer (attention block) no longer writes a normalised copy to HBM at all
@@ -66,16 +77,6 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
   }
   __syncthreads();
 
-  // acc[mt][2] += A[BM x 256] (LDS) . Wsub^T for this wave's 64 columns; wfrag = 256x256 fragment
-  // block.  Weight fragments run through an in-place register ring one 8-kc block ahead (~4k MFMA
-  // cycles of cover for the L2 latency), including across contraction boundaries (next_wfrag).
-  f32x4 ring[16];
-  auto wbase = [&](const float* wfrag) { return (const f32x4*)wfrag + (long)w * 32 * 2 * 64; };   // wave-uniform
-  auto fetch = [&](const float* wfrag) {
-    const f32x4* wf = wbase(wfrag);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) ring[i] = wf[i * 64 + lane];
-  };
   auto mm = [&](f32x16(&acc)[MT][2], const float* A, const float* wfrag, const float* next_wfrag) {
     const float* pa = A + l31 * LDH + kh;
     const f32x4* wf = wbase(wfrag);
@@ -153,7 +154,6 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
   const float* after_ffn = g.wkvxf ? g.wkvxf : (nq ? g.wqkvf : nullptr);
   f32x16 out[MT][2];
   zero(out);
-  fetch(g.w0f);
   for (int c = 0; c < 3; ++c) {
     f32x16 hacc[MT][2];
     zero(hacc);
