@@ -41,6 +41,8 @@ extern "C" {
 #define VAPX_E_NOMEM (-3)
 #define VAPX_E_RANGE (-4)    /* stream id / batch size out of range */
 #define VAPX_E_NODEVICE (-5) /* no gfx950 device visible */
+#define VAPX_E_NUMERIC (-6)  /* host-output vapx_step only: a stream produced non-finite p_now / p_future / VAD (NaN or Inf audio,
+                                or |activation| >= 65504 on the split-precision path); the out block is still filled */
 
 /* model variants: which heads are evaluated (vap_main.py:290-307, vap_bc_main.py:272-277,
  * vap_nod_main.py:273-279) */

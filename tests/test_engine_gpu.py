@@ -266,6 +266,27 @@ def test_error_paths():
     eng.close()
 
 
+def test_non_finite_state_fails_loudly_and_reset_recovers():
+    """The host output path refuses to hand NaNs to the caller (VAPX_E_NUMERIC).  Bad audio samples cannot cause it —
+    ReLU after the first ChannelNorm maps NaN to 0 (fmaxf), unlike torch — so the state is poisoned directly."""
+    from vap_realtime_amd import engine
+    c = Case("vap20")
+    eng = make_engine(c, max_streams=2)
+    good = np.concatenate([c.new_samples(0), c.new_samples(1)], axis=0)          # two streams
+    eng.step(good)
+    bad = good.copy()
+    bad[1, 0, 17] = np.nan
+    assert np.isfinite(eng.step(bad)[:, :10]).all()
+    st = eng.get_state(1)
+    st["lstm"][0, 0, 5] = np.nan
+    eng.set_state(1, st)
+    with pytest.raises(engine.VapxError, match="non-finite outputs for batch slot 1"):
+        eng.step(good)
+    eng.reset_stream(1)
+    assert np.isfinite(eng.step(good)[:, :10]).all()
+    eng.close()
+
+
 def test_long_run_does_not_drift():
     """300 frames (15 s): the persistent LSTM state and the ring / QKV cache wrap six times; the HIP path
     must stay within tolerance of the oracle all the way (no error accumulation)."""

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -736,6 +737,14 @@ int vapx_step(vapx_handle h, int32_t n, const int32_t* stream_ids, const float* 
     HIPCHK(h, hipMemcpyAsync(h->out_pinned, h->out_dev, (size_t)n * VAPX_OUT_STRIDE * sizeof(float), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     memcpy(out, h->out_pinned, (size_t)n * VAPX_OUT_STRIDE * sizeof(float));
+    for (int i = 0; i < n; ++i) {   // fail loudly rather than hand NaNs to a dialogue system
+      const float* r = out + (size_t)i * VAPX_OUT_STRIDE;
+      bool ok = true;
+      for (int k = 0; k < 10; ++k) ok = ok && std::isfinite(r[k]);
+      if (!ok)
+        return fail(h, VAPX_E_NUMERIC, "non-finite outputs for batch slot %d (stream %d); its state is poisoned: reset the stream", i,
+                    (stream_ids && !(flags & VAPX_IDS_DEVICE)) ? stream_ids[i] : i);
+    }
   }
   return VAPX_OK;
 }
