@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
 """bench.py — VAP frames/s of the MI355X-native streaming forward pass.
 
-One "step" = one VAP frame (one tick) for every stream of this rank: frame assembly -> CPC CNN ->
-LSTM -> downsample -> context ring -> 1+3 transformer layers -> heads, through the C ABI
-(vapx_step) with audio and outputs resident in HBM.  Workload at N=1 = BASELINE.json configs[1]:
-256 concurrent synthetic stereo streams, 20 Hz frames, 2.5 s context (T=50).  With N GPUs every
-rank runs its own 256 streams (weak scaling, no data-path collective: streams are independent).
+One "step" = one VAP frame (one tick) for every stream of this rank: frame assembly -> CPC CNN -> LSTM -> downsample ->
+context ring -> 1+3 transformer layers -> heads, through the C ABI (vapx_step) with audio and outputs resident in HBM.
 
-Prints ONE JSON line on rank 0 (contract in the task prompt): metric/value/unit/... plus
-  "roofline":     dominant kernel (by summed time), HIP-event timed inside the timed region
-  "cpu_baseline": the oracle (CPU restatement of the reference step) timed on this host, 1 thread
+Headline workload (`value`) = BASELINE.json configs[1] ("c2"): 256 concurrent synthetic stereo streams, 20 Hz frames,
+2.5 s context (T = 50) per GPU.  The same command also measures, as sub-records under "configs" with their own
+`roofline` each, the other single-GPU configurations of BASELINE.json:
+  s4096_20hz  4096 streams x 20 Hz / T = 50   (the per-GPU shard of configs[3]: 32768 streams over 8 GPUs)
+  c3          4096 streams x 50 Hz / T = 250  (configs[2], the largest single-GPU configuration)
+  c5          bc + nod on one shared CPC trunk, 4096 streams (configs[4])
+`--gpus N` with N > 1 (and no WORLD_SIZE in the environment) re-executes itself under torch.distributed.run with N ranks,
+one per GPU; streams are sharded over the ranks with NO data-path collective (they are independent), every record is then
+the whole-job aggregate (units of all ranks / max-over-ranks time), so "s4096_20hz" at N = 8 IS configs[3].
+
+Prints ONE JSON line on rank 0 (contract in the task prompt): metric / value / unit / ... plus
+  "roofline":      dominant kernel (by summed time), HIP-event timed inside the timed region on the launch stream
+  "cpu_baseline":  the oracle (CPU restatement of the reference step) timed on this host (1 thread, and all physical cores)
+  "paced_latency": >= 6144 distinct streams in phase-staggered sub-ticks on a wall-clock schedule (the <= 10 ms p99 target)
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,37 +35,77 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TF = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact f32
+F16_MFMA_PEAK_TF = 2516.6     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16, dense
 HBM_PEAK_GBS = 8000.0
-GFLOP_PER_STREAM_FRAME = {(20, 50): 0.920, (50, 250): 4.505, (10, 50): 1.054}   # SURVEY.md §8d / BASELINE.md §3
+GFLOP_PER_STREAM_FRAME = {(20, 50): 0.920, (50, 250): 4.505, (10, 50): 1.054}   # dense count: SURVEY.md §8d / BASELINE.md §3
+
+WORKLOADS = {   # name -> (streams per GPU, frame_hz, ctx_sec, mode, default steps, default warmup)
+    "c2": (256, 20, 2.5, "vap", 100, 10),
+    "s4096_20hz": (4096, 20, 2.5, "vap", 20, 3),
+    "c3": (4096, 50, 5.0, "vap", 8, 2),
+    "c5": (4096, 20, 2.5, "bc+nod", 10, 2),
+}
+KERNEL_NAMES = {"ffn_block": "ffn_block_kernel", "attention": "attn_block_kernel", "conv_tail": "conv_tail_kernel",
+                "last_row": "last_block_kernel", "lstm": "lstm_kernel", "head": "head_kernel", "conv0": "conv0_kernel"}
 
 
 def macs_per_stream_frame(hz: int, T: int) -> dict:
-    """Useful multiply-accumulates per stream-frame (both channels) by kernel class."""
+    """EXECUTED multiply-accumulates per stream-frame (both channels) by kernel class of the default path (exact last-layer
+    pruning, absorbed last-layer K/V projections, cached layer-0 Q|K|V).  The attention classes count the DENSE T x T
+    products like SURVEY.md does (the kernels skip most of the causally masked tiles, see `attention_executed_fraction`)."""
     hop = 16000 // hz
     L = hop + 320
     P0 = L // 5; P1 = P0 // 4; P2 = P1 // 2; P3 = P2 // 2; P4 = P3 // 2; ncpc = P4 - 2
     D = 256
     rows = 2 * T
+    fused = T <= 64          # fused attention block (attention + projection + LN + cross-q) vs attention_mfma_kernel + GEMMs
+    attn = 5 * 2 * 4 * (T * T * 64 * 2)
     m = {
         "conv0": 2 * P0 * D * 10,
         "gemm_cn_relu": 2 * (P1 * 8 + P2 * 4 + P3 * 4 + ncpc * 4) * D * D,
         "lstm": 2 * ncpc * D * 4 * D + 2 * ncpc * D * D,                # recurrence (K=256) + fused downsample
         "gemm_bias_ln_gelu": 0,
-        # executed work with exact last-layer pruning (only the newest row of layer 3 is consumed):
-        "gemm_store": 2 * ncpc * D * 4 * D + 2 * D * 768,               # LSTM input projection + layer-0 QKV of the NEW row (others cached)
-        "gemm_resid_ln": 0,
+        "gemm_store": 2 * ncpc * D * 4 * D + 2 * D * 768                # LSTM input projection + layer-0 QKV of the NEW row (others cached)
+                      + (0 if fused else rows * 2 * D * D),             # long windows: the two cross-attention query projections
+        "gemm_resid_ln": 0 if fused else rows * 5 * D * D,              # long windows: the five output projections (+ residual + LN)
         "ffn_block": rows * D * (3 * 2 * 768 + 2 * 768 + 2 * 512),      # FFN x3 + QKV and cross-KV of layers 1, 2 (layer 3: absorbed)
         # layer 3 on one row per channel: 14 contractions (q, Wk^T q, Wv, proj, their cross twins, FFN) + two
         # 4-head single-query attentions over T rows of 256 (score + weighted sum)
         "last_row": 2 * (14 * D * D + 2 * 4 * T * D * 2),
         "gemm_gelu": 0, "gemm_resid": 0,
-        # fused attention block: dense T x T attention (as SURVEY counts it) of layers 0-2 + output
-        # projections (x5) + cross-attention query projections (x2)
-        "attention": 5 * 2 * 4 * (T * T * 64 * 2) + rows * 7 * D * D,
+        # dense T x T attention of layers 0-2 (+ in the fused block: output projections x5, cross-q projections x2)
+        "attention": attn + (rows * 7 * D * D if fused else 0),
         "head": 3 * D * D + 2 * D,
         "gather_ln": 0,
     }
     return m
+
+
+def attention_executed_fraction(T: int) -> float:
+    """Share of the dense T x T score / PV products the attention kernels execute: 32-row tiles, causal tiles jt <= it only."""
+    nt = (T + 31) // 32
+    if T <= 64:
+        return 1.0 if nt == 1 else 0.75       # fused block: 64 x 64 scores, tile (0,1) skipped
+    return (nt * (nt + 1) / 2) / (nt * nt)
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def physical_cores() -> int:
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
 
 
 def _cpu_worker(job):
@@ -68,7 +118,7 @@ def _cpu_worker(job):
     cpc, vap = W.synthetic_weights(0, hz, "vap")
     hop = 16000 // hz
     NF = 32
-    a = synth.dialogue_batch([widx], hop * NF).reshape(1, 2, NF, hop).transpose(2, 0, 1, 3)
+    a = synth.dialogue_batch([widx % 64], hop * NF).reshape(1, 2, NF, hop).transpose(2, 0, 1, 3)
     o = VapOracle(cpc, vap, hz, ctx_sec)
     st, fr = o.new_state(1), ServerFramer(1, hop)
     for i in range(int(ctx_sec * hz)):
@@ -80,267 +130,440 @@ def _cpu_worker(job):
     return n, time.perf_counter() - t1
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=256, help="concurrent streams per GPU")
-    ap.add_argument("--frame-hz", type=int, default=20)
-    ap.add_argument("--ctx-sec", type=float, default=2.5)
-    ap.add_argument("--cpu-baseline-sec", type=float, default=12.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-procs", type=int, default=-1,
-                    help="processes of the multi-core CPU leg (-1 = min(16, logical cores / 2), 0 = skip)")
-    ap.add_argument("--no-latency", action="store_true")
-    ap.add_argument("--groups", type=int, default=0, help="intra-tick overlap groups (0 = engine default)")
-    ap.add_argument("--mode", default="vap", choices=["vap", "bc", "nod", "bc+nod", "vap+bc+nod"],
-                    help="model variant (config 5: bc / nod); a+b = weight sets served on one shared CPC trunk "
-                         "(one stream-frame = one audio frame through the shared encoder and every listed model)")
-    ap.add_argument("--split-f16", action="store_true",
-                    help="opt-in: FFN-block contractions as fp32-accurate 3-term f16 split products (VAPX_FLAG_SPLIT_F16)")
-    ap.add_argument("--defer-join", action="store_true", help="with --groups > 1: let overlap groups free-run across ticks")
-    ap.add_argument("--subtick-streams", type=int, default=1024,
-                    help="sub-tick size for the <=10 ms latency leg (0 = skip)")
-    args = ap.parse_args()
-
-    import torch
-    from vap_realtime_amd import dist_util, engine, synth, weights as W
-    from vap_realtime_amd.sharding import shard_streams
-    rank, local_rank, world = dist_util.env_rank()
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dist = dist_util.init("nccl", torch.device("cuda", local_rank))
-
-    hz, S = args.frame_hz, args.streams
-    T = int(args.ctx_sec * hz)
-    hop = 16000 // hz
-    my_streams = shard_streams(S * world, world, rank)           # global stream ids of this rank
-    modes = args.mode.split("+")
-    cpc, vap = W.synthetic_weights(0, hz, modes[0])
-    eng = engine.Engine(W.pack_blob(cpc, vap, modes[0]), hz, args.ctx_sec, max_streams=S, device_id=local_rank,
-                        groups=args.groups, mode=modes[0], split_f16=args.split_f16)
-    followers = []
-    for k, m in enumerate(modes[1:]):                            # same cpc_model "file", own VAP state dict
-        f = engine.Engine(W.pack_blob(cpc, W.synthetic_weights(1 + k, hz, m)[1], m), hz, args.ctx_sec, max_streams=S,
-                          device_id=local_rank, groups=args.groups, mode=m)
-        f.attach_trunk(eng)
-        followers.append(f)
-
-    NF = 32                                                      # distinct audio frames, cycled
-    base = synth.dialogue_batch(my_streams[:min(S, 64)], hop * NF)   # [<=64,2,hop*NF]
+def synth_audio(stream_ids, S: int, hop: int, NF: int) -> np.ndarray:
+    """[NF, S, 2, hop] float32: seeded two-speaker dialogue for up to 64 streams, tiled (shifted / scaled) to S streams."""
+    from vap_realtime_amd import synth
+    base = synth.dialogue_batch(stream_ids[:min(S, 64)], hop * NF)
     reps = (S + base.shape[0] - 1) // base.shape[0]
-    audio = np.concatenate([np.roll(base, 97 * r, axis=2) * (1.0 - 0.01 * r) for r in range(reps)], 0)[:S]
-    audio = np.ascontiguousarray(audio.reshape(S, 2, NF, hop).transpose(2, 0, 1, 3))   # [NF,S,2,hop]
-    d_audio = torch.from_numpy(audio).cuda()
-    d_out = torch.zeros(S, engine.OUT_STRIDE, device="cuda")
-    d_out_f = [torch.zeros(S, engine.OUT_STRIDE, device="cuda") for _ in followers]
-    stream = torch.cuda.current_stream().cuda_stream
+    audio = np.concatenate([np.roll(base, 97 * r, axis=2) * (1.0 - 0.01 * (r % 50)) for r in range(reps)], 0)[:S]
+    return np.ascontiguousarray(audio.reshape(S, 2, NF, hop).transpose(2, 0, 1, 3))
 
-    def step(i):
-        eng.step_device(S, d_audio[i % NF].data_ptr(), hop, d_out.data_ptr(), stream=stream, defer_join=args.defer_join)
-        for f, o in zip(followers, d_out_f):
-            f.step_follow_device(S, o.data_ptr(), stream=stream)
 
-    def profile_enable(classes):
-        for e in [eng] + followers:
+class Workload:
+    """Engines + resident synthetic audio of one configuration on this rank."""
+
+    def __init__(self, S, hz, ctx_sec, mode, rank, world, local_rank, groups=0, split_f16=False):
+        import torch
+        from vap_realtime_amd import engine, weights as W
+        from vap_realtime_amd.sharding import shard_streams
+        self.S, self.hz, self.ctx_sec, self.mode = S, hz, ctx_sec, mode
+        self.T = int(ctx_sec * hz)
+        self.hop = 16000 // hz
+        self.modes = mode.split("+")
+        self.my_streams = shard_streams(S * world, world, rank)         # global stream ids of this rank
+        self.cpc, self.vap = W.synthetic_weights(0, hz, self.modes[0])
+        self.eng = engine.Engine(W.pack_blob(self.cpc, self.vap, self.modes[0]), hz, ctx_sec, max_streams=S, device_id=local_rank,
+                                 groups=groups, mode=self.modes[0], split_f16=split_f16)
+        self.followers = []
+        for k, m in enumerate(self.modes[1:]):                          # same cpc_model "file", own VAP state dict
+            f = engine.Engine(W.pack_blob(self.cpc, W.synthetic_weights(1 + k, hz, m)[1], m), hz, ctx_sec, max_streams=S,
+                              device_id=local_rank, groups=groups, mode=m)
+            f.attach_trunk(self.eng)
+            self.followers.append(f)
+        self.NF = 32 if S * self.hop <= 1024 * 800 else 8               # distinct audio frames, cycled
+        self.audio = synth_audio(self.my_streams, S, self.hop, self.NF)
+        self.d_audio = torch.from_numpy(self.audio).cuda()
+        self.d_out = torch.zeros(S, engine.OUT_STRIDE, device="cuda")
+        self.d_out_f = [torch.zeros(S, engine.OUT_STRIDE, device="cuda") for _ in self.followers]
+        self.stream = torch.cuda.current_stream().cuda_stream
+
+    def step(self, i, defer_join=False):
+        self.eng.step_device(self.S, self.d_audio[i % self.NF].data_ptr(), self.hop, self.d_out.data_ptr(), stream=self.stream,
+                             defer_join=defer_join)
+        for f, o in zip(self.followers, self.d_out_f):
+            f.step_follow_device(self.S, o.data_ptr(), stream=self.stream)
+
+    def profile_enable(self, classes):
+        for e in [self.eng] + self.followers:
             e.profile_enable(classes)
 
-    def profile_read():
+    def profile_read(self):
         tot = {}
-        for e in [eng] + followers:
+        for e in [self.eng] + self.followers:
             for k, (ms, cnt) in e.profile_read().items():
                 a = tot.get(k, (0.0, 0))
                 tot[k] = (a[0] + ms, a[1] + cnt)
         return tot
 
+    def close(self):
+        for f in self.followers:
+            f.close()
+        self.eng.close()
+
+
+def load_traffic(key: str, dominant: str):
+    """HBM bytes / launch of the dominant kernel from the committed PMC passes (separate rocprofv3 --pmc runs of this very
+    command, profiles/pmc_traffic.json; counters cannot be collected inside a timed run)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pt = json.load(f)
+        return pt.get(key, {}).get(dominant, {}).get("bytes_per_launch_corrected")
+    except Exception:
+        return None
+
+
+def run_workload(name, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=0, split_f16=False, defer_join=False):
+    """Prime the window, find the dominant kernel class, then time exactly `steps` ticks bracketed by barrier + device
+    synchronise; returns (record, workload) — the caller closes the workload."""
+    import torch
+    from vap_realtime_amd import dist_util, engine
+    rank, local_rank, world, dist = ctx
+    wl = Workload(S, hz, ctx_sec, mode, rank, world, local_rank, groups=groups, split_f16=split_f16)
+    T = wl.T
+
     def barrier():
         dist_util.barrier(dist, torch.cuda.synchronize)
 
-    # prime the context window (so the timed region is the steady state), then a profiled pass to
-    # find the dominant kernel class
-    for i in range(T):
-        step(i)
+    for i in range(T):                               # fill the context window: the timed region is the steady state
+        wl.step(i)
     torch.cuda.synchronize()
-    profile_enable(range(13))
-    profile_read()
-    NP = 5
+    wl.profile_enable(range(13))
+    wl.profile_read()
+    NP = 3 if S * T > 100000 else 5
     for i in range(NP):
-        step(i)
-    prof_all = profile_read()
-    breakdown = {k: v[0] / NP for k, v in prof_all.items()}
+        wl.step(i)
+    breakdown = {k: v[0] / NP for k, v in wl.profile_read().items()}
     dominant = max(breakdown, key=breakdown.get)
     dom_id = [k for k, v in engine.PROF_CLASSES.items() if v == dominant][0]
-    profile_enable([dom_id])
-    profile_read()
+    wl.profile_enable([dom_id])
+    wl.profile_read()
 
-    for i in range(args.warmup):
-        step(i)
+    for i in range(warmup):
+        wl.step(i)
     barrier()
-    profile_read()
+    wl.profile_read()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    for i in range(steps):
+        wl.step(i, defer_join=defer_join)
+    if defer_join:
+        wl.eng.join(wl.stream)
     barrier()
     dt = time.perf_counter() - t0
-    dom_ms, dom_launches = profile_read()[dominant]
-    profile_enable([])
+    dom_ms, dom_launches = wl.profile_read()[dominant]
+    wl.profile_enable([])
     dt = dist_util.max_over_ranks(dist, dt, "cuda")
-    assert torch.isfinite(d_out[:, :6]).all(), "non-finite outputs"
+    assert torch.isfinite(wl.d_out[:, :6]).all(), "non-finite outputs"
+    assert not wl.d_out[:, engine.OUT_STATUS].any(), "engine flagged non-finite rows"
 
-    frames = S * world * args.steps
-    value = frames / dt
+    value = S * world * steps / dt
     macs = macs_per_stream_frame(hz, T)
-    if len(modes) > 1:   # every model runs its own downsample + transformer; the encoder classes run once
+    nm = len(wl.modes)
+    if nm > 1:   # every model runs its own downsample + transformer; the encoder classes run once
         shared = ("conv0", "gemm_cn_relu", "conv_tail", "lstm")
-        macs = {k: v * (1 if k in shared else len(modes)) for k, v in macs.items()}
-    launches_per_step = dom_launches / args.steps
+        macs = {k: v * (1 if k in shared else nm) for k, v in macs.items()}
+    launches_per_step = dom_launches / steps
     flop_per_launch = 2.0 * macs[dominant] * S / launches_per_step
     avg_launch_s = dom_ms * 1e-3 / dom_launches
     achieved_tf = flop_per_launch / avg_launch_s / 1e12
-    gflop_sf = GFLOP_PER_STREAM_FRAME.get((hz, T), 2.0 * sum(macs.values()) / 1e9)
-
-    traffic = None
-    try:   # HBM bytes/launch of the dominant kernel from the committed PMC passes (cannot be collected live)
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            pt = json.load(f)
-        if S == 256 and hz == 20 and T == 50:
-            traffic = pt["256x20hz_T50"].get(dominant, {}).get("bytes_per_launch_corrected")
-    except Exception:
-        traffic = None
-
-    result = {
-        "metric": "VAP frames/sec (concurrent 16 kHz stereo streams, one frame per stream per step)",
-        "value": value,
-        "unit": "frames/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic (seeded two-speaker dialogue audio, seeded random weights)",
-        "config": {"workload": f"{S} concurrent synthetic stereo streams per GPU, {args.ctx_sec} s / {hz} Hz (T={T}), 1 MI355X per rank",
-                   "streams_per_gpu": S, "frame_hz": hz, "ctx_frames": T, "mode": args.mode, "gemm_arithmetic": ("fp32 MFMA; FFN block: f16x3 split products, fp32 accumulate" if args.split_f16 else "fp32 MFMA"), "parallelism": f"stream-sharded x{world}, no collective"},
+    dense_gflop = GFLOP_PER_STREAM_FRAME.get((hz, T))
+    exec_gflop = 2.0 * sum(macs.values()) / 1e9      # executed, attention still counted dense
+    fa = attention_executed_fraction(T)
+    exec_gflop_causal = exec_gflop - 2.0 * (1.0 - fa) * 5 * 2 * 4 * (T * T * 64 * 2) * nm / 1e9
+    peak = FP32_MFMA_PEAK_TF
+    kernel = KERNEL_NAMES.get(dominant, f"gemm_f32_kernel ({dominant})")
+    if dominant == "attention" and T > 64:
+        kernel = "attention_mfma_kernel"
+    roof = {"bound": "mfma", "kernel": kernel, "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tf / peak,
+            "traffic": load_traffic(f"{S}x{hz}hz_T{T}" + ("" if mode == "vap" else "_" + mode), dominant),
+            "avg_launch_us": avg_launch_s * 1e6, "launches_per_step": launches_per_step, "gflop_per_launch": flop_per_launch / 1e9,
+            "flop_count": "algorithmic FLOPs of the launch (dense T x T for attention), MACs x 2"}
+    if dominant == "attention":
+        roof["frac_executed_causal"] = roof["frac"] * fa
+    if split_f16:
+        roof["note"] = ("GEMM-shaped contractions run as 3 f16 MFMA products each: the fp32-MFMA peak is NOT the bound of this path "
+                        "(3/16 of the MFMA time); its bound is the L2 -> VGPR weight stream")
+    rec = {
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+        "config": {"workload": f"{name}: {S} concurrent synthetic stereo streams per GPU, {ctx_sec} s / {hz} Hz (T={T}), mode {mode}, 1 MI355X per rank",
+                   "streams_per_gpu": S, "streams_total": S * world, "frame_hz": hz, "ctx_frames": T, "mode": mode,
+                   "gemm_arithmetic": ("f16x3 split products, fp32 accumulate" if split_f16 else "fp32 MFMA"),
+                   "parallelism": f"stream-sharded x{world}, no collective"},
         "realtime_streams_sustained": value / hz,
-        "step_tflops": value * gflop_sf / 1e3,
-        "step_frac_of_fp32_mfma_peak": value * gflop_sf / 1e3 / (FP32_MFMA_PEAK_TF * world),
-        "roofline": {"bound": "mfma", "kernel": {"ffn_block": "ffn_block_kernel", "attention": "attn_block_kernel"}.get(dominant, f"gemm_f32_kernel ({dominant})"), "achieved": achieved_tf,
-                     "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": achieved_tf / FP32_MFMA_PEAK_TF,
-                     "traffic": traffic, "avg_launch_us": avg_launch_s * 1e6, "launches_per_step": launches_per_step,
-                     "gflop_per_launch": flop_per_launch / 1e9},
+        "executed_gflop_per_stream_frame": exec_gflop, "executed_gflop_per_stream_frame_causal_attention": exec_gflop_causal,
+        "executed_tflops": value * exec_gflop / 1e3,
+        "executed_frac_of_fp32_mfma_peak": value * exec_gflop / 1e3 / (FP32_MFMA_PEAK_TF * world),
+        "roofline": roof,
         "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1])},
     }
+    if dense_gflop and nm == 1:
+        rec["dense_gflop_per_stream_frame"] = dense_gflop
+        rec["dense_tflops"] = value * dense_gflop / 1e3
+        rec["dense_frac_of_fp32_mfma_peak"] = value * dense_gflop / 1e3 / (FP32_MFMA_PEAK_TF * world)
+    return rec, wl
 
-    if rank == 0 and world == 1 and not args.no_latency and not followers and args.groups <= 1:
+
+def paced_latency(cpc, vap, hz, ctx_sec, local_rank, seconds, target_ms=10.0, max_util=0.85):
+    """The north-star latency target measured, not extrapolated: ONE engine holding G x Ssub DISTINCT streams, its G
+    sub-batches phase-staggered over the frame period (50 ms at 20 Hz) on a wall-clock schedule for `seconds`;
+    latency of a sub-tick = its scheduled audio-ready time -> results on the host (pinned H2D + kernels + D2H + sync,
+    including any wait behind a late predecessor).  A short calibration picks the largest G x Ssub whose sub-tick service
+    time keeps the GPU under `max_util`; if the paced run misses p99 <= target it is repeated one group smaller."""
+    from vap_realtime_amd import engine, weights as W
+    period = 1.0 / hz
+    hop = 16000 // hz
+    T = int(ctx_sec * hz)
+    blob = W.pack_blob(cpc, vap)
+    Ssub_opts = (1024, 768, 512)
+    Gmax = 12
+    eng = engine.Engine(blob, hz, ctx_sec, max_streams=Gmax * max(Ssub_opts), max_batch=max(Ssub_opts), device_id=local_rank)
+    NF = 8
+    base = synth_audio(list(range(64)), max(Ssub_opts), hop, NF)          # [NF, Ssub, 2, hop]
+    pin_in = [engine.pinned_empty((max(Ssub_opts), 2, hop)) for _ in range(NF)]
+    for i in range(NF):
+        pin_in[i][...] = base[i]
+    pin_out = engine.pinned_empty((max(Ssub_opts), engine.OUT_STRIDE))
+
+    def service_time(Ssub, reps=24):
+        ids = np.arange(Ssub, dtype=np.int32)
+        ts = []
+        for i in range(reps):
+            t1 = time.perf_counter()
+            eng.step(pin_in[i % NF][:Ssub], ids, out=pin_out)
+            ts.append(time.perf_counter() - t1)
+        return float(np.percentile(ts[4:], 95))
+
+    calib = {}
+    best = None
+    for Ssub in Ssub_opts:
+        sv = service_time(Ssub)
+        calib[Ssub] = sv * 1e3
+        G = min(Gmax, int(max_util * period / sv))
+        if sv * 1e3 <= 0.8 * target_ms and G >= 1 and (best is None or G * Ssub > best[0] * best[1]):
+            best = (G, Ssub)
+    out = {"calibration_subtick_p95_ms": calib, "frame_period_ms": period * 1e3, "target_p99_ms": target_ms, "max_utilisation": max_util,
+           "method": "one engine, G phase-staggered sub-batches of DISTINCT streams per frame period, wall-clock schedule; latency = "
+                     "scheduled audio-ready -> results on host (pinned staging both ways)", "runs": []}
+    if best is None:
+        eng.close()
+        out["sustained_streams"] = 0
+        return out
+    G, Ssub = best
+    for attempt in range(2):
+        for s in range(G * Ssub):                     # every trial starts from clean streams (queued, applied by the next step)
+            eng.reset_stream(s)
+        idsets = [np.arange(g * Ssub, (g + 1) * Ssub, dtype=np.int32) for g in range(G)]
+        n_periods = max(T + 20, int(seconds / period))
+        lat, busy = [], 0.0
+        t_start = time.perf_counter() + 0.01
+        for k in range(n_periods):
+            for g in range(G):
+                ready = t_start + k * period + g * period / G
+                while True:                            # wait for the audio of this sub-batch to be "ready"
+                    now = time.perf_counter()
+                    if now >= ready:
+                        break
+                    if ready - now > 2e-4:
+                        time.sleep((ready - now) * 0.5)
+                t1 = time.perf_counter()
+                eng.step(pin_in[(k + g) % NF][:Ssub], idsets[g], out=pin_out)
+                t2 = time.perf_counter()
+                busy += t2 - t1
+                if k >= T:                             # window full: steady state
+                    lat.append((t2 - ready) * 1e3)
+        wall = time.perf_counter() - t_start
+        lat = np.asarray(lat)
+        run = {"groups": G, "sub_tick_streams": Ssub, "streams": G * Ssub, "seconds": wall, "sub_ticks_timed": int(lat.size),
+               "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)), "max_ms": float(lat.max()),
+               "gpu_busy_fraction": busy / wall, "late_fraction": float((lat > target_ms).mean())}
+        out["runs"].append(run)
+        if run["p99_ms"] <= target_ms and run["gpu_busy_fraction"] <= max_util + 0.02:
+            out["sustained_streams"] = G * Ssub
+            out.update({k: run[k] for k in ("groups", "sub_tick_streams", "p50_ms", "p99_ms", "max_ms", "gpu_busy_fraction")})
+            break
+        G -= 1
+        if G < 1:
+            break
+    else:
+        out["sustained_streams"] = 0
+    out.setdefault("sustained_streams", 0)
+    eng.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS), help="headline workload (`value`)")
+    ap.add_argument("--configs", default="s4096_20hz,c3,c5",
+                    help="comma list of further workloads measured as sub-records under \"configs\" ('' = none)")
+    ap.add_argument("--streams", type=int, default=None, help="override: concurrent streams per GPU of the headline workload")
+    ap.add_argument("--frame-hz", type=int, default=None)
+    ap.add_argument("--ctx-sec", type=float, default=None)
+    ap.add_argument("--mode", default=None, choices=["vap", "bc", "nod", "bc+nod", "vap+bc+nod"],
+                    help="override: model variant; a+b = weight sets served on one shared CPC trunk (one stream-frame = one audio "
+                         "frame through the shared encoder and every listed model)")
+    ap.add_argument("--cpu-baseline-sec", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-procs", type=int, default=-1,
+                    help="processes of the multi-core CPU leg (-1 = every physical core, 0 = skip)")
+    ap.add_argument("--no-latency", action="store_true", help="skip the latency legs and the overlap / split-precision side records")
+    ap.add_argument("--paced-sec", type=float, default=20.0, help="duration of the paced many-stream latency run (0 = skip)")
+    ap.add_argument("--groups", type=int, default=0, help="intra-tick overlap groups (0 = engine default)")
+    ap.add_argument("--split-f16", action="store_true",
+                    help="opt-in: GEMM-shaped contractions as fp32-accurate 3-term f16 split products (VAPX_FLAG_SPLIT_F16)")
+    ap.add_argument("--defer-join", action="store_true", help="with --groups > 1: let overlap groups free-run across ticks")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="multi-rank plumbing check without a GPU: spawn, rendezvous, shard the streams, barrier, print the ranks")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # one process per GPU: re-execute under torch.distributed.run exactly as the driver would launch us
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", f"--master-port={free_port()}", os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    import torch
+    from vap_realtime_amd import dist_util
+    from vap_realtime_amd.sharding import shard_streams
+    rank, local_rank, world = dist_util.env_rank()
+    pinned = dist_util.pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+
+    if args.rendezvous_only:
+        dist = dist_util.init("gloo")
+        S = WORKLOADS["s4096_20hz"][0]
+        mine = shard_streams(S * world, world, rank)
+        ends = dist_util.gather_ints(dist, [mine[0], mine[-1], len(mine), os.getpid()])
+        dist_util.barrier(dist)
+        worst = dist_util.max_over_ranks(dist, 0.001 * (rank + 1))
+        if dist is not None:
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"rendezvous_only": True, "n_gpus": world, "shards": [e[:3] for e in ends], "pids": [e[3] for e in ends],
+                              "max_over_ranks": worst, "cores_pinned": pinned}))
+        return
+
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dist = dist_util.init(args.backend, torch.device("cuda", local_rank))
+    ctx = (rank, local_rank, world, dist)
+
+    S, hz, ctx_sec, mode, dsteps, dwarm = WORKLOADS[args.workload]
+    S = args.streams or S
+    hz = args.frame_hz or hz
+    ctx_sec = args.ctx_sec or ctx_sec
+    mode = args.mode or mode
+    steps = args.steps if args.steps is not None else dsteps
+    warmup = args.warmup if args.warmup is not None else dwarm
+    head, wl = run_workload(args.workload, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=args.groups, split_f16=args.split_f16,
+                            defer_join=args.defer_join)
+    T = wl.T
+    result = {
+        "metric": "VAP frames/sec (concurrent 16 kHz stereo streams, one frame per stream per step)",
+        "value": head["value"], "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (seeded two-speaker dialogue audio, seeded random weights)",
+    }
+    result.update({k: v for k, v in head.items() if k not in result})
+    result["config"] = head["config"]
+    # kept from round 1 for continuity: throughput priced with the reference's DENSE FLOP count
+    if "dense_tflops" in head:
+        result["step_tflops"] = head["dense_tflops"]
+        result["step_frac_of_fp32_mfma_peak"] = head["dense_frac_of_fp32_mfma_peak"]
+
+    side = rank == 0 and world == 1 and not args.no_latency and not wl.followers
+    from vap_realtime_amd import engine, weights as W
+    if side and args.groups <= 1:
         # the same workload with the tick split into two overlap groups that free-run across ticks (VAPX_DEFER_JOIN):
         # reported next to `value`, not as `value`, because co-running kernels stretch each other's launch time and the
         # per-kernel roofline above would stop meaning anything
-        eng_g = engine.Engine(W.pack_blob(cpc, vap, modes[0]), hz, args.ctx_sec, max_streams=S, device_id=local_rank,
-                              groups=2, mode=modes[0])
+        eng_g = engine.Engine(W.pack_blob(wl.cpc, wl.vap, wl.modes[0]), hz, ctx_sec, max_streams=S, device_id=local_rank,
+                              groups=2, mode=wl.modes[0])
         for i in range(T + 5):
-            eng_g.step_device(S, d_audio[i % NF].data_ptr(), hop, d_out.data_ptr(), stream=stream, defer_join=True)
-        eng_g.join(stream)
+            eng_g.step_device(S, wl.d_audio[i % wl.NF].data_ptr(), wl.hop, wl.d_out.data_ptr(), stream=wl.stream, defer_join=True)
+        eng_g.join(wl.stream)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for i in range(args.steps):
-            eng_g.step_device(S, d_audio[i % NF].data_ptr(), hop, d_out.data_ptr(), stream=stream, defer_join=True)
-        eng_g.join(stream)
+        for i in range(steps):
+            eng_g.step_device(S, wl.d_audio[i % wl.NF].data_ptr(), wl.hop, wl.d_out.data_ptr(), stream=wl.stream, defer_join=True)
+        eng_g.join(wl.stream)
         torch.cuda.synchronize()
         dtg = time.perf_counter() - t1
-        result["overlap_groups"] = {"groups": 2, "defer_join": True, "value": S * args.steps / dtg, "unit": "frames/s",
-                                    "ms_per_step": dtg / args.steps * 1e3}
+        result["overlap_groups"] = {"groups": 2, "defer_join": True, "value": S * steps / dtg, "unit": "frames/s",
+                                    "ms_per_step": dtg / steps * 1e3}
         eng_g.close()
 
-    if rank == 0 and world == 1 and not args.no_latency and not followers and not args.split_f16:
-        # the same workload on the opt-in split-precision path (VAPX_FLAG_SPLIT_F16): every GEMM-shaped contraction as
-        # three f16 MFMA products with fp32 accumulation — same deviation from the reference as the fp32-MFMA path
-        # (tests/test_split_precision_gpu.py).  Reported next to `value`, never as `value`.
-        eng_s = engine.Engine(W.pack_blob(cpc, vap, modes[0]), hz, args.ctx_sec, max_streams=S, device_id=local_rank,
-                              mode=modes[0], split_f16=True)
-        for i in range(T + 5):
-            eng_s.step_device(S, d_audio[i % NF].data_ptr(), hop, d_out.data_ptr(), stream=stream)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            eng_s.step_device(S, d_audio[i % NF].data_ptr(), hop, d_out.data_ptr(), stream=stream)
-        torch.cuda.synchronize()
-        dts = time.perf_counter() - t1
-        assert torch.isfinite(d_out[:, :6]).all(), "non-finite outputs on the split-precision path"
-        result["split_f16"] = {"value": S * args.steps / dts, "unit": "frames/s", "ms_per_step": dts / args.steps * 1e3,
-                               "arithmetic": "x = hi + lo (f16); hi.hi + lo.hi + hi.lo on v_mfma_f32_32x32x16_f16, fp32 accumulate; "
-                                             "FFN block, attention projections, conv / projection GEMMs; opt-in, not the default"}
-        eng_s.close()
-
-    if rank == 0 and not args.no_latency and not followers:
-        # host-inclusive tick latency: host audio -> results on host (H2D + kernels + D2H + sync)
+    if side:
+        # host-inclusive tick latency: host audio -> results on host (pinned H2D + kernels + D2H + sync)
+        pin_in = engine.pinned_empty((S, 2, wl.hop))
+        pin_out = engine.pinned_empty((S, engine.OUT_STRIDE))
         lat = []
         for i in range(210):
-            a = audio[i % NF]
+            pin_in[...] = wl.audio[i % wl.NF]
             t1 = time.perf_counter()
-            eng.step(a)
+            wl.eng.step(pin_in, out=pin_out)
             lat.append((time.perf_counter() - t1) * 1e3)
         lat = np.array(lat[10:])
         result["latency_ms_host_inclusive"] = {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)),
-                                               "max": float(lat.max())}
+                                               "max": float(lat.max()), "staging": "pinned (vapx_host_alloc)"}
+        del pin_in, pin_out
+    cpc, vap = wl.cpc, wl.vap
+    audio_one = wl.audio[:, :1].copy()                       # [NF,1,2,hop] for the CPU leg
+    NF = wl.NF
+    wl.close()
+    del wl
+    torch.cuda.empty_cache()
 
-    if rank == 0 and not args.no_latency and args.subtick_streams > 0 and hz == 20 and args.mode == "vap":
-        # "concurrent streams at <= 10 ms/frame p99": a frame period (50 ms at 20 Hz) is filled with
-        # phase-staggered sub-ticks; each sub-tick is host audio -> results on host.  Streams one GPU
-        # sustains = sub-tick size x (sub-ticks that fit into one frame period at the p99 latency).
-        Ssub = args.subtick_streams
-        eng2 = engine.Engine(W.pack_blob(cpc, vap), hz, args.ctx_sec, max_streams=Ssub, device_id=local_rank)
-        a2 = np.ascontiguousarray(np.concatenate([audio] * ((Ssub + S - 1) // S), axis=1)[:, :Ssub])
-        for i in range(T):
-            eng2.step(a2[i % NF])
-        lat2 = []
-        for i in range(210):                                      # 200 timed sub-ticks: p99 is a real percentile
-            t1 = time.perf_counter()
-            eng2.step(a2[i % NF])
-            lat2.append((time.perf_counter() - t1) * 1e3)
-        lat2 = np.array(lat2[10:])
-        p99 = float(np.percentile(lat2, 99))
-        period_ms = 1000.0 / hz
-        result["concurrent_streams_at_10ms"] = {
-            "sub_tick_streams": Ssub, "samples": int(lat2.size), "max_ms": float(lat2.max()), "p50_ms": float(np.percentile(lat2, 50)), "p99_ms": p99,
-            "sub_ticks_per_frame_period": int(period_ms // p99),
-            "sustained_streams": int(period_ms // p99) * Ssub if p99 <= 10.0 else 0,
-            "note": "host-inclusive (pageable H2D + kernels + D2H + sync); streams = sub-tick size x floor(50 ms / p99)"}
-        eng2.close()
+    if side and not args.split_f16 and mode == "vap":
+        # the same workload on the opt-in split-precision path (VAPX_FLAG_SPLIT_F16): every GEMM-shaped contraction as
+        # three f16 MFMA products with fp32 accumulation — same deviation from the reference as the fp32-MFMA path
+        # (tests/test_split_precision_gpu.py).  Reported next to `value`, never as `value`, with its own roofline record.
+        rec, w2 = run_workload(args.workload + "_split_f16", S, hz, ctx_sec, mode, steps, warmup, ctx, split_f16=True)
+        w2.close()
+        rec["arithmetic"] = ("x = hi + lo (f16); hi.hi + lo.hi + hi.lo on v_mfma_f32_32x32x16_f16, fp32 accumulate; FFN block, attention "
+                             "projections, conv / projection GEMMs; opt-in, not the default")
+        result["split_f16"] = rec
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "vap":
+    # ---- the other single-GPU configurations of BASELINE.json, each with its own roofline ----
+    result["configs"] = {}
+    for name in [c for c in args.configs.split(",") if c]:
+        if name == args.workload and not (args.streams or args.frame_hz or args.ctx_sec or args.mode):
+            continue
+        cS, chz, cctx, cmode, csteps, cwarm = WORKLOADS[name]
+        rec, w2 = run_workload(name, cS, chz, cctx, cmode, csteps, cwarm, ctx)
+        w2.close()
+        del w2
+        torch.cuda.empty_cache()
+        result["configs"][name] = rec
+
+    if rank == 0 and world == 1 and not args.no_latency and args.paced_sec > 0 and hz == 20 and mode == "vap":
+        result["paced_latency"] = paced_latency(cpc, vap, hz, ctx_sec, local_rank, args.paced_sec)
+        result["concurrent_streams_at_10ms"] = result["paced_latency"].get("sustained_streams", 0)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and mode == "vap":
         from oracle.vap_oracle import ServerFramer, VapOracle
         torch.set_num_threads(1)
-        o = VapOracle(cpc, vap, hz, args.ctx_sec)
-        st, fr = o.new_state(1), ServerFramer(1, hop)
-        one = audio[:, :1]                                        # [NF,1,2,hop]
+        o = VapOracle(cpc, vap, hz, ctx_sec)
+        st, fr = o.new_state(1), ServerFramer(1, 16000 // hz)
         for i in range(T):                                        # fill the window (not timed)
-            o.step(fr.frame(one[i % NF]), st)
+            o.step(fr.frame(audio_one[i % NF]), st)
         n, t1 = 0, time.perf_counter()
         while time.perf_counter() - t1 < args.cpu_baseline_sec:
-            o.step(fr.frame(one[n % NF]), st)
+            o.step(fr.frame(audio_one[n % NF]), st)
             n += 1
         cdt = time.perf_counter() - t1
         result["cpu_baseline"] = {"value": n / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
-                                  "sample": f"{n} frames of 1 stream (batch 1, window full, torch-CPU fp32, 1 thread) in {cdt:.1f} s; host has {os.cpu_count()} logical cores",
+                                  "sample": f"{n} frames of 1 stream (batch 1, window full, torch-CPU fp32, 1 thread) in {cdt:.1f} s; host has "
+                                            f"{physical_cores()} physical / {os.cpu_count()} logical cores",
                                   "ms_per_frame": cdt / n * 1e3}
-        P = args.cpu_procs if args.cpu_procs >= 0 else max(1, min(16, (os.cpu_count() or 2) // 2))
+        P = args.cpu_procs if args.cpu_procs >= 0 else physical_cores()
         if P > 1:
-            # the reference deployed on every core: P independent single-threaded processes (one stream each), as
-            # SURVEY.md §8d asks; aggregate = sum of the per-process rates over the common window
+            # the reference deployed on every core: P independent single-threaded processes (one stream each), P = the
+            # host's physical cores (SURVEY.md §8d); aggregate = sum of the per-process rates over the common window
             import multiprocessing as mp
+            try:
+                os.sched_setaffinity(0, range(os.cpu_count() or 1))   # the workers must not inherit this rank's core pinning
+            except Exception:
+                pass
             with mp.get_context("spawn").Pool(P) as pool:
-                res = pool.map(_cpu_worker, [(i, hz, args.ctx_sec, 8.0) for i in range(P)])
+                res = pool.map(_cpu_worker, [(i, hz, ctx_sec, 8.0) for i in range(P)], chunksize=1)
             agg = sum(n_ / dt_ for n_, dt_ in res)
             result["cpu_baseline_multiprocess"] = {
                 "value": agg, "unit": "frames/s", "cores": P, "kind": "port",
-                "sample": f"{P} single-threaded oracle processes x 8 s, one stream each ({sum(r[0] for r in res)} frames); "
-                          f"host has {os.cpu_count()} logical cores", "per_core": agg / P}
-    for f in followers:
-        f.close()
-    eng.close()
+                "sample": f"{P} single-threaded oracle processes (= physical cores) x 8 s, one stream each ({sum(r[0] for r in res)} frames); "
+                          f"host has {physical_cores()} physical / {os.cpu_count()} logical cores", "per_core": agg / P}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VAPX_ABI_VERSION 1
+#define VAPX_ABI_VERSION 2
 
 /* error codes */
 #define VAPX_OK 0
@@ -41,8 +41,12 @@ extern "C" {
 #define VAPX_E_NOMEM (-3)
 #define VAPX_E_RANGE (-4)    /* stream id / batch size out of range */
 #define VAPX_E_NODEVICE (-5) /* no gfx950 device visible */
-#define VAPX_E_NUMERIC (-6)  /* host-output vapx_step only: a stream produced non-finite p_now / p_future / VAD (NaN or Inf audio,
-                                or |activation| >= 65504 on the split-precision path); the out block is still filled */
+#define VAPX_E_NUMERIC (-6)  /* host-output vapx_step only: at least one stream produced non-finite p_now / p_future / VAD / aux
+                                probabilities (a poisoned LSTM / ring state, Inf audio, or |activation| >= 65504 on the
+                                split-precision path).  PER STREAM, not per call: the out block is complete, every other row is
+                                valid, the offending rows carry VAPX_OUT_STATUS = 1 and vapx_bad_slots() lists them; reset those
+                                streams and keep serving the rest.  NaN audio SAMPLES do not trigger it: the ReLU after the first
+                                ChannelNorm is fmaxf(y, 0), which maps NaN to 0 (torch.relu would propagate it). */
 
 /* model variants: which heads are evaluated (vap_main.py:290-307, vap_bc_main.py:272-277,
  * vap_nod_main.py:273-279) */
@@ -56,9 +60,12 @@ extern "C" {
 #define VAPX_OUT_HOST 0
 #define VAPX_OUT_DEVICE 2
 #define VAPX_IDS_DEVICE 4 /* stream_ids points to device memory (default: host) */
-#define VAPX_DEFER_JOIN 8 /* with overlap groups > 1 and VAPX_OUT_DEVICE: do not make hip_stream wait for the groups at the
-                             end of the step; the caller orders consumers of `out` with vapx_join.  Lets group g's next tick
-                             start while other groups still finish this one (phase-staggered sub-ticks). */
+#define VAPX_DEFER_JOIN 8 /* with overlap groups > 1: do not make hip_stream wait for the groups at the end of the step; the
+                             caller orders consumers of `out` with vapx_join.  Lets group g's next tick start while other
+                             groups still finish this one.  Honoured only when the whole step is device-resident
+                             (VAPX_AUDIO_DEVICE | VAPX_OUT_DEVICE, ids NULL or VAPX_IDS_DEVICE) — otherwise ignored; a step
+                             whose n (or group split) differs from the previous one, or that has resets pending, first
+                             joins the previous tick's groups itself. */
 
 /* vapx_config.flags */
 #define VAPX_FLAG_GROUPS_MASK 0xF     /* bits 0-3: intra-tick overlap groups (0 = default 1 = none, max 8) */
@@ -79,6 +86,8 @@ extern "C" {
 #define VAPX_OUT_AUX 6       /* [4]  bc: {-, p_bc_react, p_bc_emo, -}; nod: {-, short, long, long_p} */
 #define VAPX_OUT_NVALID 10   /* [1]  n = rows in the context window this frame (as float) */
 #define VAPX_OUT_VAD_LOGIT 11 /* [2] va_classifier outputs before the sigmoid (what the training-style forward() returns) */
+#define VAPX_OUT_STATUS 13   /* [1]  0 = ok, 1 = this row's probabilities are not finite (see VAPX_E_NUMERIC); written on device,
+                                      so the device-output path carries it too */
 #define VAPX_OUT_LOGITS 16   /* [256] vap_head logits of the newest row  vap_main.py:290;
                                       nod mode: p_bc of rows 0..n-1 instead (vap_nod_main.py:276 quirk) */
 #define VAPX_OUT_E 272       /* [2*256] this frame's embeddings e1,e2   vap_main.py:272 */
@@ -109,17 +118,29 @@ int vapx_create(const vapx_config* cfg, const float* weights_blob, size_t n_floa
 void vapx_destroy(vapx_handle h);
 
 /* Stands in for VAPRealTime.process_vap (vap_main.py:249-335) for n streams at once.
- *   stream_ids : n ids in [0,max_streams), all distinct; NULL means 0..n-1.
+ *   stream_ids : n ids in [0,max_streams), all distinct (host ids are checked: VAPX_E_RANGE / VAPX_E_INVAL for a duplicate;
+ *                device ids are the caller's responsibility); NULL means 0..n-1.
  *   audio      : fp32 [n][2][samples_per_ch].  samples_per_ch == hop (=16000/frame_hz): new
  *                samples only, the engine prepends its own 320-sample carry like proc_serv_in
  *                (vap_main.py:397-409).  samples_per_ch == hop+320: a complete frame exactly as
  *                process_vap receives x1/x2 (carry supplied by the caller, vap_offline.py:51-61);
  *                the engine's carry is then set to the frame's last 320 samples.
  *   out        : fp32 [n][VAPX_OUT_STRIDE].
- *   flags      : VAPX_AUDIO_* | VAPX_OUT_* | VAPX_IDS_DEVICE
- *   hip_stream : hipStream_t to order the work on (NULL = default stream). */
+ *   flags      : VAPX_AUDIO_* | VAPX_OUT_* | VAPX_IDS_DEVICE | VAPX_DEFER_JOIN
+ *   hip_stream : hipStream_t to order the work on (NULL = default stream).
+ * Host audio / out in vapx_host_alloc memory is copied with true async DMA; pageable memory is staged through the engine's
+ * own pinned buffers (one extra memcpy each way). */
 int vapx_step(vapx_handle h, int32_t n, const int32_t* stream_ids, const float* audio,
               int32_t samples_per_ch, float* out, int32_t flags, void* hip_stream);
+
+/* Batch slots (row indices of `out`) of the latest host-output vapx_step whose results were not finite; returns their number
+ * (writes at most max_slots of them; slots may be NULL to just count). */
+int32_t vapx_bad_slots(vapx_handle h, int32_t* slots, int32_t max_slots);
+
+/* Page-locked host memory for audio / out blocks (hipHostMalloc): vapx_step then DMAs straight from / into it.
+ * NULL on failure.  Not tied to a handle. */
+void* vapx_host_alloc(size_t bytes);
+void vapx_host_free(void* p);
 
 /* Make hip_stream wait for every overlap group of the latest vapx_step (see VAPX_DEFER_JOIN). */
 int vapx_join(vapx_handle h, void* hip_stream);
@@ -139,7 +160,10 @@ int vapx_attach_trunk(vapx_handle follower, vapx_handle leader);
 
 /* Zero one stream's state (context ring fill, LSTM h/c, carry).  The reference never resets
  * model state on reconnect (vap_main.py:368-369 re-zeroes only the carry); this is the explicit
- * equivalent of constructing a fresh VAPRealTime for that stream. */
+ * equivalent of constructing a fresh VAPRealTime for that stream.
+ * Stream-ordered and free for everybody else: the call only queues the request (no device work, no synchronisation); the
+ * next vapx_step / vapx_encode_audio applies it on its HIP stream before touching any state, and vapx_get_state /
+ * vapx_set_state / vapx_peek apply it before they look. */
 int vapx_reset_stream(vapx_handle h, int32_t stream_id);
 
 /* State export / import for one stream (tests, migration between GPUs).  Host pointers, any may

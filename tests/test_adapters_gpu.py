@@ -169,3 +169,43 @@ def test_vapgpt_forward_signature_with_realtime_semantics():
         assert np.abs(got_v - c.z["vad"]).max() <= TOL
     with pytest.raises(NotImplementedError):
         m(wav, attention=True)
+
+
+@pytest.mark.parametrize("name", ["vap20", "bc20", "nod20"])
+def test_vaprealtime_from_reference_format_checkpoint_files(name, tmp_path):
+    """``VAPRealTime(vap_model_path, cpc_model_path, device, rate, ctx)`` exactly as vap_main.py:500 calls it,
+    on files in the reference's on-disk format (torch state dict incl. the ignored ``encoder.encoder.*`` keys; CPC file =
+    {"weights": ..., "config": argparse.Namespace}); outputs must equal the golden of the imported reference, and
+    ``get_result()`` must carry the mode's keys (vap_realtime/model.py:189-240)."""
+    import argparse
+    import torch
+    from vap_realtime_amd.realtime import VAPRealTime
+    c = Case(name)
+    vap_t = {k: torch.from_numpy(np.asarray(v)) for k, v in c.vap_sd.items()}
+    vap_t["encoder.encoder.gEncoder.conv0.weight"] = torch.zeros(256, 1, 10)     # skipped like vap_main.py:199-201
+    vap_p, cpc_p = tmp_path / "vap_state_dict.pt", tmp_path / "60k_epoch4-d0f474de.pt"
+    torch.save(vap_t, vap_p)
+    torch.save({"weights": {k: torch.from_numpy(np.asarray(v)) for k, v in c.cpc_sd.items()},
+                "config": argparse.Namespace(hiddenGar=256, hiddenEncoder=256)}, cpc_p)
+    rt = VAPRealTime(str(vap_p), str(cpc_p), torch.device("cuda", 0), c.frame_hz, c.ctx_sec, mode=c.mode)
+    cur = np.zeros((2, 320))
+    for f in range(c.n_frames):
+        cur = np.concatenate([cur, c.new_samples(f)[0].astype(np.float64)], axis=1)
+        rt.process_vap(cur[0], cur[1])
+        cur = cur[:, -320:]
+        r = rt.get_result()
+        if c.mode == "vap":
+            assert set(r) == {"t", "x1", "x2", "p_now", "p_future", "vad"}
+            np.testing.assert_allclose(r["p_now"], c.z["p_now"][f][0], rtol=0, atol=TOL)
+            np.testing.assert_allclose(r["p_future"], c.z["p_future"][f][0], rtol=0, atol=TOL)
+            np.testing.assert_allclose(r["vad"], c.z["vad"][f][0], rtol=0, atol=TOL)
+        elif c.mode == "bc":
+            assert set(r) == {"t", "x1", "x2", "p_bc_react", "p_bc_emo"}
+            np.testing.assert_allclose(r["p_bc_react"], c.z["p_bc_react"][f][0], rtol=0, atol=TOL)
+            np.testing.assert_allclose(r["p_bc_emo"], c.z["p_bc_emo"][f][0], rtol=0, atol=TOL)
+        else:
+            assert set(r) == {"t", "x1", "x2", "p_bc", "p_nod_short", "p_nod_long", "p_nod_long_p"}
+            n = min(f + 1, c.T)
+            np.testing.assert_allclose(np.asarray(r["p_bc"]).reshape(-1), c.z["p_bc"][f][0, :n], rtol=0, atol=TOL)
+            np.testing.assert_allclose(r["p_nod_short"], c.z["p_nod_short"][f][0], rtol=0, atol=TOL)
+            np.testing.assert_allclose(r["p_nod_long_p"], c.z["p_nod_long_p"][f][0], rtol=0, atol=TOL)

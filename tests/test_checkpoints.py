@@ -77,3 +77,28 @@ def test_missing_files_and_bad_shapes_are_named(tmp_path):
     no_const = {k: v for k, v in vap.items() if not k.endswith(".m") and "codebook" not in k}
     ck.validate(cpc, no_const, 20)                       # constants may be absent
     assert ck.infer_mode(vap) == "vap" and ck.infer_frame_rate(vap) == 20
+
+
+def test_loader_is_safe_by_default(tmp_path):
+    """The stock CPC checkpoint's argparse.Namespace leaf loads through the weights-only unpickler (allow-listed); a pickle
+    with a code-executing reducer is refused unless the caller opts in (no silent fallback to the full unpickler)."""
+    import argparse
+    import pickle
+    cpc, _ = W.synthetic_weights(1, 20)
+    p = tmp_path / "cpc.pt"
+    torch.save({"weights": {k: torch.from_numpy(v) for k, v in cpc.items()}, "config": argparse.Namespace(hiddenGar=256)}, p)
+    sd, _ = ck.load_state_dicts({}, str(p))
+    assert set(sd) == set(cpc)
+
+    marker = tmp_path / "pwned"
+
+    class Evil:
+        def __reduce__(self):
+            return (open, (str(marker), "w"))
+
+    q = tmp_path / "evil.pt"
+    with open(q, "wb") as f:
+        pickle.dump({"weights": Evil()}, f)
+    with pytest.raises(RuntimeError, match="weights-only unpickler"):
+        ck.load_state_dicts({}, str(q))
+    assert not marker.exists()

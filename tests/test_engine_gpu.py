@@ -263,6 +263,8 @@ def test_error_paths():
         eng.step(np.zeros((3, 2, 800), np.float32))
     with pytest.raises(engine.VapxError):
         eng.reset_stream(2)
+    with pytest.raises(engine.VapxError, match="appears twice"):
+        eng.step(np.zeros((2, 2, 800), np.float32), [1, 1])
     eng.close()
 
 
@@ -282,9 +284,101 @@ def test_non_finite_state_fails_loudly_and_reset_recovers():
     eng.set_state(1, st)
     with pytest.raises(engine.VapxError, match="non-finite outputs for batch slot 1"):
         eng.step(good)
+    assert eng.bad_slots() == [1]
+    # per stream, not per call: the block is complete, the healthy row is valid and flagged ok
+    ref = make_engine(c, max_streams=2)
+    ref.step(good); ref.step(bad); ref.step(good)
+    want = ref.step(good)
+    got = eng.step(good, on_numeric="status")
+    assert got[:, engine.OUT_STATUS].tolist() == [0.0, 1.0] and eng.bad_slots() == [1]
+    np.testing.assert_array_equal(got[0], want[0])
     eng.reset_stream(1)
-    assert np.isfinite(eng.step(good)[:, :10]).all()
-    eng.close()
+    out = eng.step(good)
+    assert np.isfinite(out[:, :10]).all() and not out[:, engine.OUT_STATUS].any() and eng.bad_slots() == []
+    eng.close(); ref.close()
+
+
+def test_reset_is_stream_ordered_and_leaves_the_other_streams_alone():
+    """vapx_reset_stream only queues the request; the next step applies it on its own HIP stream.  Resetting one stream of
+    a 1024-stream engine mid-run: every other stream's outputs are bit-identical to an engine that saw no reset, the reset
+    stream restarts from a fresh context, and the reset call itself costs microseconds (no device synchronisation)."""
+    import time
+    import torch
+    from vap_realtime_amd import engine, synth, weights as W
+    cpc, vap = W.synthetic_weights(5, 20, "vap")
+    blob = W.pack_blob(cpc, vap)
+    S, F_ = 1024, 8
+    audio = synth.noise_batch(S, 800 * F_, seed=4)
+    a, b = engine.Engine(blob, 20, 2.5, max_streams=S), engine.Engine(blob, 20, 2.5, max_streams=S)
+    fresh = engine.Engine(blob, 20, 2.5, max_streams=1)
+    d_out = torch.zeros(S, engine.OUT_STRIDE, device="cuda")
+    victim = 517
+    for f in range(F_):
+        new = np.ascontiguousarray(audio[:, :, f * 800:(f + 1) * 800])
+        if f == 5:
+            d_audio = torch.from_numpy(new).cuda()
+            a.step_device(S, d_audio.data_ptr(), 800, d_out.data_ptr())      # a tick in flight on the GPU ...
+            t0 = time.perf_counter()
+            a.reset_stream(victim)                                           # ... does not block the reset call
+            dt = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            assert dt < 2e-3, f"reset_stream took {dt * 1e3:.2f} ms: it must not synchronise the device"
+            b.step(new)
+            continue
+        oa, ob = a.step(new), b.step(new)
+        if f < 5:
+            np.testing.assert_array_equal(oa, ob)
+        else:
+            keep = np.arange(S) != victim
+            np.testing.assert_array_equal(oa[keep], ob[keep])
+            of = fresh.step(new[victim:victim + 1])
+            np.testing.assert_array_equal(oa[victim, :272], of[0, :272])
+            assert oa[victim, engine.OUT_NVALID] == f - 5
+    a.close(); b.close(); fresh.close()
+
+
+def test_pinned_host_blocks_take_the_direct_dma_path():
+    """Audio / out in vapx_host_alloc memory (engine.pinned_empty) give the same numbers as pageable numpy arrays."""
+    from vap_realtime_amd import engine
+    c = Case("multi3")
+    a, b = make_engine(c), make_engine(c)
+    pin_in = engine.pinned_empty((3, 2, c.hop))
+    pin_out = engine.pinned_empty((3, engine.OUT_STRIDE))
+    for f in range(6):
+        new = c.new_samples(f)
+        want = a.step(new)
+        pin_in[...] = new
+        got = b.step(pin_in, out=pin_out)
+        assert got.ctypes.data == pin_out.ctypes.data
+        np.testing.assert_array_equal(got, want)
+    a.close(); b.close()
+    del pin_in, pin_out, got
+
+
+def test_changing_batch_size_under_deferred_join_is_safe():
+    """VAPX_DEFER_JOIN with a batch size that changes between ticks re-slices the shared scratch: the engine joins the
+    previous tick's groups itself.  Host-staged steps ignore the flag."""
+    import torch
+    from vap_realtime_amd import engine, synth, weights as W
+    cpc, vap = W.synthetic_weights(5, 20, "vap")
+    blob = W.pack_blob(cpc, vap)
+    S, F_ = 128, 6
+    audio = synth.noise_batch(S, 800 * F_, seed=3)
+    one = engine.Engine(blob, 20, 2.5, max_streams=S)
+    grp = engine.Engine(blob, 20, 2.5, max_streams=S, groups=2)
+    sizes = [128, 96, 128, 64, 128, 80]
+    d_audio = [torch.from_numpy(np.ascontiguousarray(audio[:n, :, f * 800:(f + 1) * 800])).cuda() for f, n in enumerate(sizes)]
+    d_out = [torch.zeros(n, engine.OUT_STRIDE, device="cuda") for n in sizes]
+    want = [one.step(audio[:n, :, f * 800:(f + 1) * 800]) for f, n in enumerate(sizes)]
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for f, n in enumerate(sizes):
+        grp.step_device(n, d_audio[f].data_ptr(), 800, d_out[f].data_ptr(), stream=side.cuda_stream, defer_join=True)
+    grp.join(side.cuda_stream)
+    side.synchronize()
+    for f in range(F_):
+        np.testing.assert_array_equal(d_out[f].cpu().numpy(), want[f])
+    one.close(); grp.close()
 
 
 def test_long_run_does_not_drift():

@@ -1,0 +1,87 @@
+"""Parity at production batch sizes (BASELINE.json configs 2, 3 and 5 at their real stream counts).
+
+The goldens of the imported reference hold 1-3 streams.  Streams are independent (process_vap has no cross-stream
+term), so a full-size batch whose slots are replicas of the golden streams must reproduce the golden in EVERY
+replica: the golden audio is tiled over 1100 / 4096 stream slots under a shuffled slot assignment and every row of
+every frame is compared with the reference's numbers (<= 1e-4 abs, north_star).  This runs the code that only
+large batches reach under a checker: head_kernel<4> (> 1024 streams), the three-GEMM conv tail (> 512 streams),
+the large-M GEMM tile choices, and scratch offsets beyond 4 GB.
+"""
+import numpy as np
+import pytest
+
+from golden_util import Case
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _tiled_run(name, S, keys, extra=None, max_frames=None, seed=0):
+    from vap_realtime_amd import engine, weights as W
+    c = Case(name)
+    ns = len(c.streams)
+    blob = W.pack_blob(c.cpc_sd, c.vap_sd, c.mode)
+    eng = engine.Engine(blob, c.frame_hz, c.ctx_sec, max_streams=S + 7, max_batch=S, mode=c.mode)
+    rng = np.random.default_rng(seed + S)
+    ids = rng.permutation(S + 7)[:S].astype(np.int32)            # shuffled slots, a few left unused
+    src = (np.arange(S) % ns).astype(np.int64)                   # batch row k replays golden stream src[k]
+    worst = {}
+    spread = 0.0
+    F_ = c.n_frames if max_frames is None else min(max_frames, c.n_frames)
+    for f in range(F_):
+        audio = np.ascontiguousarray(c.new_samples(f)[src])      # [S,2,hop]
+        o = engine.split_outputs(eng.step(audio, ids))
+        assert np.all(o["n"] == min(f + 1, c.T))
+        for k in keys:
+            want = c.z[k][f][src]
+            got = o[k].reshape(want.shape)
+            worst[k] = max(worst.get(k, 0.0), float(np.abs(got - want).max()))
+        if extra is not None:
+            extra(c, f, o, src, worst)
+        first = o["p_now"][:ns] if "p_now" in keys else o["vad"][:ns]
+        allr = o["p_now"] if "p_now" in keys else o["vad"]
+        spread = max(spread, float(np.abs(allr - first[src]).max()))
+    eng.close()
+    print(f"{name} x {S} slots: worst |hip - reference golden| = {worst}; replica spread {spread:.2e}")
+    for k, v in worst.items():
+        assert v <= TOL, (name, S, k, v)
+
+
+@pytest.mark.parametrize("S", [1100, 4096])
+def test_multi3_tiled_over_full_size_batches(S):
+    """C2 / C4 shape (20 Hz, T = 50) at 1100 and 4096 streams per engine."""
+    _tiled_run("multi3", S, ("p_now", "p_future", "vad", "logits"))
+
+
+def test_vap50_tiled_over_1100_slots():
+    """C3 shape (50 Hz, T = 250: attention_mfma_kernel + the unfused GEMM chain) at 1100 streams, all 256 frames
+    (window fills and slides)."""
+    _tiled_run("vap50", 1100, ("p_now", "p_future", "vad", "logits"))
+
+
+def test_vap50_tiled_over_4096_slots():
+    """C3 at its full size: 4096 streams x T = 250 (2 M transformer rows; scratch buffers of 2-6 GB each).  The first
+    40 frames (the window is still filling: every frame has a different n) keep the run short."""
+    _tiled_run("vap50", 4096, ("p_now", "p_future", "vad", "logits"), max_frames=40)
+
+
+def _bc_extra(c, f, o, src, worst):
+    for k, col in (("p_bc_react", 1), ("p_bc_emo", 2)):
+        want = c.z[k][f].reshape(-1)[src]
+        worst[k] = max(worst.get(k, 0.0), float(np.abs(o["aux"][:, col] - want).max()))
+
+
+def _nod_extra(c, f, o, src, worst):
+    for k, col in (("p_nod_short", 1), ("p_nod_long", 2), ("p_nod_long_p", 3)):
+        want = c.z[k][f].reshape(-1)[src]
+        worst[k] = max(worst.get(k, 0.0), float(np.abs(o["aux"][:, col] - want).max()))
+    n = min(f + 1, c.T)                                          # p_bc of every window row (reference quirk)
+    want = c.z["p_bc"][f][src][:, :n]
+    worst["p_bc"] = max(worst.get("p_bc", 0.0), float(np.abs(o["logits"][:, :n] - want).max()))
+
+
+def test_bc_and_nod_heads_at_4096_streams():
+    """C5 shape: the bc and nod variants at 4096 streams (nod runs the full last layer + the all-rows p_bc)."""
+    _tiled_run("bc20", 4096, ("vad",), extra=_bc_extra)
+    _tiled_run("nod20", 4096, ("vad",), extra=_nod_extra)

@@ -74,7 +74,7 @@ def test_cabi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libvapx.so does not export {name}"
     assert set(engine.EXPORTS) == declared
-    assert lib.vapx_abi_version() == 1
+    assert lib.vapx_abi_version() == 2
     for hz, K in ((50, 2), (20, 5), (10, 10), (5, 20)):
         assert lib.vapx_blob_floats(hz) == W.blob_layout(K)["__total__"][0]
     assert lib.vapx_blob_floats(7) == 0
@@ -150,3 +150,30 @@ def test_two_rank_gloo_sharding_and_timing_reduction(tmp_path):
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {r} ok" in o, o
+
+
+def test_bench_gpus_flag_really_spawns_one_rank_per_gpu():
+    """`python bench.py --gpus 2` as the driver invokes it (no WORLD_SIZE in the environment) must create TWO ranks that
+    rendezvous, shard the streams disjointly and reduce over both ranks.  --rendezvous-only stops before any GPU work
+    (gloo), everything before that point is the real launch path."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    line = [l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 2 and len(set(r["pids"])) == 2
+    assert r["shards"] == [[0, 4095, 4096], [4096, 8191, 4096]]      # 4096 streams per rank, disjoint, contiguous
+    assert r["max_over_ranks"] == 0.002                               # the reduction saw rank 1's value
+
+
+def test_bench_flop_accounting_matches_the_survey_counts():
+    """bench.py's per-kernel MAC table: the executed work it prices is below the reference's dense count by the exact savings
+    (last-layer pruning, absorbed K/V, cached layer-0 Q|K|V), for both the fused (T <= 64) and the long-window kernel chains."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for (hz, T), dense in bench.GFLOP_PER_STREAM_FRAME.items():
+        ex = 2.0 * sum(bench.macs_per_stream_frame(hz, T).values()) / 1e9
+        assert 0.65 * dense < ex < 0.80 * dense, (hz, T, ex, dense)
+    assert bench.attention_executed_fraction(250) == 36 / 64 and bench.attention_executed_fraction(50) == 0.75

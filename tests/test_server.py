@@ -157,3 +157,97 @@ def test_connection_burst_larger_than_the_default_backlog():
             if s is not None:
                 s.close()
         srv.stop()
+
+
+class FakeAuxVap:
+    """bc / nod stand-in returning what ManyStreamVAP.process returns (engine.split_outputs keys): constant head
+    values taken from the wire golden, so the packet bytes can be compared with the reference codec's output."""
+
+    def __init__(self, mode, z, hop=800):
+        self.mode, self.n_streams, self.hop, self.z = mode, 2, hop, z
+        self.resets = []
+
+    def process(self, frames, ids):
+        R = len(ids)
+        aux = np.zeros((R, 4), np.float32)
+        logits = np.zeros((R, 256), np.float32)
+        if self.mode == "bc":
+            aux[:, 1], aux[:, 2] = self.z["bc.p_bc_react"][0], self.z["bc.p_bc_emo"][0]
+        else:
+            aux[:, 1], aux[:, 2], aux[:, 3] = self.z["nod.p_nod_short"][0], self.z["nod.p_nod_long"][0], self.z["nod.p_nod_long_p"][0]
+            logits[:, :50] = self.z["nod.p_bc"]
+        return {"aux": aux, "logits": logits, "n": np.full(R, 50, np.int32), "status": np.zeros(R, np.int32)}
+
+    def reset(self, sid):
+        self.resets.append(sid)
+
+
+def _f32_exact(a):
+    """The goldens' head values as float32-representable doubles (the engine's outputs are float32)."""
+    return np.asarray(a, np.float32).astype(np.float64)
+
+
+def test_bc_and_nod_result_packets_carry_the_reference_bytes():
+    """bc: u32 1 | p_bc_react | u32 1 | p_bc_emo (util.py:193-211); nod: u32 n | p_bc of EVERY window row | three u32 1
+    blocks (util.py:213-237, vap_nod_main.py:276,398-406).  The packet body after the time stamp must equal what the
+    reference codec produces for the same values."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "wire.npz"))
+    for mode in ("bc", "nod"):
+        vap = FakeAuxVap(mode, z)
+        srv = ManyStreamServer(vap, port_in=0, port_out=0, max_wait_s=0.5).start()
+        try:
+            i = socket.create_connection(("127.0.0.1", srv.port_in))
+            time.sleep(0.05)
+            o = socket.create_connection(("127.0.0.1", srv.port_out))
+            time.sleep(0.1)
+            i.sendall(wire.encode_input(z["vap.x1"], z["vap.x2"]))
+            o.settimeout(5)
+            ln = struct.unpack("<I", _recv_exact(o, 4))[0]
+            got = _recv_exact(o, ln)
+            res = {"t": 0.0, "x1": z["vap.x1"], "x2": z["vap.x2"]}
+            keys = ("p_bc_react", "p_bc_emo") if mode == "bc" else ("p_bc", "p_nod_short", "p_nod_long", "p_nod_long_p")
+            for k in keys:
+                res[k] = _f32_exact(z[f"{mode}.{k}"])
+            want = wire.encode_result(res, mode)
+            assert ln == len(want) == len(bytes(z[f"{mode}.bytes"]))
+            assert got[8:] == want[8:]
+            r = wire.decode_result(got, mode)
+            if mode == "nod":
+                assert len(r["p_bc"]) == 50
+        finally:
+            srv.stop()
+
+
+def test_non_finite_stream_is_reset_and_skipped_while_the_others_are_served():
+    hop = 800
+
+    class Poisoned(FakeVap):
+        def process(self, frames, ids):
+            r = super().process(frames, ids)
+            r["status"] = np.array([1 if s == 1 else 0 for s in ids], np.int32)
+            return r
+
+    vap = Poisoned(2, hop)
+    srv = ManyStreamServer(vap, port_in=0, port_out=0, max_wait_s=0.5, reset_on_connect=False).start()
+    try:
+        ins = [socket.create_connection(("127.0.0.1", srv.port_in)) for _ in range(2)]
+        time.sleep(0.1)
+        outs = [socket.create_connection(("127.0.0.1", srv.port_out)) for _ in range(2)]
+        time.sleep(0.1)
+        for f in range(2):
+            for s in range(2):
+                ins[s].sendall(wire.encode_input(np.full(hop, 0.5), np.full(hop, 0.25)))
+            outs[0].settimeout(5)
+            ln = struct.unpack("<I", _recv_exact(outs[0], 4))[0]
+            r = wire.decode_result(_recv_exact(outs[0], ln))
+            assert r["p_now"] == [0.5, 0.25]
+        outs[1].settimeout(0.3)
+        try:
+            data = outs[1].recv(4)
+        except socket.timeout:
+            data = b""
+        assert data == b""                                   # the poisoned stream got no packet ...
+        assert vap.resets == [1, 1] and srv.numeric_resets == 2   # ... and was reset each time; the server kept running
+    finally:
+        srv.stop()

@@ -94,19 +94,31 @@ def _np(t) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(t, dtype=np.float32))
 
 
-def _torch_load(path):
+def _torch_load(path, allow_unsafe: bool = False):
+    """``torch.load`` with the safe (weights-only) unpickler.  The stock CPC checkpoint carries an ``argparse.Namespace``
+    next to its tensors (the reference loads it with a full unpickle, encoder_components.py:372-380): that one class is
+    allow-listed.  Anything else the safe loader rejects is NOT retried with the arbitrary-code unpickler unless the
+    caller opts in (``allow_unsafe=True`` or ``VAPX_ALLOW_UNSAFE_PICKLE=1``), and the opt-in is logged."""
+    import argparse
+    import pickle
+    import sys
     import torch
     try:
-        return torch.load(path, map_location="cpu", weights_only=True)
-    except Exception:                                   # older pickles with non-tensor leaves
+        with torch.serialization.safe_globals([argparse.Namespace]):
+            return torch.load(path, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError as e:
+        if not (allow_unsafe or os.environ.get("VAPX_ALLOW_UNSAFE_PICKLE") == "1"):
+            raise RuntimeError(f"{path}: rejected by the weights-only unpickler ({e}). If the file is trusted, pass "
+                               f"allow_unsafe=True or set VAPX_ALLOW_UNSAFE_PICKLE=1 to unpickle it in full.") from e
+        print(f"[vapx] WARNING: loading {path} with the full (arbitrary-code) unpickler", file=sys.stderr)
         return torch.load(path, map_location="cpu", weights_only=False)
 
 
-def load_state_dicts(vap_model, cpc_model):
+def load_state_dicts(vap_model, cpc_model, allow_unsafe: bool = False):
     """Paths (``torch.load``-ed like vap_main.py:199 and encoder_components.py:372) or ready dicts ->
     ``(cpc_sd, vap_sd)`` with the CPC ``"weights"`` wrapper removed."""
-    vap_sd = _torch_load(vap_model) if isinstance(vap_model, (str, bytes, os.PathLike)) else vap_model
-    cpc_sd = _torch_load(cpc_model) if isinstance(cpc_model, (str, bytes, os.PathLike)) else cpc_model
+    vap_sd = _torch_load(vap_model, allow_unsafe) if isinstance(vap_model, (str, bytes, os.PathLike)) else vap_model
+    cpc_sd = _torch_load(cpc_model, allow_unsafe) if isinstance(cpc_model, (str, bytes, os.PathLike)) else cpc_model
     if "weights" in cpc_sd:
         cpc_sd = cpc_sd["weights"]
     return cpc_sd, vap_sd

@@ -4,6 +4,7 @@
 // Reference path being replaced: VAPRealTime.__init__/process_vap, rvap/vap_main/vap_main.py:192-335.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -90,9 +91,16 @@ struct vapx_engine {
   int n_groups = 1;
   int ffn_tile_rows = 0;   // tuning knob (env VAPX_FFN_TILE): 32 or 64 rows per FFN-block workgroup
   float* out_pinned = nullptr;
+  float* audio_pinned = nullptr;          // staging for pageable host audio (callers holding vapx_host_alloc memory skip it)
+  hipEvent_t audio_evt = nullptr;         // the H2D copy out of audio_pinned has completed
   int* ids_pinned = nullptr;
   hipEvent_t ids_evt = nullptr;
   int last_B = 0, last_G = 1;
+  bool deferred_pending = false;          // the latest step left its overlap groups un-joined (VAPX_DEFER_JOIN)
+  std::vector<int32_t> pending_resets;    // vapx_reset_stream requests, applied stream-ordered by the next step
+  std::vector<uint32_t> id_stamp;         // duplicate-id check: id_stamp[sid] == id_gen <=> sid already in this batch
+  uint32_t id_gen = 0;
+  std::vector<int32_t> bad_slots;         // batch slots of the latest host-output step whose results were not finite
 
   // shared trunk (vapx_attach_trunk): followers take the leader's LSTM outputs instead of running the CPC encoder
   vapx_engine* trunk = nullptr;           // set on a follower
@@ -139,6 +147,13 @@ hipError_t dalloc(T** p, size_t n, bool zero = true) {
   hipError_t e = hipMalloc((void**)p, n * sizeof(T));
   if (e != hipSuccess) return e;
   return zero ? hipMemset(*p, 0, n * sizeof(T)) : hipSuccess;
+}
+
+// true when p is page-locked host memory known to HIP (hipHostMalloc / hipHostRegister), i.e. a real async copy source / target
+bool is_pinned_host(const void* p) {
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return at.type == hipMemoryTypeHost;
 }
 
 int rate_ok(int hz) { return hz == 5 || hz == 10 || hz == 20 || hz == 50; }
@@ -414,6 +429,15 @@ __global__ void fill_int_kernel(int* p, int v, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
 }
+// stream-ordered reset of up to 16 stream slots: LSTM h/c, carry and window fill back to zero (the rings need no
+// clearing: rows beyond frames_seen are never read).  One workgroup per slot.
+struct ResetList { int n; int ids[16]; int* fs[4]; };   // fs[0] = this engine's frames_seen, fs[1..] = trunk followers'
+__global__ void reset_streams_kernel(ResetList r, float* h_state, float* c_state, float* carry) {
+  const int sid = r.ids[blockIdx.x];
+  for (int i = threadIdx.x; i < 512; i += blockDim.x) { h_state[(long)sid * 512 + i] = 0.f; c_state[(long)sid * 512 + i] = 0.f; }
+  for (int i = threadIdx.x; i < 2 * VAPX_PAD; i += blockDim.x) carry[(long)sid * 2 * VAPX_PAD + i] = 0.f;
+  if (threadIdx.x < 4 && r.fs[threadIdx.x]) r.fs[threadIdx.x][sid] = 0;
+}
 __global__ void add_kernel(float* o, const float* a, const float* b, long n) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) o[i] = a[i] + b[i];
@@ -432,8 +456,13 @@ __global__ void compact_rows_kernel(float* dst, const float* src, int T, int row
 int upload_ids(vapx_engine* h, int n, const int32_t* ids, int flags, hipStream_t st, const int** out) {
   if (!ids) { *out = nullptr; return VAPX_OK; }
   if (flags & VAPX_IDS_DEVICE) { *out = ids; return VAPX_OK; }
-  for (int i = 0; i < n; ++i)
+  if (++h->id_gen == 0) { std::fill(h->id_stamp.begin(), h->id_stamp.end(), 0u); h->id_gen = 1; }
+  for (int i = 0; i < n; ++i) {
     if (ids[i] < 0 || ids[i] >= h->cfg.max_streams) return fail(h, VAPX_E_RANGE, "stream id %d out of range [0,%d)", ids[i], h->cfg.max_streams);
+    // two batch slots on one stream would race on its ring slot, LSTM state, carry and frame counter
+    if (h->id_stamp[ids[i]] == h->id_gen) return fail(h, VAPX_E_INVAL, "stream id %d appears twice in one step (batch slot %d)", ids[i], i);
+    h->id_stamp[ids[i]] = h->id_gen;
+  }
   HIPCHK(h, hipEventSynchronize(h->ids_evt));  // previous async copy out of the pinned buffer is done
   memcpy(h->ids_pinned, ids, n * sizeof(int));
   HIPCHK(h, hipMemcpyAsync(h->ids_dev, h->ids_pinned, n * sizeof(int), hipMemcpyHostToDevice, st));
@@ -442,6 +471,49 @@ int upload_ids(vapx_engine* h, int n, const int32_t* ids, int flags, hipStream_t
   return VAPX_OK;
 }
 
+
+// apply the vapx_reset_stream requests collected since the last step, ordered on `st` (no host or device sync)
+int flush_resets(vapx_engine* h, hipStream_t st) {
+  if (h->pending_resets.empty()) return VAPX_OK;
+  ResetList r;
+  memset(&r, 0, sizeof r);
+  r.fs[0] = h->frames_seen;
+  size_t nf = 0;
+  for (vapx_engine* f : h->followers)
+    if (nf + 1 < 4) r.fs[++nf] = f->frames_seen;   // a fourth and later follower gets its own tiny launches below
+  for (size_t i = 0; i < h->pending_resets.size(); i += 16) {
+    r.n = (int)std::min<size_t>(16, h->pending_resets.size() - i);
+    for (int k = 0; k < r.n; ++k) r.ids[k] = h->pending_resets[i + k];
+    hipLaunchKernelGGL(reset_streams_kernel, dim3(r.n), dim3(256), 0, st, r, h->h_state, h->c_state, h->carry);
+    for (size_t f = 3; f < h->followers.size(); ++f)
+      for (int k = 0; k < r.n; ++k) hipLaunchKernelGGL(fill_int_kernel, dim3(1), dim3(64), 0, st, h->followers[f]->frames_seen + r.ids[k], 0, 1);
+  }
+  HIPCHK(h, hipGetLastError());
+  h->pending_resets.clear();
+  return VAPX_OK;
+}
+
+// quiesce the device and apply queued resets (state import / export, peeks)
+int quiesce(vapx_engine* h) {
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipDeviceSynchronize());
+  vapx_engine* lead = h->trunk ? h->trunk : h;
+  if (!lead->pending_resets.empty()) {
+    int rc = flush_resets(lead, nullptr);
+    if (rc) return rc;
+    HIPCHK(h, hipDeviceSynchronize());
+  }
+  h->deferred_pending = false;
+  return VAPX_OK;
+}
+
+// make `st` wait for overlap groups a VAPX_DEFER_JOIN step left running
+int join_deferred(vapx_engine* h, hipStream_t st) {
+  if (!h->deferred_pending) return VAPX_OK;
+  for (int g = 0; g < h->last_G; ++g) HIPCHK(h, hipStreamWaitEvent(st, h->gdone[g], 0));
+  h->deferred_pending = false;
+  return VAPX_OK;
+}
 
 // Combinator on ALL rows: comb = gelu(LN(a.Wa^T)) + gelu(LN(b.Wb^T)), shared LN (modules.py:449-464).
 // Tower rows of channel c of stream b sit at ((b*2+c)*T + t).  Result in sc.xmid as [n][T][256].
@@ -558,7 +630,9 @@ void vapx_destroy(vapx_handle h) {
     if (p) (void)hipFree(p);
   if (h->out_pinned) (void)hipHostFree(h->out_pinned);
   if (h->ids_pinned) (void)hipHostFree(h->ids_pinned);
+  if (h->audio_pinned) (void)hipHostFree(h->audio_pinned);
   if (h->ids_evt) (void)hipEventDestroy(h->ids_evt);
+  if (h->audio_evt) (void)hipEventDestroy(h->audio_evt);
   if (h->gstart) (void)hipEventDestroy(h->gstart);
   for (int g = 0; g < vapx_engine::kMaxGroups; ++g) {
     if (h->gdone[g]) (void)hipEventDestroy(h->gdone[g]);
@@ -659,6 +733,8 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
   CR(dalloc(&h->sc.lffn, B * 2 * 768));
   CR(hipHostMalloc((void**)&h->out_pinned, B * VAPX_OUT_STRIDE * sizeof(float), hipHostMallocDefault));
   CR(hipHostMalloc((void**)&h->ids_pinned, B * sizeof(int), hipHostMallocDefault));
+  CR(hipHostMalloc((void**)&h->audio_pinned, B * 2 * h->L * sizeof(float), hipHostMallocDefault));
+  h->id_stamp.assign(S, 0u);
   if (const char* ev = getenv("VAPX_FFN_TILE")) h->ffn_tile_rows = atoi(ev);
   h->n_groups = cfg->flags & 0xF;
   if (h->n_groups == 0) h->n_groups = 1;   // measured: no gain at 256 streams, +2 % at 4096 with 2
@@ -670,6 +746,8 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
   CR(hipEventCreateWithFlags(&h->gstart, hipEventDisableTiming));
   CR(hipEventCreateWithFlags(&h->ids_evt, hipEventDisableTiming));
   CR(hipEventRecord(h->ids_evt, nullptr));
+  CR(hipEventCreateWithFlags(&h->audio_evt, hipEventDisableTiming));
+  CR(hipEventRecord(h->audio_evt, nullptr));
   CR(hipDeviceSynchronize());
 #undef CR
   *out = h;
@@ -695,22 +773,41 @@ int vapx_step(vapx_handle h, int32_t n, const int32_t* stream_ids, const float* 
   if (!stream_ids && n > h->cfg.max_streams) return fail(h, VAPX_E_RANGE, "n exceeds max_streams");
   hipStream_t st = (hipStream_t)hip_stream;
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  const int* ids = nullptr;
+  // split the batch into groups on separate HIP streams: streams are independent, and a second
+  // group's kernels fill the prologue / epilogue / tail bubbles of the first group's kernels
+  int G = h->n_groups;
+  while (G > 1 && n / G < 32) --G;
+  // free-running groups are only safe when nothing of this step is staged through engine-owned buffers on `st`
+  // (host audio / host ids would be overwritten under a still-running group of the previous tick)
+  const bool all_device = (flags & VAPX_OUT_DEVICE) && (lead || (flags & VAPX_AUDIO_DEVICE)) && (!stream_ids || (flags & VAPX_IDS_DEVICE));
+  const bool defer_join = G > 1 && (flags & VAPX_DEFER_JOIN) && all_device;
   int rc = VAPX_OK;
+  // a different batch split re-slices the shared scratch, and a reset touches state a running group may still use:
+  // in both cases the previous tick's groups are joined first
+  if (h->deferred_pending && (!defer_join || n != h->last_B || G != h->last_G || !h->pending_resets.empty())) {
+    rc = join_deferred(h, st);
+    if (rc) return rc;
+  }
+  if (!lead) { rc = flush_resets(h, st); if (rc) return rc; }
+  const int* ids = nullptr;
   if (lead) ids = lead->last_ids;   // same streams, same order as the leader's step (stream_ids is ignored)
   else rc = upload_ids(h, n, stream_ids, flags, st, &ids);
   if (rc) return rc;
   const float* ad = audio;
   if (!lead && !(flags & VAPX_AUDIO_DEVICE)) {
-    HIPCHK(h, hipMemcpyAsync(h->audio_dev, audio, (size_t)n * 2 * spc * sizeof(float), hipMemcpyHostToDevice, st));
+    const size_t bytes = (size_t)n * 2 * spc * sizeof(float);
+    const float* src = audio;
+    if (!is_pinned_host(audio)) {   // pageable memory: stage through the engine's pinned buffer (an async copy from
+                                    // pageable memory is a hidden synchronous staging copy inside the runtime)
+      HIPCHK(h, hipEventSynchronize(h->audio_evt));
+      memcpy(h->audio_pinned, audio, bytes);
+      src = h->audio_pinned;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->audio_dev, src, bytes, hipMemcpyHostToDevice, st));
+    if (src == h->audio_pinned) HIPCHK(h, hipEventRecord(h->audio_evt, st));
     ad = h->audio_dev;
   }
   float* od = (flags & VAPX_OUT_DEVICE) ? out : h->out_dev;
-  // split the batch into groups on separate HIP streams: streams are independent, and a second
-  // group's kernels fill the prologue / epilogue / tail bubbles of the first group's kernels
-  int G = h->n_groups;
-  while (G > 1 && n / G < 32) --G;
-  const bool defer_join = G > 1 && (flags & VAPX_DEFER_JOIN) && (flags & VAPX_OUT_DEVICE);
   if (G > 1) {
     HIPCHK(h, hipEventRecord(h->gstart, st));
     for (int g = 0; g < G; ++g) HIPCHK(h, hipStreamWaitEvent(h->gstream[g], h->gstart, 0));
@@ -729,31 +826,58 @@ int vapx_step(vapx_handle h, int32_t n, const int32_t* stream_ids, const float* 
   }
   if (G > 1 && !defer_join)
     for (int g = 0; g < G; ++g) HIPCHK(h, hipStreamWaitEvent(st, h->gdone[g], 0));
+  h->deferred_pending = defer_join;
   h->last_G = G;
   h->last_B = n;
   h->last_ids = ids;
   if (lead) h->followed_tick = lead->tick; else ++h->tick;
   if (!(flags & VAPX_OUT_DEVICE)) {
-    HIPCHK(h, hipMemcpyAsync(h->out_pinned, h->out_dev, (size_t)n * VAPX_OUT_STRIDE * sizeof(float), hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipStreamSynchronize(st));
-    memcpy(out, h->out_pinned, (size_t)n * VAPX_OUT_STRIDE * sizeof(float));
-    for (int i = 0; i < n; ++i) {   // fail loudly rather than hand NaNs to a dialogue system
-      const float* r = out + (size_t)i * VAPX_OUT_STRIDE;
-      bool ok = true;
-      for (int k = 0; k < 10; ++k) ok = ok && std::isfinite(r[k]);
-      if (!ok)
-        return fail(h, VAPX_E_NUMERIC, "non-finite outputs for batch slot %d (stream %d); its state is poisoned: reset the stream", i,
-                    (stream_ids && !(flags & VAPX_IDS_DEVICE)) ? stream_ids[i] : i);
+    const size_t bytes = (size_t)n * VAPX_OUT_STRIDE * sizeof(float);
+    if (is_pinned_host(out)) {   // vapx_host_alloc memory: the D2H lands in the caller's buffer directly
+      HIPCHK(h, hipMemcpyAsync(out, h->out_dev, bytes, hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipStreamSynchronize(st));
+    } else {
+      HIPCHK(h, hipMemcpyAsync(h->out_pinned, h->out_dev, bytes, hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipStreamSynchronize(st));
+      memcpy(out, h->out_pinned, bytes);
+    }
+    // Fail loudly rather than hand NaNs to a dialogue system — but per stream: the out block is complete, the healthy rows
+    // are valid, the offending batch slots carry VAPX_OUT_STATUS = 1 and are listed by vapx_bad_slots().
+    h->bad_slots.clear();
+    for (int i = 0; i < n; ++i)
+      if (out[(size_t)i * VAPX_OUT_STRIDE + VAPX_OUT_STATUS] != 0.f) h->bad_slots.push_back(i);
+    if (!h->bad_slots.empty()) {
+      const int i = h->bad_slots[0];
+      return fail(h, VAPX_E_NUMERIC, "non-finite outputs for batch slot %d (stream %d) and %zu more; the other rows are valid; these streams' state is "
+                  "poisoned: reset them (vapx_bad_slots lists the slots)", i,
+                  (stream_ids && !(flags & VAPX_IDS_DEVICE)) ? stream_ids[i] : i, h->bad_slots.size() - 1);
     }
   }
   return VAPX_OK;
+}
+
+int32_t vapx_bad_slots(vapx_handle h, int32_t* slots, int32_t max_slots) {
+  if (!h) return VAPX_E_INVAL;
+  const int32_t n = (int32_t)h->bad_slots.size();
+  for (int32_t i = 0; i < n && i < max_slots && slots; ++i) slots[i] = h->bad_slots[i];
+  return n;
+}
+
+void* vapx_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+
+void vapx_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
 }
 
 int vapx_join(vapx_handle h, void* hip_stream) {
   if (!h) return VAPX_E_INVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   for (int g = 0; g < h->last_G && h->last_G > 1; ++g) HIPCHK(h, hipStreamWaitEvent((hipStream_t)hip_stream, h->gdone[g], 0));
-  return VAPX_OK;
+  return VAPX_OK;   // deferred_pending stays set: only `hip_stream` waited, a later step on another stream still has to
 }
 
 int vapx_attach_trunk(vapx_handle f, vapx_handle lead) {
@@ -789,21 +913,18 @@ int vapx_reset_stream(vapx_handle h, int32_t sid) {
   if (!h) return VAPX_E_INVAL;
   if (sid < 0 || sid >= h->cfg.max_streams) return fail(h, VAPX_E_RANGE, "stream id out of range");
   if (h->trunk) return fail(h, VAPX_E_INVAL, "reset the trunk leader: it resets its followers too");
-  HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  HIPCHK(h, hipDeviceSynchronize());
-  HIPCHK(h, hipMemset(h->h_state + (size_t)sid * 512, 0, 512 * sizeof(float)));
-  HIPCHK(h, hipMemset(h->c_state + (size_t)sid * 512, 0, 512 * sizeof(float)));
-  HIPCHK(h, hipMemset(h->carry + (size_t)sid * 2 * VAPX_PAD, 0, 2 * VAPX_PAD * sizeof(float)));
-  HIPCHK(h, hipMemset(h->frames_seen + sid, 0, sizeof(int)));
-  for (vapx_engine* f : h->followers) HIPCHK(h, hipMemset(f->frames_seen + sid, 0, sizeof(int)));
+  // No device work and no synchronisation here: the request is queued and the NEXT vapx_step applies it with one tiny
+  // kernel ordered on its HIP stream, before that step touches any state — a joining client costs the other streams nothing.
+  for (int32_t q : h->pending_resets)
+    if (q == sid) return VAPX_OK;
+  h->pending_resets.push_back(sid);
   return VAPX_OK;
 }
 
 int vapx_get_state(vapx_handle h, int32_t sid, float* ring, int32_t* n_frames, float* lstm, float* carry) {
   if (!h) return VAPX_E_INVAL;
   if (sid < 0 || sid >= h->cfg.max_streams) return fail(h, VAPX_E_RANGE, "stream id out of range");
-  HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  HIPCHK(h, hipDeviceSynchronize());
+  { int rc = quiesce(h); if (rc) return rc; }
   int fs = 0;
   HIPCHK(h, hipMemcpy(&fs, h->frames_seen + sid, sizeof(int), hipMemcpyDeviceToHost));
   const int T = h->T, n = fs < T ? fs : T;
@@ -833,8 +954,7 @@ int vapx_set_state(vapx_handle h, int32_t sid, const float* ring, int32_t n_fram
   if (sid < 0 || sid >= h->cfg.max_streams) return fail(h, VAPX_E_RANGE, "stream id out of range");
   if (n_frames < 0 || n_frames > h->T) return fail(h, VAPX_E_INVAL, "n_frames outside [0,T]");
   if (h->trunk && (lstm || carry)) return fail(h, VAPX_E_INVAL, "LSTM / carry state lives in the trunk leader");
-  HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  HIPCHK(h, hipDeviceSynchronize());
+  { int rc = quiesce(h); if (rc) return rc; }
   const int T = h->T;
   if (ring) {
     // chronological rows land in slots 0..n-1 and frames_seen = n, so the next append goes to slot n % T
@@ -874,7 +994,11 @@ int vapx_encode_audio(vapx_handle h, int32_t n, const int32_t* stream_ids, const
   hipStream_t st = (hipStream_t)hip_stream;
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   const int* ids = nullptr;
-  int rc = upload_ids(h, n, stream_ids, 0, st, &ids);
+  int rc = join_deferred(h, st);
+  if (rc) return rc;
+  rc = flush_resets(h, st);
+  if (rc) return rc;
+  rc = upload_ids(h, n, stream_ids, 0, st, &ids);
   if (rc) return rc;
   const StateView sv{h->ring, h->ring_qkv, h->h_state, h->c_state, h->carry, h->frames_seen};
   rc = run_encoder(h, h->sc, sv, n, ids, frames, h->L, false, st);
@@ -897,6 +1021,7 @@ int vapx_transformer(vapx_handle h, int32_t n, int32_t rows, const float* x, flo
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   const int T = h->T;
   const int l_begin = stage == 2 ? 1 : 0, l_end = stage == 1 ? 1 : 4;
+  { int rc0 = join_deferred(h, st); if (rc0) return rc0; }   // the stage API shares the step's scratch
   hipLaunchKernelGGL(fill_int_kernel, dim3((n + 255) / 256), dim3(256), 0, st, h->sc.bn, rows, n);
   GatherArgs ga;
   memset(&ga, 0, sizeof ga);
@@ -924,8 +1049,7 @@ int vapx_transformer(vapx_handle h, int32_t n, int32_t rows, const float* x, flo
 
 int64_t vapx_peek(vapx_handle h, const char* name, float* dst, size_t max_floats) {
   if (!h || !name || !dst) return VAPX_E_INVAL;
-  HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  HIPCHK(h, hipDeviceSynchronize());
+  { int rc = quiesce(h); if (rc) return rc; }
   const size_t B = h->last_B, T = h->T;
   const int* P = h->P;
   const float* src = nullptr;

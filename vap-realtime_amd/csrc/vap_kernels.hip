@@ -806,9 +806,17 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
         for (int r = 0; r < nr; ++r) { z[r] = expf(z[r] - zm); zs += z[r]; }
         for (int r = 0; r < 4; ++r) out[6 + r] = r < nr ? z[r] / zs : 0.f;
       }
+      {   // per-row numeric status (VAPX_OUT_STATUS): 1 = p_now / p_future / VAD / aux probabilities not all finite (poisoned state)
+        float chk = (out[0] + out[1]) + (out[2] + out[3]) + (out[4] + out[5]);
+        if (a.mode != 0) chk += (out[6] + out[7]) + (out[8] + out[9]);
+        out[13] = (chk - chk == 0.f) ? 0.f : 1.f;
+      }
       if (a.frames_seen) {
         int sid = a.ids ? a.ids[b] : b;
-        a.frames_seen[sid] += 1;
+        int fs = a.frames_seen[sid] + 1;
+        // only fs % T and min(fs, T) are ever used: fold the counter long before it could overflow (2^30 frames = 1.7 years at 20 Hz)
+        if (fs >= (1 << 30)) fs = a.T + fs % a.T;
+        a.frames_seen[sid] = fs;
       }
     }
   }

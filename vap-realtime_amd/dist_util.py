@@ -27,6 +27,56 @@ def init(backend: str, device=None):
     return dist
 
 
+def _parse_cpulist(txt: str):
+    cpus = []
+    for part in txt.strip().split(","):
+        if "-" in part:
+            lo, hi = part.split("-")
+            cpus.extend(range(int(lo), int(hi) + 1))
+        elif part:
+            cpus.append(int(part))
+    return cpus
+
+
+def pin_rank_to_cores(local_rank: int, local_world: int):
+    """Pin this process to host cores near its GPU: the NUMA node of the GPU's PCI function when sysfs exposes it
+    (shared evenly by the ranks of that node), else an even split of the visible cores.  The host side of a shard (audio
+    staging, result fan-out) then stays off the other ranks' cores.  Returns the core list or None (single rank / no
+    affinity support)."""
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+        cores = None
+        try:
+            import torch
+            if torch.cuda.is_available():
+                nodes = []
+                for r in range(local_world):
+                    p = torch.cuda.get_device_properties(r)
+                    bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+                    with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+                        nodes.append(int(f.read()))
+                node = nodes[local_rank]
+                if node >= 0:
+                    with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+                        ncpus = [c for c in _parse_cpulist(f.read()) if c in avail]
+                    peers = [r for r in range(local_world) if nodes[r] == node]
+                    k, m = peers.index(local_rank), len(peers)
+                    per = len(ncpus) // m
+                    if per >= 1:
+                        cores = ncpus[k * per:(k + 1) * per]
+        except Exception:
+            cores = None
+        if not cores:
+            per = max(1, len(avail) // local_world)
+            cores = avail[local_rank * per:(local_rank + 1) * per] or avail
+        os.sched_setaffinity(0, cores)
+        return [cores[0], cores[-1], len(cores)]
+    except Exception:
+        return None
+
+
 def barrier(dist, device_sync=None):
     if device_sync:
         device_sync()

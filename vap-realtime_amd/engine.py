@@ -18,13 +18,16 @@ LIB_PATH = os.path.join(_HERE, "libvapx.so")
 OUT_STRIDE = 784
 OUT_P_NOW, OUT_P_FUTURE, OUT_VAD, OUT_AUX, OUT_NVALID, OUT_LOGITS, OUT_E = 0, 2, 4, 6, 10, 16, 272
 OUT_VAD_LOGIT = 11
+OUT_STATUS = 13
+E_NUMERIC = -6
+ABI_VERSION = 2
 AUDIO_DEVICE, OUT_DEVICE, IDS_DEVICE = 1, 2, 4
 MODE = {"vap": 0, "bc": 1, "nod": 2}
 
 EXPORTS = ("vapx_abi_version", "vapx_blob_floats", "vapx_create", "vapx_destroy", "vapx_step",
            "vapx_attach_trunk", "vapx_join", "vapx_reset_stream", "vapx_get_state", "vapx_set_state", "vapx_encode_audio",
            "vapx_transformer", "vapx_peek", "vapx_gemm", "vapx_last_error", "vapx_profile_enable",
-           "vapx_profile_read")
+           "vapx_profile_read", "vapx_bad_slots", "vapx_host_alloc", "vapx_host_free")
 PROF_CLASSES = {0: "gemm_store", 1: "gemm_gelu", 2: "gemm_resid", 3: "gemm_resid_ln", 4: "gemm_cn_relu",
                 5: "conv_tail", 6: "ffn_block", 7: "last_row", 8: "conv0", 9: "lstm", 10: "gather_ln", 11: "attention", 12: "head"}
 
@@ -91,6 +94,12 @@ def load_library(path: Optional[str] = None):
     lib.vapx_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
     lib.vapx_last_error.restype = C.c_char_p
     lib.vapx_last_error.argtypes = [vp]
+    lib.vapx_bad_slots.restype = i32
+    lib.vapx_bad_slots.argtypes = [vp, i32p, i32]
+    lib.vapx_host_alloc.restype = vp
+    lib.vapx_host_alloc.argtypes = [C.c_size_t]
+    lib.vapx_host_free.restype = None
+    lib.vapx_host_free.argtypes = [vp]
     if path is None:
         _lib = lib
     return lib
@@ -98,6 +107,34 @@ def load_library(path: Optional[str] = None):
 
 def _np_ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class _PinnedOwner:
+    """Frees a vapx_host_alloc block when the last numpy view of it is collected."""
+
+    def __init__(self, lib, ptr):
+        self.lib, self.ptr = lib, ptr
+
+    def __del__(self):
+        try:
+            self.lib.vapx_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float32) -> np.ndarray:
+    """numpy array in page-locked host memory (vapx_host_alloc): ``Engine.step`` DMAs straight from / into such arrays
+    instead of staging through the engine's own pinned buffers."""
+    lib = load_library()
+    dt = np.dtype(dtype)
+    nbytes = int(np.prod(shape)) * dt.itemsize
+    ptr = lib.vapx_host_alloc(max(nbytes, 1))
+    if not ptr:
+        raise VapxError(f"vapx_host_alloc({nbytes}) failed")
+    owner = _PinnedOwner(lib, ptr)
+    buf = (C.c_char * max(nbytes, 1)).from_address(ptr)
+    buf._owner = owner                                   # the ctypes buffer is the numpy base: keeps the block alive
+    return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
 
 
 class Engine:
@@ -148,18 +185,35 @@ class Engine:
         return rc
 
     # -- the step --------------------------------------------------------------------------------
-    def step(self, audio: np.ndarray, stream_ids: Optional[Sequence[int]] = None) -> np.ndarray:
+    def step(self, audio: np.ndarray, stream_ids: Optional[Sequence[int]] = None, out: Optional[np.ndarray] = None,
+             on_numeric: str = "raise") -> np.ndarray:
         """Host path.  audio: float [n,2,hop] (new samples; engine keeps the carry) or [n,2,hop+320]
-        (complete frames as ``process_vap`` receives them).  Returns float32 [n, OUT_STRIDE]."""
+        (complete frames as ``process_vap`` receives them).  Returns float32 [n, OUT_STRIDE] (``out`` if given, e.g. a
+        ``pinned_empty`` block).  A stream with non-finite results (VAPX_E_NUMERIC) raises by default; with
+        ``on_numeric="status"`` the block is returned — every other row is valid, the bad rows have column OUT_STATUS = 1
+        and ``bad_slots()`` lists them."""
         audio = np.ascontiguousarray(audio, dtype=np.float32)
         n, two, spc = audio.shape
         assert two == 2
         ids = None if stream_ids is None else np.ascontiguousarray(stream_ids, dtype=np.int32)
         if ids is not None:
             assert ids.shape == (n,)
-        out = np.empty((n, OUT_STRIDE), dtype=np.float32)
-        self._check(self.lib.vapx_step(self._h, n, _np_ptr(ids), _np_ptr(audio), spc, _np_ptr(out), 0, None), "vapx_step")
-        return out
+        if out is None:
+            out = np.empty((n, OUT_STRIDE), dtype=np.float32)
+        assert out.dtype == np.float32 and out.flags.c_contiguous and out.size >= n * OUT_STRIDE
+        rc = self.lib.vapx_step(self._h, n, _np_ptr(ids), _np_ptr(audio), spc, _np_ptr(out), 0, None)
+        if not (rc == E_NUMERIC and on_numeric == "status"):
+            self._check(rc, "vapx_step")
+        return out.reshape(-1, OUT_STRIDE)[:n]
+
+    def bad_slots(self) -> list:
+        """Batch slots of the latest host-path step whose results were not finite."""
+        n = self.lib.vapx_bad_slots(self._h, None, 0)
+        if n <= 0:
+            return []
+        buf = np.empty(n, np.int32)
+        self.lib.vapx_bad_slots(self._h, _np_ptr(buf), n)
+        return buf.tolist()
 
     def attach_trunk(self, leader: "Engine"):
         """Make this engine a follower of ``leader``: it shares the leader's CPC CNN + LSTM (vapx.h, vapx_attach_trunk)."""
@@ -277,5 +331,6 @@ def split_outputs(out: np.ndarray) -> dict:
         "vad": out[:, OUT_VAD:OUT_VAD + 2], "aux": out[:, OUT_AUX:OUT_AUX + 4],
         "n": out[:, OUT_NVALID].astype(np.int32), "logits": out[:, OUT_LOGITS:OUT_LOGITS + 256],
         "vad_logit": out[:, OUT_VAD_LOGIT:OUT_VAD_LOGIT + 2],
+        "status": out[:, OUT_STATUS].astype(np.int32),
         "e": out[:, OUT_E:OUT_E + 512].reshape(-1, 2, 256),
     }

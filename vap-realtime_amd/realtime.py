@@ -108,9 +108,17 @@ class VAPRealTime:
         self.process_time_abs = time.time()
 
     def get_result(self) -> Dict:
-        """Library-twin result dict (vap_realtime/model.py:189-194)."""
-        return {"t": self.result_last_time, "x1": self.current_x1_audio, "x2": self.current_x2_audio,
-                "p_now": self.result_p_now, "p_future": self.result_p_future, "vad": self.result_vad}
+        """Library-twin result dict: vap keys vap_realtime/model.py:189-194, bc :208-214, nod :226-240 (``Vap.get_result``
+        switches on the loaded model's mode)."""
+        r = {"t": self.result_last_time, "x1": self.current_x1_audio, "x2": self.current_x2_audio}
+        if self.mode == "vap":
+            r.update(p_now=self.result_p_now, p_future=self.result_p_future, vad=self.result_vad)
+        elif self.mode == "bc":
+            r.update(p_bc_react=self.result_p_bc_react, p_bc_emo=self.result_p_bc_emo)
+        else:
+            r.update(p_bc=self.result_p_bc, p_nod_short=self.result_p_nod_short, p_nod_long=self.result_p_nod_long,
+                     p_nod_long_p=self.result_p_nod_long_p)
+        return r
 
 
 class ManyStreamVAP:
@@ -128,7 +136,10 @@ class ManyStreamVAP:
 
     def process(self, new_samples: np.ndarray, stream_ids: Optional[Sequence[int]] = None) -> Dict[str, np.ndarray]:
         """new_samples float [n,2,hop] (or [n,2,hop+320] complete frames) -> dict of [n,...] arrays."""
-        return _engine.split_outputs(self.engine.step(new_samples, stream_ids))
+        res = _engine.split_outputs(self.engine.step(new_samples, stream_ids, on_numeric="status"))
+        if self.mode == "nod":      # p_bc of every window row (vap_nod_main.py:276 quirk) sits in the logits columns
+            res["p_bc"] = [res["logits"][k, :int(res["n"][k])] for k in range(len(res["n"]))]
+        return res
 
     def reset(self, stream_id: int):
         self.engine.reset_stream(stream_id)

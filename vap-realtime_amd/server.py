@@ -54,6 +54,7 @@ class ManyStreamServer:
         self.out_all: List[socket.socket] = []
         self.first_ready_t: Optional[float] = None
         self.frames_done = 0
+        self.numeric_resets = 0          # streams reset because their results went non-finite
         self._stop = threading.Event()
         self._thread: Optional[threading.Thread] = None
 
@@ -144,9 +145,18 @@ class ManyStreamServer:
         echo = self.asm.last_echo
         res = self.vap.process(frames, ready.astype(np.int32))
         t = time.time()
+        # a stream whose results are not finite (poisoned state, engine status column) is reset and gets no packet this
+        # tick; every other stream of the batch is served as usual
+        status = res.get("status")
+        bad = set(np.nonzero(status)[0].tolist()) if status is not None else set()
+        for k in bad:
+            self.vap.reset(int(ready[k]))
+            self.numeric_resets += 1
         batch = wire.frame_results_batch(t, echo, res["p_now"], res["p_future"], res["vad"]) if self.mode == "vap" else None
         for k, sid in enumerate(ready):
             sid = int(sid)
+            if k in bad:
+                continue
             if batch is not None:
                 pkt = memoryview(batch[k])
                 for conn in list(self.out_all if self.broadcast else self.out_conns[sid]):
@@ -159,8 +169,10 @@ class ManyStreamServer:
             if self.mode == "bc":
                 r.update(p_bc_react=[res["aux"][k, 1]], p_bc_emo=[res["aux"][k, 2]])
             else:
-                r.update(p_bc=res.get("p_bc", np.zeros((len(ready), 0)))[k], p_nod_short=[res["aux"][k, 1]],
-                         p_nod_long=[res["aux"][k, 2]], p_nod_long_p=[res["aux"][k, 3]])
+                # p_bc of EVERY window row (vap_nod_main.py:276 indexes the batch dim; :398-406 sends all n values): the
+                # engine returns them in the logits columns of the row
+                p_bc = res["p_bc"][k] if "p_bc" in res else res["logits"][k, :int(res["n"][k])]
+                r.update(p_bc=p_bc, p_nod_short=[res["aux"][k, 1]], p_nod_long=[res["aux"][k, 2]], p_nod_long_p=[res["aux"][k, 3]])
             pkt = wire.frame_result(r, self.mode)
             for conn in list(self.out_all if self.broadcast else self.out_conns[sid]):
                 try:
