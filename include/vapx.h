@@ -166,6 +166,14 @@ int vapx_attach_trunk(vapx_handle follower, vapx_handle leader);
  * vapx_set_state / vapx_peek apply it before they look. */
 int vapx_reset_stream(vapx_handle h, int32_t stream_id);
 
+/* Zero only the 320-sample carry of a stream: exactly what the reference does when an input client (re)connects
+ * (vap_main.py:368-369: current_x1 / current_x2 restart from zeros, LSTM and context are kept).  Queued and stream-ordered
+ * like vapx_reset_stream. */
+int vapx_reset_carry(vapx_handle h, int32_t stream_id);
+
+/* The configuration a handle was created with. */
+int vapx_get_config(vapx_handle h, vapx_config* out);
+
 /* State export / import for one stream (tests, migration between GPUs).  Host pointers, any may
  * be NULL to skip.  ring: [2][T][256] oldest->newest, rows >= n_frames undefined;
  * lstm: [2 ch][2 (h,c)][256]; carry: [2][320]. */
@@ -214,6 +222,79 @@ int vapx_gemm(void* hip_stream, int32_t M, int32_t N, int32_t K, const float* A,
 #define VAPX_PROF_CLASSES 13
 int vapx_profile_enable(vapx_handle h, uint32_t class_mask);
 int vapx_profile_read(vapx_handle h, double* total_ms, int64_t* launches, int32_t n_classes);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Native many-stream TCP front-end with the reference's packet framing.
+ *
+ * Stands in for proc_serv_in / proc_serv_out / proc_serv_out_dist (rvap/vap_main/vap_main.py:338-457) and the codec
+ * rvap/common/util.py:52-237, for MANY dialogues in one process: the reference accepts exactly one input client
+ * (`s.listen(1)`, :360-366) and decodes every sample with a Python struct.unpack.  Here: epoll receive threads decode the
+ * 2560-byte packets (160 x {f64 ch1, f64 ch2}, little-endian) straight into page-locked staging (f64 -> f32 cast as
+ * vap_main.py:266-270; optional gain multiplied in float64 first, :393-395), a tick thread steps every stream whose frame is
+ * complete (vapx_step, host in / host out), and sender threads write the length-prefixed result packets
+ * (u32 len | f64 t | u32 n | x1 | u32 n | x2 | u32 2 | p_now | u32 2 | p_future | u32 2 | vad, util.py:122-143; bc / nod variants
+ * :193-237) byte-identical to the reference codec.
+ *   - every connection accepted on port_in becomes a stream (lowest free slot); the 320-sample carry lives on the device
+ *     and is re-zeroed for a new connection like vap_main.py:368-369 (reset_on_connect additionally clears the LSTM /
+ *     context state, which the reference keeps);
+ *   - every connection accepted on port_out is attached to the stream with the fewest listeners (lowest index first), i.e.
+ *     the k-th output connection hears the k-th input stream; broadcast = 1 sends every result to every output
+ *     connection (the reference's behaviour; default for a 1-stream engine);
+ *   - a tick runs when min_batch streams are ready (0: all connected ones), or max_wait_us after the first became ready
+ *     (ragged batches: only the ready streams are stepped);
+ *   - output sockets are non-blocking like the reference's (:346-347): a listener that cannot take a whole packet is dropped;
+ *   - a stream whose results are not finite (VAPX_OUT_STATUS) is reset and skipped for that tick, the others are served.
+ * The engine handle must outlive the front-end and must not be stepped by anyone else while it runs. */
+typedef struct vapx_ingest* vapx_ingest_handle;
+
+typedef struct vapx_ingest_config {
+  int32_t struct_size;      /* sizeof(vapx_ingest_config) */
+  int32_t port_in;          /* 50007 in the reference (vap_main.py:470); 0 = ephemeral, see vapx_ingest_ports */
+  int32_t port_out;         /* 50008 */
+  int32_t rx_threads;       /* 0 = 2 */
+  int32_t tx_threads;       /* 0 = 2 */
+  int32_t max_wait_us;      /* 0 = 2000 */
+  int32_t min_batch;        /* 0 = every connected stream */
+  int32_t reset_on_connect; /* 1 = a new input connection starts from a fresh stream state */
+  int32_t broadcast;        /* -1 = auto (1 for a single-stream engine), 0, 1 */
+  int32_t bind_any;         /* 0 = 127.0.0.1 like the reference, 1 = 0.0.0.0 */
+  double gain;              /* audio_gain, 1.0 = off */
+} vapx_ingest_config;
+
+typedef struct vapx_ingest_stats {
+  int64_t frames_done;      /* stream-frames stepped and answered */
+  int64_t ticks;            /* vapx_step calls */
+  int64_t rx_bytes, tx_bytes;
+  int64_t in_connections, out_connections;   /* currently open */
+  int64_t dropped_listeners;                 /* output connections closed because they could not take a packet */
+  int64_t numeric_resets;                    /* streams reset after non-finite results */
+  int64_t overruns;                          /* frames a sender delivered faster than the engine consumed (input paused) */
+  double mean_batch;                         /* streams per tick */
+  double lat_mean_ms, lat_p50_ms, lat_p99_ms, lat_max_ms;   /* frame complete on the host -> result packet handed to the kernel */
+  double step_mean_ms;                       /* time inside vapx_step per tick */
+} vapx_ingest_stats;
+
+int vapx_ingest_open(vapx_handle engine, const vapx_ingest_config* cfg, vapx_ingest_handle* out);
+/* The same front-end over a caller-supplied step function instead of an engine (host-logic tests without a GPU):
+ * step(user, n, stream_ids, audio[n][2][hop], out[n][VAPX_OUT_STRIDE]) returns 0 or a negative VAPX_E_* code;
+ * reset(user, stream_id) may be NULL. */
+typedef int (*vapx_ingest_step_fn)(void* user, int32_t n, const int32_t* stream_ids, const float* audio, float* out);
+typedef void (*vapx_ingest_reset_fn)(void* user, int32_t stream_id);
+int vapx_ingest_open_fn(vapx_ingest_step_fn step, vapx_ingest_reset_fn reset, void* user, int32_t n_streams, int32_t max_batch,
+                        int32_t frame_hz, int32_t mode, const vapx_ingest_config* cfg, vapx_ingest_handle* out);
+int vapx_ingest_ports(vapx_ingest_handle g, int32_t* port_in, int32_t* port_out);
+int vapx_ingest_stats_read(vapx_ingest_handle g, vapx_ingest_stats* out, int32_t reset_latency_window);
+void vapx_ingest_close(vapx_ingest_handle g);
+
+/* The wire codec on its own (byte-parity tests against the reference's util.py output, tests/golden/wire.npz).
+ * decode: n_bytes (a multiple of 16) of input packets -> n_bytes / 16 samples per channel as the engine sees them (f32) and as
+ * the result packet echoes them (f64, gain applied); either destination may be NULL.  Returns the sample count or < 0.
+ * encode: one result packet INCLUDING the 4-byte length prefix for an output row of vapx_step; x1 / x2 = the frame's n
+ * echoed samples; returns the packet size (or the size needed if dst is NULL / cap too small, nothing written). */
+int64_t vapx_wire_decode_input(const uint8_t* bytes, size_t n_bytes, double gain, float* x1_f32, float* x2_f32, double* x1_f64,
+                               double* x2_f64);
+int64_t vapx_wire_encode_result(int32_t mode, double t, const double* x1, const double* x2, int32_t n, const float* out_row,
+                                uint8_t* dst, size_t cap);
 
 const char* vapx_last_error(vapx_handle h);
 int32_t vapx_abi_version(void);

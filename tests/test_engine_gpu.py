@@ -332,7 +332,7 @@ def test_reset_is_stream_ordered_and_leaves_the_other_streams_alone():
             keep = np.arange(S) != victim
             np.testing.assert_array_equal(oa[keep], ob[keep])
             of = fresh.step(new[victim:victim + 1])
-            np.testing.assert_array_equal(oa[victim, :272], of[0, :272])
+            np.testing.assert_allclose(oa[victim, :272], of[0, :272], rtol=0, atol=2e-5)   # batch 1024 vs 1: different conv-tail kernels
             assert oa[victim, engine.OUT_NVALID] == f - 5
     a.close(); b.close(); fresh.close()
 

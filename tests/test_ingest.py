@@ -1,0 +1,259 @@
+"""Native front-end (libvapx vapx_ingest_* / vapx_wire_*): codec bytes == the reference's rvap/common/util.py output (goldens of
+the imported reference, tests/golden/wire.npz), and the socket plumbing — routing, ragged ticks, segmentation, back-pressure,
+broadcast, non-finite streams — over a Python step function (the real model has no CPU path)."""
+import os
+import socket
+import struct
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from vap_realtime_amd import engine, ingest, wire
+
+Z = np.load(os.path.join(os.path.dirname(__file__), "golden", "wire.npz"))
+
+
+def _row(mode):
+    row = np.zeros(engine.OUT_STRIDE, np.float32)
+    if mode == "vap":
+        row[0:2], row[2:4], row[4:6] = Z["vap.p_now"], Z["vap.p_future"], Z["vap.vad"]
+    elif mode == "bc":
+        row[engine.OUT_AUX + 1], row[engine.OUT_AUX + 2] = Z["bc.p_bc_react"][0], Z["bc.p_bc_emo"][0]
+    else:
+        row[engine.OUT_NVALID] = 50
+        row[engine.OUT_LOGITS:engine.OUT_LOGITS + 50] = Z["nod.p_bc"]
+        row[engine.OUT_AUX + 1], row[engine.OUT_AUX + 2], row[engine.OUT_AUX + 3] = Z["nod.p_nod_short"][0], Z["nod.p_nod_long"][0], Z["nod.p_nod_long_p"][0]
+    return row
+
+
+def test_native_input_decode_equals_reference_codec():
+    b = bytes(Z["in.bytes"])
+    x1, x2, f1, f2 = ingest.decode_input(b)
+    np.testing.assert_array_equal(x1, Z["in.x1"])
+    np.testing.assert_array_equal(x2, Z["in.x2"])
+    np.testing.assert_array_equal(f1, Z["in.x1"].astype(np.float32))        # the f64 -> f32 cast of vap_main.py:266-270
+    g1, _, h1, _ = ingest.decode_input(b, gain=1.5)
+    np.testing.assert_array_equal(g1, Z["in.x1"] * 1.5)                     # float64 multiply before the cast (:393-395)
+    np.testing.assert_array_equal(h1, (Z["in.x1"] * 1.5).astype(np.float32))
+    with pytest.raises(ValueError):
+        ingest.decode_input(b"\0" * 17)
+
+
+@pytest.mark.parametrize("mode", ["vap", "bc", "nod"])
+def test_native_result_packet_bytes_equal_reference_codec(mode):
+    """The golden bytes were produced by util.conv_vapresult_2_bytearray(/_bc/_nod) from float64 head values; the engine's
+    heads are float32, so the comparison uses the float32-representable values of the same numbers on both sides."""
+    keys = {"vap": ("p_now", "p_future", "vad"), "bc": ("p_bc_react", "p_bc_emo"), "nod": ("p_bc", "p_nod_short", "p_nod_long", "p_nod_long_p")}[mode]
+    res = {"t": float(Z["vap.t"]), "x1": Z["vap.x1"], "x2": Z["vap.x2"]}
+    for k in keys:
+        res[k] = np.asarray(Z[f"{mode}.{k}"], np.float32).astype(np.float64)
+    want = wire.frame_result(res, mode)                # wire.py is proven byte-identical to the reference in test_wire.py
+    got = ingest.encode_result(mode, float(Z["vap.t"]), Z["vap.x1"], Z["vap.x2"], _row(mode))
+    assert got == want
+    assert len(got) == 4 + len(bytes(Z[f"{mode}.bytes"]))
+    # where the golden's head values are exactly float32-representable the packet equals the REFERENCE's bytes outright
+    ref = bytes(Z[f"{mode}.bytes"])
+    n_echo = 8 + 2 * (4 + 8 * 800)
+    assert got[4:4 + n_echo] == ref[:n_echo]
+
+
+class Model:
+    """p_now = mean |x| per channel of the frame, p_future reversed: routing errors show up in the numbers."""
+
+    def __init__(self, poison=()):
+        self.calls, self.resets, self.poison = [], [], set(poison)
+
+    def step(self, ids, audio, out):
+        self.calls.append(ids.tolist())
+        m = np.abs(audio).mean(axis=2)
+        out[:, 0:2] = m
+        out[:, 2:4] = m[:, ::-1]
+        out[:, 4:6] = (m > 0.5)
+        for k, s in enumerate(ids):
+            if int(s) in self.poison:
+                out[k, engine.OUT_STATUS] = 1.0
+        return 0
+
+    def reset(self, sid):
+        self.resets.append(sid)
+
+
+def _recv_exact(sock, n):
+    b = b""
+    while len(b) < n:
+        chunk = sock.recv(n - len(b))
+        assert chunk, "socket closed"
+        b += chunk
+    return b
+
+
+def _read_result(sock, mode="vap"):
+    sock.settimeout(10)
+    ln = struct.unpack("<I", _recv_exact(sock, 4))[0]
+    return ln, wire.decode_result(_recv_exact(sock, ln), mode)
+
+
+def _wait(cond, timeout=5.0):
+    t0 = time.time()
+    while not cond() and time.time() - t0 < timeout:
+        time.sleep(0.005)
+    assert cond()
+
+
+def test_two_streams_routed_framed_and_segmentation_agnostic():
+    hop = 800
+    m = Model()
+    srv = ingest.NativeServer.over_function(m.step, 4, 20, reset=m.reset, max_wait_s=0.5)
+    try:
+        ins = [socket.create_connection(("127.0.0.1", srv.port_in)) for _ in range(2)]
+        _wait(lambda: srv.stats()["in_connections"] == 2)
+        outs = [socket.create_connection(("127.0.0.1", srv.port_out)) for _ in range(2)]
+        _wait(lambda: srv.stats()["out_connections"] == 2)
+        rng = np.random.default_rng(5)
+        x = rng.standard_normal((2, 2, 3 * hop)) * np.array([0.1, 2.0])[:, None, None]
+        for f in range(3):
+            for s in range(2):
+                data = wire.encode_input(x[s, 0, f * hop:(f + 1) * hop], x[s, 1, f * hop:(f + 1) * hop])
+                if f == 0:                                  # 2560-byte packets like the reference client
+                    for p in range(5):
+                        ins[s].sendall(data[p * 2560:(p + 1) * 2560])
+                elif f == 1:                                # odd segmentation: sample pairs split across sends
+                    for a, b in ((0, 7), (7, 5003), (5003, 5004), (5004, len(data))):
+                        ins[s].sendall(data[a:b])
+                        time.sleep(0.002)
+                else:
+                    ins[s].sendall(data)                    # the whole frame at once
+            for s in range(2):
+                ln, r = _read_result(outs[s])
+                assert ln == 12876
+                np.testing.assert_array_equal(r["x1"], x[s, 0, f * hop:(f + 1) * hop])     # float64 echo, bit-exact
+                np.testing.assert_array_equal(r["x2"], x[s, 1, f * hop:(f + 1) * hop])
+                want = np.abs(x[s, :, f * hop:(f + 1) * hop].astype(np.float32)).mean(axis=1)
+                np.testing.assert_allclose(r["p_now"], want, rtol=1e-6)
+                np.testing.assert_allclose(r["p_future"], want[::-1], rtol=1e-6)
+                assert abs(r["t"] - time.time()) < 30
+        assert sorted(m.resets) == [0, 1]
+        assert all(sorted(c) == [0, 1] for c in m.calls) and len(m.calls) == 3
+        st = srv.stats()
+        assert st["frames_done"] == 6 and st["ticks"] == 3 and st["mean_batch"] == 2.0 and st["lat_p99_ms"] > 0
+    finally:
+        srv.close()
+
+
+def test_ragged_tick_when_one_stream_lags_and_carry_only_reset():
+    m = Model()
+    srv = ingest.NativeServer.over_function(m.step, 2, 50, reset=m.reset, max_wait_s=0.05, reset_on_connect=False)
+    try:
+        a = socket.create_connection(("127.0.0.1", srv.port_in))
+        b = socket.create_connection(("127.0.0.1", srv.port_in))
+        _wait(lambda: srv.stats()["in_connections"] == 2)
+        z = np.zeros(160)
+        for _ in range(2):
+            a.sendall(wire.encode_input(z, z))
+        b.sendall(wire.encode_input(z, z))              # b has only half a 50 Hz frame
+        _wait(lambda: len(m.calls) >= 1)
+        assert m.calls[0] == [0]                        # only stream 0 was stepped
+        b.sendall(wire.encode_input(z, z))
+        _wait(lambda: len(m.calls) >= 2)
+        assert m.calls[1] == [1]
+        assert sorted(m.resets) == [-2, -1]             # reset_on_connect=False: carry-only resets, like vap_main.py:368-369
+    finally:
+        srv.close()
+
+
+def test_single_stream_broadcasts_like_the_reference():
+    m = Model()
+    srv = ingest.NativeServer.over_function(m.step, 1, 20)
+    try:
+        i = socket.create_connection(("127.0.0.1", srv.port_in))
+        outs = [socket.create_connection(("127.0.0.1", srv.port_out)) for _ in range(3)]
+        _wait(lambda: srv.stats()["out_connections"] == 3 and srv.stats()["in_connections"] == 1)
+        z = np.ones(800)
+        i.sendall(wire.encode_input(z, z))
+        for o in outs:
+            _, r = _read_result(o)
+            assert r["p_now"] == [1.0, 1.0]
+    finally:
+        srv.close()
+
+
+def test_non_finite_stream_is_reset_and_skipped_the_others_are_served():
+    m = Model(poison=[1])
+    srv = ingest.NativeServer.over_function(m.step, 2, 20, reset=m.reset, max_wait_s=0.5, reset_on_connect=False)
+    try:
+        ins = [socket.create_connection(("127.0.0.1", srv.port_in)) for _ in range(2)]
+        _wait(lambda: srv.stats()["in_connections"] == 2)
+        outs = [socket.create_connection(("127.0.0.1", srv.port_out)) for _ in range(2)]
+        _wait(lambda: srv.stats()["out_connections"] == 2)
+        for f in range(2):
+            for s in range(2):
+                ins[s].sendall(wire.encode_input(np.full(800, 0.5), np.full(800, 0.25)))
+            _, r = _read_result(outs[0])
+            assert r["p_now"] == [0.5, 0.25]
+        outs[1].settimeout(0.3)
+        with pytest.raises(socket.timeout):
+            outs[1].recv(4)
+        assert [r for r in m.resets if r >= 0] == [1, 1] and srv.stats()["numeric_resets"] == 2
+    finally:
+        srv.close()
+
+
+def test_a_sender_that_outruns_the_engine_is_paused_not_dropped():
+    """Ten frames pushed at once into a model that takes 30 ms per tick: the connection is back-pressured (at most three
+    frames buffered), every frame is answered, in order."""
+    hop = 800
+
+    class Slow(Model):
+        def step(self, ids, audio, out):
+            time.sleep(0.03)
+            return super().step(ids, audio, out)
+
+    m = Slow()
+    srv = ingest.NativeServer.over_function(m.step, 1, 20, max_wait_s=0.001)
+    try:
+        i = socket.create_connection(("127.0.0.1", srv.port_in))
+        o = socket.create_connection(("127.0.0.1", srv.port_out))
+        _wait(lambda: srv.stats()["out_connections"] == 1 and srv.stats()["in_connections"] == 1)
+        level = [0.1 * (k + 1) for k in range(10)]
+        blob = b"".join(wire.encode_input(np.full(hop, v), np.full(hop, v)) for v in level)
+        threading.Thread(target=i.sendall, args=(blob,), daemon=True).start()
+        for v in level:
+            _, r = _read_result(o)
+            np.testing.assert_allclose(r["p_now"], [np.float32(v)] * 2, rtol=1e-6)
+        assert srv.stats()["overruns"] >= 1 and srv.stats()["frames_done"] == 10
+    finally:
+        srv.close()
+
+
+def test_connection_burst_and_reconnect_reuse_slots():
+    S, hop = 300, 800
+    m = Model()
+    srv = ingest.NativeServer.over_function(m.step, S, 20, reset=m.reset, max_wait_s=0.02)
+    ins, outs = [], []
+    try:
+        for _ in range(S):
+            ins.append(socket.create_connection(("127.0.0.1", srv.port_in), timeout=10))
+        _wait(lambda: srv.stats()["in_connections"] == S, 10)
+        for _ in range(S):
+            outs.append(socket.create_connection(("127.0.0.1", srv.port_out), timeout=10))
+        _wait(lambda: srv.stats()["out_connections"] == S, 10)
+        for k, s in enumerate(ins):
+            s.sendall(wire.encode_input(np.full(hop, 0.001 * (k + 1)), np.full(hop, -0.5)))
+        for k, s in enumerate(outs):                      # the k-th output connection hears the k-th stream
+            _, r = _read_result(s)
+            assert abs(r["p_now"][0] - 0.001 * (k + 1)) < 1e-6 and abs(r["p_now"][1] - 0.5) < 1e-6
+        ins[7].close()                                    # a dialogue ends, a new client takes the lowest free slot (7)
+        _wait(lambda: srv.stats()["in_connections"] == S - 1)
+        n = socket.create_connection(("127.0.0.1", srv.port_in))
+        ins[7] = n
+        _wait(lambda: srv.stats()["in_connections"] == S)
+        n.sendall(wire.encode_input(np.full(hop, 0.9), np.full(hop, 0.9)))
+        _, r = _read_result(outs[7])
+        assert abs(r["p_now"][0] - 0.9) < 1e-6
+        assert m.resets.count(7) == 2
+    finally:
+        for s in ins + outs:
+            s.close()
+        srv.close()

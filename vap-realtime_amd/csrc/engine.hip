@@ -432,10 +432,14 @@ __global__ void fill_int_kernel(int* p, int v, int n) {
 // stream-ordered reset of up to 16 stream slots: LSTM h/c, carry and window fill back to zero (the rings need no
 // clearing: rows beyond frames_seen are never read).  One workgroup per slot.
 struct ResetList { int n; int ids[16]; int* fs[4]; };   // fs[0] = this engine's frames_seen, fs[1..] = trunk followers'
+// ids[k] < 0 encodes "carry only" for stream -ids[k] - 1 (what a reconnect does in the reference, vap_main.py:368-369)
 __global__ void reset_streams_kernel(ResetList r, float* h_state, float* c_state, float* carry) {
-  const int sid = r.ids[blockIdx.x];
-  for (int i = threadIdx.x; i < 512; i += blockDim.x) { h_state[(long)sid * 512 + i] = 0.f; c_state[(long)sid * 512 + i] = 0.f; }
+  const int raw = r.ids[blockIdx.x];
+  const bool carry_only = raw < 0;
+  const int sid = carry_only ? -raw - 1 : raw;
   for (int i = threadIdx.x; i < 2 * VAPX_PAD; i += blockDim.x) carry[(long)sid * 2 * VAPX_PAD + i] = 0.f;
+  if (carry_only) return;
+  for (int i = threadIdx.x; i < 512; i += blockDim.x) { h_state[(long)sid * 512 + i] = 0.f; c_state[(long)sid * 512 + i] = 0.f; }
   if (threadIdx.x < 4 && r.fs[threadIdx.x]) r.fs[threadIdx.x][sid] = 0;
 }
 __global__ void add_kernel(float* o, const float* a, const float* b, long n) {
@@ -486,7 +490,8 @@ int flush_resets(vapx_engine* h, hipStream_t st) {
     for (int k = 0; k < r.n; ++k) r.ids[k] = h->pending_resets[i + k];
     hipLaunchKernelGGL(reset_streams_kernel, dim3(r.n), dim3(256), 0, st, r, h->h_state, h->c_state, h->carry);
     for (size_t f = 3; f < h->followers.size(); ++f)
-      for (int k = 0; k < r.n; ++k) hipLaunchKernelGGL(fill_int_kernel, dim3(1), dim3(64), 0, st, h->followers[f]->frames_seen + r.ids[k], 0, 1);
+      for (int k = 0; k < r.n; ++k)
+        if (r.ids[k] >= 0) hipLaunchKernelGGL(fill_int_kernel, dim3(1), dim3(64), 0, st, h->followers[f]->frames_seen + r.ids[k], 0, 1);
   }
   HIPCHK(h, hipGetLastError());
   h->pending_resets.clear();
@@ -915,9 +920,27 @@ int vapx_reset_stream(vapx_handle h, int32_t sid) {
   if (h->trunk) return fail(h, VAPX_E_INVAL, "reset the trunk leader: it resets its followers too");
   // No device work and no synchronisation here: the request is queued and the NEXT vapx_step applies it with one tiny
   // kernel ordered on its HIP stream, before that step touches any state — a joining client costs the other streams nothing.
-  for (int32_t q : h->pending_resets)
+  for (int32_t& q : h->pending_resets) {
     if (q == sid) return VAPX_OK;
+    if (q == -sid - 1) { q = sid; return VAPX_OK; }   // a queued carry-only reset is subsumed
+  }
   h->pending_resets.push_back(sid);
+  return VAPX_OK;
+}
+
+int vapx_reset_carry(vapx_handle h, int32_t sid) {
+  if (!h) return VAPX_E_INVAL;
+  if (sid < 0 || sid >= h->cfg.max_streams) return fail(h, VAPX_E_RANGE, "stream id out of range");
+  if (h->trunk) return fail(h, VAPX_E_INVAL, "the carry lives in the trunk leader");
+  for (int32_t q : h->pending_resets)
+    if (q == sid || q == -sid - 1) return VAPX_OK;   // a full reset (or the same request) is already queued
+  h->pending_resets.push_back(-sid - 1);
+  return VAPX_OK;
+}
+
+int vapx_get_config(vapx_handle h, vapx_config* out) {
+  if (!h || !out) return VAPX_E_INVAL;
+  *out = h->cfg;
   return VAPX_OK;
 }
 

@@ -1,0 +1,815 @@
+// Native many-stream TCP front-end of libvapx (include/vapx.h, "vapx_ingest_*"), host code only.
+//
+// Reference being replaced: proc_serv_in / proc_serv_out / proc_serv_out_dist, rvap/vap_main/vap_main.py:338-457, and the
+// per-sample Python codec rvap/common/util.py:52-237 — one dialogue per process there, thousands per process here.
+//
+//   rx threads (epoll)      recv -> decode f64 pairs -> per-stream frame buffers (f32 staging in page-locked memory + the
+//                           f64 echo the result packet carries); a complete frame is queued for the tick thread
+//   tick thread             batches the ready frames (ragged), vapx_step (host in / host out), hands rows to the senders
+//   tx threads              encode header / tail, sendmsg() with the echo arrays as iovecs (no copy), free the frame buffer
+//
+// Every stream owns NBUF frame buffers (filling / waiting / in flight / being sent), so reception never waits for the GPU
+// unless a sender outruns the engine by two whole frames; then the connection is paused (TCP back-pressure), never dropped.
+#include <arpa/inet.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/epoll.h>
+#include <sys/eventfd.h>
+#include <sys/socket.h>
+#include <sys/uio.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/vapx.h"
+
+namespace {
+
+constexpr int NBUF = 3;
+constexpr int PAIR_BYTES = 16;                 // one sample of both channels: f64 ch1, f64 ch2 (util.py:52-62)
+enum BufState : int { B_FREE = 0, B_FILLING = 1, B_READY = 2, B_INFLIGHT = 3 };
+
+double mono_now() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+double unix_now() {
+  timespec ts;
+  clock_gettime(CLOCK_REALTIME, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+// ---- codec ---------------------------------------------------------------------------------------
+inline void put_u32(uint8_t*& p, uint32_t v) { memcpy(p, &v, 4); p += 4; }   // little-endian host (x86-64 / the GPU box)
+inline void put_f64(uint8_t*& p, double v) { memcpy(p, &v, 8); p += 8; }
+
+// number of head values after the echo blocks, by mode
+int tail_bytes(int mode, int n_rows_pbc) {
+  if (mode == VAPX_MODE_VAP) return 3 * (4 + 16);
+  if (mode == VAPX_MODE_BC) return 2 * (4 + 8);
+  return (4 + 8 * n_rows_pbc) + 3 * (4 + 8);
+}
+
+// heads of one out row -> tail of the packet (after "u32 n | x2"); returns bytes written
+int encode_tail(int mode, const float* row, uint8_t* dst) {
+  uint8_t* p = dst;
+  if (mode == VAPX_MODE_VAP) {            // u32 2 | p_now | u32 2 | p_future | u32 2 | vad   (util.py:134-141)
+    for (int blk = 0; blk < 3; ++blk) {
+      put_u32(p, 2);
+      put_f64(p, (double)row[blk * 2]);
+      put_f64(p, (double)row[blk * 2 + 1]);
+    }
+  } else if (mode == VAPX_MODE_BC) {      // u32 1 | p_bc_react | u32 1 | p_bc_emo            (util.py:193-211)
+    put_u32(p, 1); put_f64(p, (double)row[VAPX_OUT_AUX + 1]);
+    put_u32(p, 1); put_f64(p, (double)row[VAPX_OUT_AUX + 2]);
+  } else {                                // u32 n | p_bc rows | 3 x (u32 1 | p)              (util.py:213-237, vap_nod_main.py:276)
+    const int n = (int)row[VAPX_OUT_NVALID];
+    put_u32(p, (uint32_t)n);
+    for (int i = 0; i < n; ++i) put_f64(p, (double)row[VAPX_OUT_LOGITS + i]);
+    for (int k = 1; k <= 3; ++k) { put_u32(p, 1); put_f64(p, (double)row[VAPX_OUT_AUX + k]); }
+  }
+  return (int)(p - dst);
+}
+
+struct Hist {   // log2-spaced latency histogram, 8 sub-buckets per octave from 1 us
+  static constexpr int N = 8 * 27;
+  std::atomic<int64_t> b[N];
+  std::atomic<int64_t> cnt{0};
+  std::atomic<int64_t> sum_us{0};
+  std::atomic<int64_t> max_us{0};
+  Hist() { for (auto& x : b) x = 0; }
+  void add(double sec) {
+    double us = sec * 1e6;
+    if (us < 1.0) us = 1.0;
+    int k = (int)(log2(us) * 8.0);
+    if (k >= N) k = N - 1;
+    b[k].fetch_add(1, std::memory_order_relaxed);
+    cnt.fetch_add(1, std::memory_order_relaxed);
+    sum_us.fetch_add((int64_t)us, std::memory_order_relaxed);
+    int64_t m = max_us.load(std::memory_order_relaxed), v = (int64_t)us;
+    while (v > m && !max_us.compare_exchange_weak(m, v, std::memory_order_relaxed)) {}
+  }
+  double pct(double q) const {
+    int64_t total = cnt.load(), acc = 0;
+    if (total == 0) return 0.0;
+    int64_t want = (int64_t)ceil(q * (double)total);
+    for (int k = 0; k < N; ++k) {
+      acc += b[k].load();
+      if (acc >= want) return exp2((k + 1) / 8.0) * 1e-3;   // upper edge of the bucket, ms
+    }
+    return (double)max_us.load() * 1e-3;
+  }
+  void clear() { for (auto& x : b) x = 0; cnt = 0; sum_us = 0; max_us = 0; }
+};
+
+struct Slot {
+  int fd_in = -1;
+  uint32_t gen = 0;                       // bumped per connection: queued frames of a dead connection are dropped
+  std::atomic<int> state[NBUF];
+  double t_ready[NBUF] = {0, 0, 0};
+  int wbuf = -1, fill = 0;                // rx thread only
+  uint8_t partial[PAIR_BYTES]; int npartial = 0;
+  std::vector<uint8_t> backlog;           // bytes received while no buffer was free
+  bool paused = false;
+  std::mutex lmu;                         // guards listeners
+  std::vector<int> listeners;
+  Slot() { for (auto& s : state) s = B_FREE; }
+};
+
+struct Ready { int slot; int buf; uint32_t gen; double t; };
+
+struct Job {                               // one tick's rows on their way out
+  int n = 0;
+  std::vector<Ready> rows;
+  float* out = nullptr;                    // [max_batch][VAPX_OUT_STRIDE] pinned
+  double t_unix = 0;
+  int claimed = 0, finished = 0;          // rows handed to / completed by the senders (under job_mu)
+  bool busy = false;
+};
+
+}  // namespace
+
+struct vapx_ingest {
+  vapx_ingest_config cfg;
+  vapx_ingest_step_fn step = nullptr;
+  vapx_ingest_reset_fn reset = nullptr;
+  void* user = nullptr;
+  vapx_handle engine = nullptr;
+  int S = 0, max_batch = 0, hop = 0, mode = 0, hz = 0;
+  bool broadcast = false;
+  int R = 2, X = 2;
+
+  std::unique_ptr<Slot[]> slots;
+  float* stage = nullptr;                  // pinned [S][NBUF][2][hop] f32
+  std::vector<double> echo;                // [S][NBUF][2][hop] f64
+  float* batch_audio = nullptr;            // pinned [max_batch][2][hop]
+  std::vector<int32_t> batch_ids;
+  Job jobs[2];
+
+  int lin = -1, lout = -1;
+  int port_in = 0, port_out = 0;
+  std::vector<int> ep;                     // epoll fd per rx thread
+  std::vector<int> wake;                   // eventfd per rx thread (resume / stop)
+  std::vector<std::thread> rx_threads, tx_threads;
+  std::thread tick_thread;
+  std::atomic<bool> stop{false};
+
+  std::mutex slots_mu;                     // slot allocation, out_all
+  std::vector<int> out_all;                // broadcast listeners
+  std::mutex ready_mu;
+  std::condition_variable ready_cv;
+  std::vector<Ready> ready;                // rx -> tick
+  std::vector<std::pair<int, int>> resets; // (slot, carry_only) rx -> tick, under ready_mu
+  std::vector<std::mutex> resume_mu;
+  std::vector<std::vector<int>> resume;    // tick/tx -> rx: slots with a free buffer again
+
+  std::mutex job_mu;
+  std::condition_variable job_cv, job_done_cv;
+  std::deque<int> job_queue;
+
+  // stats
+  std::atomic<int64_t> frames_done{0}, ticks{0}, rx_bytes{0}, tx_bytes{0}, in_conns{0}, out_conns{0}, dropped{0}, numeric_resets{0},
+      overruns{0}, batch_sum{0};
+  std::atomic<int64_t> step_us{0};
+  Hist lat;
+  std::string err;
+  bool pinned_blocks = true;               // staging came from vapx_host_alloc (false: plain calloc, no HIP device)
+
+  float* f32buf(int slot, int buf) { return stage + ((size_t)slot * NBUF + buf) * 2 * hop; }
+  double* f64buf(int slot, int buf) { return echo.data() + ((size_t)slot * NBUF + buf) * 2 * hop; }
+};
+
+namespace {
+
+int listen_on(int port, bool any, int* bound) {
+  int s = socket(AF_INET, SOCK_STREAM | SOCK_NONBLOCK, 0);
+  if (s < 0) return -1;
+  int one = 1;
+  setsockopt(s, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
+  sockaddr_in a;
+  memset(&a, 0, sizeof a);
+  a.sin_family = AF_INET;
+  a.sin_addr.s_addr = htonl(any ? INADDR_ANY : INADDR_LOOPBACK);
+  a.sin_port = htons((uint16_t)port);
+  if (bind(s, (sockaddr*)&a, sizeof a) != 0 || listen(s, 8192) != 0) { close(s); return -1; }
+  socklen_t len = sizeof a;
+  getsockname(s, (sockaddr*)&a, &len);
+  *bound = ntohs(a.sin_port);
+  return s;
+}
+
+// tags in epoll_event.data.u64: low 32 bits slot (or a listen-socket / wake id), high bits kind
+constexpr uint64_t K_DATA = 0, K_LISTEN_IN = 1ull << 32, K_LISTEN_OUT = 2ull << 32, K_WAKE = 3ull << 32;
+
+void ep_add(int ep, int fd, uint64_t tag) {
+  epoll_event ev;
+  memset(&ev, 0, sizeof ev);
+  ev.events = EPOLLIN;
+  ev.data.u64 = tag;
+  epoll_ctl(ep, EPOLL_CTL_ADD, fd, &ev);
+}
+void ep_mod(int ep, int fd, uint64_t tag, bool want_in) {
+  epoll_event ev;
+  memset(&ev, 0, sizeof ev);
+  ev.events = want_in ? EPOLLIN : 0;
+  ev.data.u64 = tag;
+  epoll_ctl(ep, EPOLL_CTL_MOD, fd, &ev);
+}
+
+void kick(int efd) {
+  uint64_t one = 1;
+  ssize_t r = write(efd, &one, 8);
+  (void)r;
+}
+
+int pick_free(Slot& s) {
+  for (int b = 0; b < NBUF; ++b) {
+    int expect = B_FREE;
+    if (s.state[b].compare_exchange_strong(expect, B_FILLING)) return b;
+  }
+  return -1;
+}
+
+// free a frame buffer and, if its stream was paused for lack of buffers, ask its rx thread to resume it
+void release_buf(vapx_ingest* g, int slot, int buf) {
+  g->slots[slot].state[buf].store(B_FREE, std::memory_order_release);
+  const int r = slot % g->R;
+  bool need = false;
+  {
+    std::lock_guard<std::mutex> lk(g->resume_mu[r]);
+    // `paused` is owned by the rx thread; a stale read only costs a spurious wake-up
+    if (g->slots[slot].paused) { g->resume[r].push_back(slot); need = true; }
+  }
+  if (need) kick(g->wake[r]);
+}
+
+void drop_input(vapx_ingest* g, int r, int slot) {
+  Slot& s = g->slots[slot];
+  if (s.fd_in < 0) return;
+  epoll_ctl(g->ep[r], EPOLL_CTL_DEL, s.fd_in, nullptr);
+  close(s.fd_in);
+  if (s.wbuf >= 0) { s.state[s.wbuf].store(B_FREE); s.wbuf = -1; }
+  s.fill = 0; s.npartial = 0; s.backlog.clear(); s.paused = false;
+  {
+    std::lock_guard<std::mutex> lk(g->slots_mu);
+    s.fd_in = -1;
+    ++s.gen;                                // frames of this connection still queued are dropped by the tick thread
+  }
+  g->in_conns.fetch_sub(1);
+}
+
+// decode `n` bytes of the stream into the slot's frame buffers; returns bytes consumed (< n: no free buffer)
+size_t feed(vapx_ingest* g, int slot, const uint8_t* p, size_t n) {
+  Slot& s = g->slots[slot];
+  const int hop = g->hop;
+  const double gain = g->cfg.gain;
+  size_t used = 0;
+  while (used < n) {
+    if (s.wbuf < 0) {
+      s.wbuf = pick_free(s);
+      if (s.wbuf < 0) return used;          // engine is two frames behind this sender
+      s.fill = 0;
+    }
+    if (s.npartial) {                       // finish a sample pair split across two reads
+      size_t take = std::min<size_t>(PAIR_BYTES - s.npartial, n - used);
+      memcpy(s.partial + s.npartial, p + used, take);
+      s.npartial += (int)take; used += take;
+      if (s.npartial < PAIR_BYTES) break;
+      double v[2];
+      memcpy(v, s.partial, PAIR_BYTES);
+      s.npartial = 0;
+      float* f = g->f32buf(slot, s.wbuf);
+      double* d = g->f64buf(slot, s.wbuf);
+      const double a = gain != 1.0 ? v[0] * gain : v[0], b = gain != 1.0 ? v[1] * gain : v[1];
+      d[s.fill] = a; d[hop + s.fill] = b;
+      f[s.fill] = (float)a; f[hop + s.fill] = (float)b;
+      ++s.fill;
+    } else {
+      size_t pairs = std::min<size_t>((n - used) / PAIR_BYTES, (size_t)(hop - s.fill));
+      if (pairs == 0) {                     // fewer than 16 bytes left: keep them for the next read
+        size_t rest = n - used;
+        if (rest >= (size_t)PAIR_BYTES) { /* frame full, handled below */ }
+        else { memcpy(s.partial, p + used, rest); s.npartial = (int)rest; used = n; break; }
+      }
+      float* f = g->f32buf(slot, s.wbuf) + s.fill;
+      double* d = g->f64buf(slot, s.wbuf) + s.fill;
+      const uint8_t* q = p + used;
+      if (gain != 1.0) {
+        for (size_t i = 0; i < pairs; ++i) {
+          double v[2];
+          memcpy(v, q + i * PAIR_BYTES, PAIR_BYTES);
+          const double a = v[0] * gain, b = v[1] * gain;     // float64 multiply BEFORE the f32 cast (vap_main.py:393-395)
+          d[i] = a; d[hop + i] = b;
+          f[i] = (float)a; f[hop + i] = (float)b;
+        }
+      } else {
+        for (size_t i = 0; i < pairs; ++i) {
+          double v[2];
+          memcpy(v, q + i * PAIR_BYTES, PAIR_BYTES);
+          d[i] = v[0]; d[hop + i] = v[1];
+          f[i] = (float)v[0]; f[hop + i] = (float)v[1];       // == torch.tensor(float64).float() (vap_main.py:266-270)
+        }
+      }
+      s.fill += (int)pairs;
+      used += pairs * PAIR_BYTES;
+    }
+    if (s.fill == hop) {                    // frame complete -> tick thread
+      const int b = s.wbuf;
+      const double t = mono_now();
+      s.t_ready[b] = t;
+      s.state[b].store(B_READY, std::memory_order_release);
+      s.wbuf = -1; s.fill = 0;
+      {
+        std::lock_guard<std::mutex> lk(g->ready_mu);
+        g->ready.push_back({slot, b, s.gen, t});
+      }
+      g->ready_cv.notify_one();
+    }
+  }
+  return used;
+}
+
+void on_data(vapx_ingest* g, int r, int slot, uint8_t* scratch, size_t cap) {
+  Slot& s = g->slots[slot];
+  if (s.fd_in < 0) return;
+  for (int round = 0; round < 4; ++round) {   // bounded work per wake-up: fairness between streams
+    ssize_t n = recv(s.fd_in, scratch, cap, 0);
+    if (n < 0) {
+      if (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR) return;
+      drop_input(g, r, slot);
+      return;
+    }
+    if (n == 0) { drop_input(g, r, slot); return; }
+    g->rx_bytes.fetch_add(n, std::memory_order_relaxed);
+    size_t used = feed(g, slot, scratch, (size_t)n);
+    if (used < (size_t)n) {                 // no free frame buffer: park the rest and stop reading this socket
+      s.backlog.assign(scratch + used, scratch + n);
+      {
+        std::lock_guard<std::mutex> lk(g->resume_mu[r]);
+        s.paused = true;
+      }
+      g->overruns.fetch_add(1);
+      ep_mod(g->ep[r], s.fd_in, K_DATA | (uint32_t)slot, false);
+      // a buffer may have been released between pick_free and `paused = true`
+      for (int b = 0; b < NBUF; ++b)
+        if (s.state[b].load() == B_FREE) {
+          std::lock_guard<std::mutex> lk(g->resume_mu[r]);
+          g->resume[r].push_back(slot);
+          kick(g->wake[r]);
+          break;
+        }
+      return;
+    }
+    if ((size_t)n < cap) return;
+  }
+}
+
+void do_resume(vapx_ingest* g, int r, int slot) {
+  Slot& s = g->slots[slot];
+  if (s.fd_in < 0 || !s.paused) return;
+  if (!s.backlog.empty()) {
+    std::vector<uint8_t> b;
+    b.swap(s.backlog);
+    size_t used = feed(g, slot, b.data(), b.size());
+    if (used < b.size()) { s.backlog.assign(b.begin() + used, b.end()); return; }   // still no buffer: stay paused
+  }
+  {
+    std::lock_guard<std::mutex> lk(g->resume_mu[r]);
+    s.paused = false;
+  }
+  ep_mod(g->ep[r], s.fd_in, K_DATA | (uint32_t)slot, true);
+}
+
+void accept_in(vapx_ingest* g) {
+  for (;;) {
+    int fd = accept4(g->lin, nullptr, nullptr, SOCK_NONBLOCK);
+    if (fd < 0) return;
+    int slot = -1;
+    {
+      std::lock_guard<std::mutex> lk(g->slots_mu);
+      for (int i = 0; i < g->S; ++i)
+        if (g->slots[i].fd_in < 0) { slot = i; break; }
+      if (slot >= 0) g->slots[slot].fd_in = fd;
+    }
+    if (slot < 0) { close(fd); continue; }   // every stream slot is taken
+    int one = 1;
+    setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+    Slot& s = g->slots[slot];
+    s.wbuf = -1; s.fill = 0; s.npartial = 0; s.backlog.clear(); s.paused = false;
+    {
+      // the carry restarts from zeros for every connection (vap_main.py:368-369); reset_on_connect also clears the
+      // model state, which the reference keeps.  Applied by the tick thread before its next step.
+      std::lock_guard<std::mutex> lk(g->ready_mu);
+      g->resets.push_back({slot, g->cfg.reset_on_connect ? 0 : 1});
+    }
+    g->in_conns.fetch_add(1);
+    ep_add(g->ep[slot % g->R], fd, K_DATA | (uint32_t)slot);
+  }
+}
+
+void accept_out(vapx_ingest* g) {
+  for (;;) {
+    int fd = accept4(g->lout, nullptr, nullptr, SOCK_NONBLOCK);   // non-blocking like vap_main.py:346-347
+    if (fd < 0) return;
+    int one = 1;
+    setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+    g->out_conns.fetch_add(1);
+    std::lock_guard<std::mutex> lk(g->slots_mu);
+    if (g->broadcast) { g->out_all.push_back(fd); continue; }
+    int best = 0;
+    size_t bl = (size_t)-1;
+    for (int i = 0; i < g->S; ++i) {
+      std::lock_guard<std::mutex> l2(g->slots[i].lmu);
+      if (g->slots[i].listeners.size() < bl) { bl = g->slots[i].listeners.size(); best = i; if (bl == 0) break; }
+    }
+    std::lock_guard<std::mutex> l2(g->slots[best].lmu);
+    g->slots[best].listeners.push_back(fd);
+  }
+}
+
+void rx_main(vapx_ingest* g, int r) {
+  std::vector<uint8_t> scratch(256 * 1024);
+  epoll_event evs[256];
+  while (!g->stop.load()) {
+    int n = epoll_wait(g->ep[r], evs, 256, 100);
+    for (int i = 0; i < n; ++i) {
+      const uint64_t tag = evs[i].data.u64, kind = tag & ~0xffffffffull;
+      if (kind == K_LISTEN_IN) accept_in(g);
+      else if (kind == K_LISTEN_OUT) accept_out(g);
+      else if (kind == K_WAKE) {
+        uint64_t v;
+        ssize_t rr = read(g->wake[r], &v, 8);
+        (void)rr;
+        std::vector<int> todo;
+        {
+          std::lock_guard<std::mutex> lk(g->resume_mu[r]);
+          todo.swap(g->resume[r]);
+        }
+        for (int slot : todo) do_resume(g, r, slot);
+      } else on_data(g, r, (int)(tag & 0xffffffffu), scratch.data(), scratch.size());
+    }
+  }
+}
+
+// send one result packet to one listener; false = the listener could not take it (caller drops it)
+bool send_packet(int fd, iovec* iov, int niov, size_t total) {
+  msghdr mh;
+  memset(&mh, 0, sizeof mh);
+  mh.msg_iov = iov;
+  mh.msg_iovlen = niov;
+  ssize_t n = sendmsg(fd, &mh, MSG_NOSIGNAL | MSG_DONTWAIT);
+  return n == (ssize_t)total;
+}
+
+void tx_main(vapx_ingest* g) {
+  std::vector<uint8_t> tail(64 + 8 * 256);
+  const int hop = g->hop;
+  while (true) {
+    // claim a chunk of rows of the oldest job that still has some (claims and completions are serialised by job_mu: a
+    // few thousand lock operations per second, and a recycled Job can never be touched through a stale index)
+    int j = -1, k0 = 0, k1 = 0;
+    {
+      std::unique_lock<std::mutex> lk(g->job_mu);
+      for (;;) {
+        while (!g->job_queue.empty() && g->jobs[g->job_queue.front()].claimed >= g->jobs[g->job_queue.front()].n) g->job_queue.pop_front();
+        if (!g->job_queue.empty()) break;
+        if (g->stop.load()) return;
+        g->job_cv.wait(lk);
+      }
+      j = g->job_queue.front();
+      Job& job = g->jobs[j];
+      k0 = job.claimed;
+      k1 = std::min(job.n, k0 + 8);
+      job.claimed = k1;
+    }
+    Job& job = g->jobs[j];
+    for (int k = k0; k < k1; ++k) {
+      const Ready& rd = job.rows[k];
+      const float* row = job.out + (size_t)k * VAPX_OUT_STRIDE;
+      Slot& s = g->slots[rd.slot];
+      if (row[VAPX_OUT_STATUS] == 0.f) {
+        // u32 len | f64 t | u32 n | x1 | u32 n | x2 | tail   (util.py:122-143; length prefix vap_main.py:446-448)
+        uint8_t head[16], mid[4];
+        const int tb = encode_tail(g->mode, row, tail.data());
+        const uint32_t plen = 8 + 2 * (4 + 8 * (uint32_t)hop) + (uint32_t)tb;
+        uint8_t* p = head;
+        put_u32(p, plen); put_f64(p, job.t_unix); put_u32(p, (uint32_t)hop);
+        p = mid; put_u32(p, (uint32_t)hop);
+        double* e = g->f64buf(rd.slot, rd.buf);
+        iovec iov[5] = {{head, 16}, {e, (size_t)hop * 8}, {mid, 4}, {e + hop, (size_t)hop * 8}, {tail.data(), (size_t)tb}};
+        const size_t total = 4 + plen;
+        auto send_to = [&](std::vector<int>& fds) {
+          for (size_t i = 0; i < fds.size();) {
+            if (send_packet(fds[i], iov, 5, total)) { g->tx_bytes.fetch_add((int64_t)total, std::memory_order_relaxed); ++i; }
+            else { close(fds[i]); fds.erase(fds.begin() + i); g->dropped.fetch_add(1); g->out_conns.fetch_sub(1); }
+          }
+        };
+        if (g->broadcast) { std::lock_guard<std::mutex> lk(g->slots_mu); send_to(g->out_all); }
+        else { std::lock_guard<std::mutex> lk(s.lmu); send_to(s.listeners); }
+        g->lat.add(mono_now() - rd.t);
+      }
+      release_buf(g, rd.slot, rd.buf);
+    }
+    {
+      std::lock_guard<std::mutex> lk(g->job_mu);
+      job.finished += k1 - k0;
+      if (job.finished >= job.n) { job.busy = false; g->job_done_cv.notify_all(); }
+    }
+  }
+}
+
+void tick_main(vapx_ingest* g) {
+  std::deque<Ready> pending;
+  std::vector<uint8_t> in_batch(g->S, 0);
+  double first_ready = 0.0;
+  int jsel = 0;
+  const double max_wait = (g->cfg.max_wait_us > 0 ? g->cfg.max_wait_us : 2000) * 1e-6;
+  while (!g->stop.load()) {
+    std::vector<Ready> fresh;
+    std::vector<std::pair<int, int>> resets;
+    {
+      std::unique_lock<std::mutex> lk(g->ready_mu);
+      if (g->ready.empty() && g->resets.empty()) {
+        if (pending.empty()) g->ready_cv.wait_for(lk, std::chrono::milliseconds(20));
+        else {
+          const double left = first_ready + max_wait - mono_now();
+          if (left > 0) g->ready_cv.wait_for(lk, std::chrono::microseconds((long)(left * 1e6) + 1));
+        }
+      }
+      fresh.swap(g->ready);
+      resets.swap(g->resets);
+    }
+    for (auto& rs : resets)
+      if (g->reset) g->reset(g->user, rs.second ? -(rs.first + 1) : rs.first);   // negative = carry only
+    for (auto& rd : fresh) {
+      if (rd.gen != g->slots[rd.slot].gen) { release_buf(g, rd.slot, rd.buf); continue; }   // connection already gone
+      if (pending.empty()) first_ready = rd.t;
+      pending.push_back(rd);
+    }
+    if (pending.empty()) continue;
+    const int connected = (int)g->in_conns.load();
+    int want = g->cfg.min_batch > 0 ? g->cfg.min_batch : connected;
+    want = std::max(1, std::min(want, std::min(connected > 0 ? connected : 1, g->max_batch)));
+    const double now = mono_now();
+    if ((int)pending.size() < want && now - first_ready < max_wait) continue;
+
+    Job& job = g->jobs[jsel];
+    {
+      std::unique_lock<std::mutex> lk(g->job_mu);
+      g->job_done_cv.wait(lk, [&] { return !job.busy || g->stop.load(); });
+      if (g->stop.load()) break;
+    }
+    // one frame per stream per tick, oldest first; a second frame of the same stream waits for the next tick
+    job.rows.clear();
+    std::deque<Ready> later;
+    while (!pending.empty()) {
+      Ready rd = pending.front();
+      pending.pop_front();
+      if (rd.gen != g->slots[rd.slot].gen) { release_buf(g, rd.slot, rd.buf); continue; }
+      if (in_batch[rd.slot] || (int)job.rows.size() >= g->max_batch) { later.push_back(rd); continue; }
+      in_batch[rd.slot] = 1;
+      g->slots[rd.slot].state[rd.buf].store(B_INFLIGHT);
+      job.rows.push_back(rd);
+    }
+    pending.swap(later);
+    if (!pending.empty()) first_ready = pending.front().t;
+    const int n = (int)job.rows.size();
+    if (n == 0) continue;
+    const size_t fb = (size_t)2 * g->hop * sizeof(float);
+    for (int k = 0; k < n; ++k) {
+      in_batch[job.rows[k].slot] = 0;
+      g->batch_ids[k] = job.rows[k].slot;
+      memcpy(g->batch_audio + (size_t)k * 2 * g->hop, g->f32buf(job.rows[k].slot, job.rows[k].buf), fb);
+    }
+    const double t0 = mono_now();
+    const int rc = g->step(g->user, n, g->batch_ids.data(), g->batch_audio, job.out);
+    g->step_us.fetch_add((int64_t)((mono_now() - t0) * 1e6));
+    g->ticks.fetch_add(1);
+    g->batch_sum.fetch_add(n);
+    if (rc != 0 && rc != VAPX_E_NUMERIC) {   // the step itself failed: nothing to send; free the frames and keep serving
+      char buf[96];
+      snprintf(buf, sizeof buf, "step failed with code %d", rc);
+      g->err = buf;
+      for (int k = 0; k < n; ++k) release_buf(g, job.rows[k].slot, job.rows[k].buf);
+      continue;
+    }
+    for (int k = 0; k < n; ++k)
+      if (job.out[(size_t)k * VAPX_OUT_STRIDE + VAPX_OUT_STATUS] != 0.f) {   // poisoned stream: fresh state, no packet
+        if (g->reset) g->reset(g->user, job.rows[k].slot);
+        g->numeric_resets.fetch_add(1);
+      }
+    g->frames_done.fetch_add(n);
+    job.t_unix = unix_now();
+    {
+      std::lock_guard<std::mutex> lk(g->job_mu);
+      job.n = n;
+      job.claimed = 0;
+      job.finished = 0;
+      job.busy = true;
+      g->job_queue.push_back(jsel);
+    }
+    g->job_cv.notify_all();
+    jsel ^= 1;
+  }
+}
+
+int engine_step(void* user, int32_t n, const int32_t* ids, const float* audio, float* out) {
+  vapx_ingest* g = (vapx_ingest*)user;
+  return vapx_step(g->engine, n, ids, audio, g->hop, out, VAPX_AUDIO_HOST | VAPX_OUT_HOST, nullptr);
+}
+void engine_reset(void* user, int32_t sid) {
+  vapx_ingest* g = (vapx_ingest*)user;
+  if (sid < 0) (void)vapx_reset_carry(g->engine, -sid - 1);
+  else (void)vapx_reset_stream(g->engine, sid);
+}
+
+int open_common(vapx_ingest* g, const vapx_ingest_config* cfg) {
+  g->cfg = *cfg;
+  if (g->cfg.gain == 0.0) g->cfg.gain = 1.0;
+  g->R = cfg->rx_threads > 0 ? std::min(cfg->rx_threads, 16) : 2;
+  g->X = cfg->tx_threads > 0 ? std::min(cfg->tx_threads, 16) : 2;
+  g->broadcast = cfg->broadcast < 0 ? (g->S == 1) : (cfg->broadcast != 0);
+  g->hop = 16000 / g->hz;
+  g->slots.reset(new Slot[g->S]);
+  const size_t per = (size_t)g->S * NBUF * 2 * g->hop;
+  const size_t ba = (size_t)g->max_batch * 2 * g->hop;
+  const size_t ob = (size_t)g->max_batch * VAPX_OUT_STRIDE;
+  // page-locked staging so vapx_step DMAs straight out of / into it; without a HIP device (host-logic tests over a step
+  // function) plain memory does
+  g->stage = (float*)vapx_host_alloc(per * sizeof(float));
+  g->pinned_blocks = g->stage != nullptr;
+  auto grab = [&](size_t n) { return (float*)(g->pinned_blocks ? vapx_host_alloc(n * sizeof(float)) : calloc(n, sizeof(float))); };
+  if (!g->stage) g->stage = grab(per);
+  g->echo.assign(per, 0.0);
+  g->batch_audio = grab(ba);
+  g->batch_ids.assign(g->max_batch, 0);
+  for (auto& j : g->jobs) {
+    j.out = grab(ob);
+    j.rows.reserve(g->max_batch);
+  }
+  if (!g->stage || !g->batch_audio || !g->jobs[0].out || !g->jobs[1].out) return VAPX_E_NOMEM;
+  g->lin = listen_on(cfg->port_in, cfg->bind_any != 0, &g->port_in);
+  g->lout = listen_on(cfg->port_out, cfg->bind_any != 0, &g->port_out);
+  if (g->lin < 0 || g->lout < 0) return VAPX_E_INVAL;
+  g->resume_mu = std::vector<std::mutex>(g->R);
+  g->resume.assign(g->R, {});
+  for (int r = 0; r < g->R; ++r) {
+    g->ep.push_back(epoll_create1(0));
+    g->wake.push_back(eventfd(0, EFD_NONBLOCK));
+    ep_add(g->ep[r], g->wake[r], K_WAKE);
+  }
+  ep_add(g->ep[0], g->lin, K_LISTEN_IN);
+  ep_add(g->ep[0], g->lout, K_LISTEN_OUT);
+  for (int r = 0; r < g->R; ++r) g->rx_threads.emplace_back(rx_main, g, r);
+  for (int x = 0; x < g->X; ++x) g->tx_threads.emplace_back(tx_main, g);
+  g->tick_thread = std::thread(tick_main, g);
+  return VAPX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vapx_ingest_open_fn(vapx_ingest_step_fn step, vapx_ingest_reset_fn reset, void* user, int32_t n_streams, int32_t max_batch,
+                        int32_t frame_hz, int32_t mode, const vapx_ingest_config* cfg, vapx_ingest_handle* out) {
+  if (!step || !cfg || !out || cfg->struct_size != (int32_t)sizeof(vapx_ingest_config)) return VAPX_E_INVAL;
+  if (n_streams < 1 || max_batch < 1 || max_batch > n_streams) return VAPX_E_INVAL;
+  if (frame_hz != 5 && frame_hz != 10 && frame_hz != 20 && frame_hz != 50) return VAPX_E_INVAL;
+  if (mode < 0 || mode > 2) return VAPX_E_INVAL;
+  vapx_ingest* g = new vapx_ingest();
+  g->step = step; g->reset = reset; g->user = user;
+  g->S = n_streams; g->max_batch = max_batch; g->hz = frame_hz; g->mode = mode;
+  int rc = open_common(g, cfg);
+  if (rc != VAPX_OK) { vapx_ingest_close(g); return rc; }
+  *out = g;
+  return VAPX_OK;
+}
+
+int vapx_ingest_open(vapx_handle engine, const vapx_ingest_config* cfg, vapx_ingest_handle* out) {
+  if (!engine || !cfg || !out || cfg->struct_size != (int32_t)sizeof(vapx_ingest_config)) return VAPX_E_INVAL;
+  vapx_config ec;
+  int rc = vapx_get_config(engine, &ec);
+  if (rc != VAPX_OK) return rc;
+  vapx_ingest* g = new vapx_ingest();
+  g->engine = engine;
+  g->step = engine_step; g->reset = engine_reset; g->user = g;
+  g->S = ec.max_streams; g->max_batch = ec.max_batch; g->hz = ec.frame_hz; g->mode = ec.mode;
+  rc = open_common(g, cfg);
+  if (rc != VAPX_OK) { vapx_ingest_close(g); return rc; }
+  *out = g;
+  return VAPX_OK;
+}
+
+int vapx_ingest_ports(vapx_ingest_handle g, int32_t* port_in, int32_t* port_out) {
+  if (!g) return VAPX_E_INVAL;
+  if (port_in) *port_in = g->port_in;
+  if (port_out) *port_out = g->port_out;
+  return VAPX_OK;
+}
+
+int vapx_ingest_stats_read(vapx_ingest_handle g, vapx_ingest_stats* st, int32_t reset_latency_window) {
+  if (!g || !st) return VAPX_E_INVAL;
+  memset(st, 0, sizeof *st);
+  st->frames_done = g->frames_done.load();
+  st->ticks = g->ticks.load();
+  st->rx_bytes = g->rx_bytes.load();
+  st->tx_bytes = g->tx_bytes.load();
+  st->in_connections = g->in_conns.load();
+  st->out_connections = g->out_conns.load();
+  st->dropped_listeners = g->dropped.load();
+  st->numeric_resets = g->numeric_resets.load();
+  st->overruns = g->overruns.load();
+  st->mean_batch = st->ticks ? (double)g->batch_sum.load() / (double)st->ticks : 0.0;
+  const int64_t c = g->lat.cnt.load();
+  st->lat_mean_ms = c ? (double)g->lat.sum_us.load() / (double)c * 1e-3 : 0.0;
+  st->lat_p50_ms = g->lat.pct(0.50);
+  st->lat_p99_ms = g->lat.pct(0.99);
+  st->lat_max_ms = (double)g->lat.max_us.load() * 1e-3;
+  st->step_mean_ms = st->ticks ? (double)g->step_us.load() / (double)st->ticks * 1e-3 : 0.0;
+  if (reset_latency_window) g->lat.clear();
+  return VAPX_OK;
+}
+
+void vapx_ingest_close(vapx_ingest_handle g) {
+  if (!g) return;
+  g->stop.store(true);
+  g->ready_cv.notify_all();
+  g->job_cv.notify_all();
+  g->job_done_cv.notify_all();
+  for (int fd : g->wake) kick(fd);
+  for (auto& t : g->rx_threads) if (t.joinable()) t.join();
+  if (g->tick_thread.joinable()) g->tick_thread.join();
+  g->job_cv.notify_all();
+  for (auto& t : g->tx_threads) if (t.joinable()) t.join();
+  if (g->slots) {
+    for (int i = 0; i < g->S; ++i) {
+      if (g->slots[i].fd_in >= 0) close(g->slots[i].fd_in);
+      for (int fd : g->slots[i].listeners) close(fd);
+    }
+  }
+  for (int fd : g->out_all) close(fd);
+  if (g->lin >= 0) close(g->lin);
+  if (g->lout >= 0) close(g->lout);
+  for (int fd : g->ep) close(fd);
+  for (int fd : g->wake) close(fd);
+  auto drop = [&](void* p) {
+    if (!p) return;
+    if (g->pinned_blocks) vapx_host_free(p); else free(p);
+  };
+  drop(g->stage);
+  drop(g->batch_audio);
+  drop(g->jobs[0].out);
+  drop(g->jobs[1].out);
+  delete g;
+}
+
+int64_t vapx_wire_decode_input(const uint8_t* bytes, size_t n_bytes, double gain, float* x1_f32, float* x2_f32, double* x1_f64,
+                               double* x2_f64) {
+  if (!bytes || n_bytes % PAIR_BYTES) return VAPX_E_INVAL;   // util.conv_bytearray_2_2floatarray needs whole f64 pairs
+  const size_t n = n_bytes / PAIR_BYTES;
+  for (size_t i = 0; i < n; ++i) {
+    double v[2];
+    memcpy(v, bytes + i * PAIR_BYTES, PAIR_BYTES);
+    const double a = gain != 1.0 ? v[0] * gain : v[0], b = gain != 1.0 ? v[1] * gain : v[1];
+    if (x1_f64) x1_f64[i] = a;
+    if (x2_f64) x2_f64[i] = b;
+    if (x1_f32) x1_f32[i] = (float)a;
+    if (x2_f32) x2_f32[i] = (float)b;
+  }
+  return (int64_t)n;
+}
+
+int64_t vapx_wire_encode_result(int32_t mode, double t, const double* x1, const double* x2, int32_t n, const float* row, uint8_t* dst,
+                                size_t cap) {
+  if (mode < 0 || mode > 2 || !x1 || !x2 || n < 0 || !row) return VAPX_E_INVAL;
+  const int nr = mode == VAPX_MODE_NOD ? (int)row[VAPX_OUT_NVALID] : 0;
+  if (nr < 0 || nr > 256) return VAPX_E_INVAL;
+  const size_t plen = 8 + 2 * (4 + 8 * (size_t)n) + (size_t)tail_bytes(mode, nr);
+  if (!dst || cap < 4 + plen) return (int64_t)(4 + plen);
+  uint8_t* p = dst;
+  put_u32(p, (uint32_t)plen);
+  put_f64(p, t);
+  put_u32(p, (uint32_t)n);
+  memcpy(p, x1, (size_t)n * 8); p += (size_t)n * 8;
+  put_u32(p, (uint32_t)n);
+  memcpy(p, x2, (size_t)n * 8); p += (size_t)n * 8;
+  p += encode_tail(mode, row, p);
+  return (int64_t)(p - dst);
+}
+
+}  // extern "C"

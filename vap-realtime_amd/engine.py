@@ -27,7 +27,9 @@ MODE = {"vap": 0, "bc": 1, "nod": 2}
 EXPORTS = ("vapx_abi_version", "vapx_blob_floats", "vapx_create", "vapx_destroy", "vapx_step",
            "vapx_attach_trunk", "vapx_join", "vapx_reset_stream", "vapx_get_state", "vapx_set_state", "vapx_encode_audio",
            "vapx_transformer", "vapx_peek", "vapx_gemm", "vapx_last_error", "vapx_profile_enable",
-           "vapx_profile_read", "vapx_bad_slots", "vapx_host_alloc", "vapx_host_free")
+           "vapx_profile_read", "vapx_bad_slots", "vapx_host_alloc", "vapx_host_free", "vapx_reset_carry", "vapx_get_config",
+           "vapx_ingest_open", "vapx_ingest_open_fn", "vapx_ingest_ports", "vapx_ingest_stats_read", "vapx_ingest_close",
+           "vapx_wire_decode_input", "vapx_wire_encode_result")
 PROF_CLASSES = {0: "gemm_store", 1: "gemm_gelu", 2: "gemm_resid", 3: "gemm_resid_ln", 4: "gemm_cn_relu",
                 5: "conv_tail", 6: "ffn_block", 7: "last_row", 8: "conv0", 9: "lstm", 10: "gather_ln", 11: "attention", 12: "head"}
 
@@ -100,6 +102,24 @@ def load_library(path: Optional[str] = None):
     lib.vapx_host_alloc.argtypes = [C.c_size_t]
     lib.vapx_host_free.restype = None
     lib.vapx_host_free.argtypes = [vp]
+    lib.vapx_reset_carry.restype = i32
+    lib.vapx_reset_carry.argtypes = [vp, i32]
+    lib.vapx_get_config.restype = i32
+    lib.vapx_get_config.argtypes = [vp, C.POINTER(_Config)]
+    lib.vapx_ingest_open.restype = i32
+    lib.vapx_ingest_open.argtypes = [vp, vp, C.POINTER(vp)]
+    lib.vapx_ingest_open_fn.restype = i32
+    lib.vapx_ingest_open_fn.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, C.POINTER(vp)]
+    lib.vapx_ingest_ports.restype = i32
+    lib.vapx_ingest_ports.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    lib.vapx_ingest_stats_read.restype = i32
+    lib.vapx_ingest_stats_read.argtypes = [vp, vp, i32]
+    lib.vapx_ingest_close.restype = None
+    lib.vapx_ingest_close.argtypes = [vp]
+    lib.vapx_wire_decode_input.restype = C.c_int64
+    lib.vapx_wire_decode_input.argtypes = [vp, C.c_size_t, C.c_double, vp, vp, vp, vp]
+    lib.vapx_wire_encode_result.restype = C.c_int64
+    lib.vapx_wire_encode_result.argtypes = [i32, C.c_double, vp, vp, i32, vp, vp, C.c_size_t]
     if path is None:
         _lib = lib
     return lib
@@ -240,6 +260,10 @@ class Engine:
 
     def reset_stream(self, sid: int):
         self._check(self.lib.vapx_reset_stream(self._h, sid), "vapx_reset_stream")
+
+    def reset_carry(self, sid: int):
+        """Zero only the 320-sample carry (what a reconnect does in the reference, vap_main.py:368-369)."""
+        self._check(self.lib.vapx_reset_carry(self._h, sid), "vapx_reset_carry")
 
     def get_state(self, sid: int):
         ring = np.zeros((2, self.T, 256), np.float32)
