@@ -209,3 +209,56 @@ def test_vaprealtime_from_reference_format_checkpoint_files(name, tmp_path):
             np.testing.assert_allclose(np.asarray(r["p_bc"]).reshape(-1), c.z["p_bc"][f][0, :n], rtol=0, atol=TOL)
             np.testing.assert_allclose(r["p_nod_short"], c.z["p_nod_short"][f][0], rtol=0, atol=TOL)
             np.testing.assert_allclose(r["p_nod_long_p"], c.z["p_nod_long_p"][f][0], rtol=0, atol=TOL)
+
+
+@pytest.mark.parametrize("name", ["multi3", "bc20", "nod20"])
+def test_native_tcp_front_end_end_to_end_on_gpu(name):
+    """libvapx's own front-end (vapx_ingest_*): reference-format input packets in, reference-format result packets out,
+    numbers == the golden of the imported reference program (vap_main / vap_bc_main / vap_nod_main), echo bit-exact."""
+    from vap_realtime_amd import engine, ingest, weights as W, wire
+    c = Case(name)
+    S = len(c.streams)
+    eng = engine.Engine(W.pack_blob(c.cpc_sd, c.vap_sd, c.mode), c.frame_hz, c.ctx_sec, max_streams=S + 2, mode=c.mode)
+    srv = ingest.NativeServer(eng, port_in=0, port_out=0, max_wait_s=0.5)
+    try:
+        ins = [socket.create_connection(("127.0.0.1", srv.port_in)) for _ in range(S)]
+        while srv.stats()["in_connections"] < S:
+            time.sleep(0.01)
+        outs = [socket.create_connection(("127.0.0.1", srv.port_out)) for _ in range(S)]
+        while srv.stats()["out_connections"] < S:
+            time.sleep(0.01)
+        for f in range(c.n_frames):
+            new = c.new_samples(f).astype(np.float64)
+            for p in range(c.hop // 160):
+                for s in range(S):
+                    ins[s].sendall(wire.encode_input(new[s, 0, p * 160:(p + 1) * 160], new[s, 1, p * 160:(p + 1) * 160]))
+            for s in range(S):
+                outs[s].settimeout(20)
+                hdr = b""
+                while len(hdr) < 4:
+                    hdr += outs[s].recv(4 - len(hdr))
+                ln = struct.unpack("<I", hdr)[0]
+                payload = b""
+                while len(payload) < ln:
+                    payload += outs[s].recv(ln - len(payload))
+                r = wire.decode_result(payload, c.mode)
+                np.testing.assert_array_equal(r["x1"], new[s, 0])
+                np.testing.assert_array_equal(r["x2"], new[s, 1])
+                if c.mode == "vap":
+                    assert ln == 12876
+                    for k in ("p_now", "p_future", "vad"):
+                        np.testing.assert_allclose(r[k], c.z[k][f][s], rtol=0, atol=TOL)
+                elif c.mode == "bc":
+                    np.testing.assert_allclose(r["p_bc_react"], c.z["p_bc_react"][f][s], rtol=0, atol=TOL)
+                    np.testing.assert_allclose(r["p_bc_emo"], c.z["p_bc_emo"][f][s], rtol=0, atol=TOL)
+                else:
+                    n = min(f + 1, c.T)
+                    assert len(r["p_bc"]) == n                                  # every window row (vap_nod_main.py:276 quirk)
+                    np.testing.assert_allclose(r["p_bc"], c.z["p_bc"][f][s][:n], rtol=0, atol=TOL)
+                    for k in ("p_nod_short", "p_nod_long", "p_nod_long_p"):
+                        np.testing.assert_allclose(r[k], c.z[k][f][s], rtol=0, atol=TOL)
+        st = srv.stats()
+        assert st["frames_done"] == c.n_frames * S and st["numeric_resets"] == 0 and st["dropped_listeners"] == 0
+    finally:
+        srv.close()
+        eng.close()

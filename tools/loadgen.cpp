@@ -1,0 +1,213 @@
+// loadgen — real-time load generator for the VAP TCP front-end (reference framing: 2560-byte input packets of 160 x
+// {f64 ch1, f64 ch2}; length-prefixed result packets).  Plays S dialogue clients against one server process:
+//   * connects S input sockets, then S output sockets (the server pairs the k-th output connection with the k-th stream);
+//   * every stream sends its audio in real time — one packet per `--packet-ms` (10 ms like the reference client, or a whole
+//     frame at once) — with the streams' frame boundaries spread evenly over the frame period;
+//   * receiver threads parse the result packets; latency of a frame = just before its last packet is sent -> complete
+//     result packet read.
+// Prints one JSON line: frames sent / answered, latency percentiles, late frames (> --late-ms).
+// Build: make -C vap-realtime_amd/csrc loadgen   (plain C++17, no dependencies)
+#include <arpa/inet.h>
+#include <errno.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/epoll.h>
+#include <sys/socket.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <queue>
+#include <string>
+#include <thread>
+#include <vector>
+
+static double now_s() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+static int dial(const char* host, int port) {
+  int s = socket(AF_INET, SOCK_STREAM, 0);
+  sockaddr_in a;
+  memset(&a, 0, sizeof a);
+  a.sin_family = AF_INET;
+  a.sin_port = htons((uint16_t)port);
+  inet_pton(AF_INET, host, &a.sin_addr);
+  for (int tries = 0; tries < 50; ++tries) {
+    if (connect(s, (sockaddr*)&a, sizeof a) == 0) {
+      int one = 1;
+      setsockopt(s, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+      return s;
+    }
+    usleep(20000);
+  }
+  perror("connect");
+  exit(2);
+}
+
+struct Stream {
+  int fd_in = -1, fd_out = -1;
+  std::mutex mu;
+  std::deque<double> sent;          // send-completion time of each frame not yet answered
+  std::vector<uint8_t> rbuf;
+  long answered = 0;
+};
+
+int main(int argc, char** argv) {
+  const char* host = "127.0.0.1";
+  int port_in = 50007, port_out = 50008, S = 256, hz = 20, packet_ms = 10, threads = 4;
+  double seconds = 10.0, late_ms = 10.0, warm = 3.0;
+  for (int i = 1; i + 1 < argc; i += 2) {
+    std::string k = argv[i];
+    const char* v = argv[i + 1];
+    if (k == "--host") host = v;
+    else if (k == "--port-in") port_in = atoi(v);
+    else if (k == "--port-out") port_out = atoi(v);
+    else if (k == "--streams") S = atoi(v);
+    else if (k == "--hz") hz = atoi(v);
+    else if (k == "--seconds") seconds = atof(v);
+    else if (k == "--warm") warm = atof(v);
+    else if (k == "--packet-ms") packet_ms = atoi(v);
+    else if (k == "--threads") threads = atoi(v);
+    else if (k == "--late-ms") late_ms = atof(v);
+    else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
+  }
+  const int hop = 16000 / hz;
+  const double period = 1.0 / hz;
+  const int packets_per_frame = (int)lround(period * 1000.0 / packet_ms);
+  const int pk_samples = hop / packets_per_frame;
+  // 8 frames of synthetic two-speaker audio per phase class (harmonic stack + noise), f64 interleaved like the wire
+  const int NF = 8;
+  std::vector<double> audio((size_t)NF * hop * 2);
+  for (int i = 0; i < NF * hop; ++i) {
+    const double t = i / 16000.0;
+    audio[2 * i] = 0.2 * sin(2 * M_PI * 140.0 * t) * (0.6 + 0.4 * sin(2 * M_PI * 4.0 * t)) + 1e-3 * ((rand() % 2001) / 1000.0 - 1.0);
+    audio[2 * i + 1] = 0.15 * sin(2 * M_PI * 210.0 * t + 1.0) * (i / hop % 2 ? 1.0 : 0.05) + 1e-3 * ((rand() % 2001) / 1000.0 - 1.0);
+  }
+  std::vector<Stream> st(S);
+  for (int i = 0; i < S; ++i) st[i].fd_in = dial(host, port_in);
+  usleep(300000);
+  for (int i = 0; i < S; ++i) st[i].fd_out = dial(host, port_out);
+  usleep(300000);
+
+  std::atomic<bool> stop{false};
+  std::atomic<long> frames_sent{0}, frames_answered{0}, late{0};
+  std::mutex lat_mu;
+  std::vector<float> lats;
+  lats.reserve((size_t)(S * hz * seconds * 1.1));
+  const double t_start = now_s() + 0.2;
+  const double t_measure = t_start + warm;          // latencies before this are not recorded (window fill / ramp-up)
+  const double t_end = t_measure + seconds;
+
+  auto sender = [&](int tid) {
+    // streams tid, tid + threads, ...; stream i's frame k ends at t_start + (k + 1) * period + phase_i
+    std::vector<int> mine;
+    for (int i = tid; i < S; i += threads) mine.push_back(i);
+    struct Ev { double t; int s; int pk; long frame; };
+    auto later = [](const Ev& a, const Ev& b) { return a.t > b.t; };
+    std::priority_queue<Ev, std::vector<Ev>, decltype(later)> q(later);
+    for (int i : mine) q.push({t_start + period * i / S + period / packets_per_frame, i, 0, 0});
+    while (!stop.load() && !q.empty()) {
+      Ev e = q.top();
+      q.pop();
+      if (e.t >= t_end) continue;
+      double n = now_s();
+      while (n < e.t) {
+        if (e.t - n > 2e-4) usleep((useconds_t)((e.t - n) * 5e5));
+        n = now_s();
+      }
+      const uint8_t* p = (const uint8_t*)(audio.data() + ((size_t)(e.frame % NF) * hop + (size_t)e.pk * pk_samples) * 2);
+      size_t left = (size_t)pk_samples * 16;
+      if (e.pk + 1 == packets_per_frame) {   // time stamp BEFORE the frame's last packet leaves: the answer may overtake us
+        std::lock_guard<std::mutex> lk(st[e.s].mu);
+        st[e.s].sent.push_back(now_s());
+      }
+      while (left) {
+        ssize_t w = send(st[e.s].fd_in, p, left, MSG_NOSIGNAL);
+        if (w <= 0) { if (errno == EINTR) continue; stop.store(true); break; }
+        p += w; left -= (size_t)w;
+      }
+      if (++e.pk == packets_per_frame) {
+        e.pk = 0;
+        ++e.frame;
+        frames_sent.fetch_add(1);
+      }
+      e.t += period / packets_per_frame;
+      q.push(e);
+    }
+  };
+
+  auto receiver = [&](int tid) {
+    int ep = epoll_create1(0);
+    for (int i = tid; i < S; i += threads) {
+      epoll_event ev;
+      memset(&ev, 0, sizeof ev);
+      ev.events = EPOLLIN;
+      ev.data.u32 = (uint32_t)i;
+      epoll_ctl(ep, EPOLL_CTL_ADD, st[i].fd_out, &ev);
+    }
+    std::vector<uint8_t> buf(1 << 18);
+    epoll_event evs[128];
+    while (!stop.load()) {
+      int n = epoll_wait(ep, evs, 128, 50);
+      for (int k = 0; k < n; ++k) {
+        Stream& s = st[evs[k].data.u32];
+        ssize_t r = recv(s.fd_out, buf.data(), buf.size(), MSG_DONTWAIT);
+        if (r <= 0) continue;
+        const double t = now_s();
+        s.rbuf.insert(s.rbuf.end(), buf.begin(), buf.begin() + r);
+        size_t off = 0;
+        while (s.rbuf.size() - off >= 4) {
+          uint32_t len;
+          memcpy(&len, s.rbuf.data() + off, 4);
+          if (s.rbuf.size() - off < 4 + (size_t)len) break;
+          off += 4 + len;
+          double t_sent = 0;
+          {
+            std::lock_guard<std::mutex> lk(s.mu);
+            if (!s.sent.empty()) { t_sent = s.sent.front(); s.sent.pop_front(); }
+          }
+          ++s.answered;
+          frames_answered.fetch_add(1);
+          if (t_sent >= t_measure) {
+            const double ms = (t - t_sent) * 1e3;
+            if (ms > late_ms) late.fetch_add(1);
+            std::lock_guard<std::mutex> lk(lat_mu);
+            lats.push_back((float)ms);
+          }
+        }
+        if (off) s.rbuf.erase(s.rbuf.begin(), s.rbuf.begin() + off);
+      }
+    }
+    close(ep);
+  };
+
+  std::vector<std::thread> th;
+  for (int t = 0; t < threads; ++t) th.emplace_back(receiver, t);
+  std::vector<std::thread> snd;
+  for (int t = 0; t < threads; ++t) snd.emplace_back(sender, t);
+  for (auto& t : snd) t.join();
+  usleep(300000);                                    // let the last results arrive
+  stop.store(true);
+  for (auto& t : th) t.join();
+  std::sort(lats.begin(), lats.end());
+  auto pct = [&](double q) { return lats.empty() ? 0.0 : (double)lats[std::min(lats.size() - 1, (size_t)(q * lats.size()))]; };
+  long unanswered = 0;
+  for (auto& s : st) unanswered += (long)s.sent.size();
+  printf("{\"streams\": %d, \"frame_hz\": %d, \"packet_ms\": %d, \"seconds_measured\": %.1f, \"frames_sent\": %ld, \"frames_answered\": %ld, "
+         "\"unanswered_at_end\": %ld, \"latency_samples\": %zu, \"lat_p50_ms\": %.3f, \"lat_p99_ms\": %.3f, \"lat_p999_ms\": %.3f, \"lat_max_ms\": %.3f, "
+         "\"late_over_%.0fms\": %ld, \"stream_frames_per_s\": %.1f}\n",
+         S, hz, packet_ms, seconds, frames_sent.load(), frames_answered.load(), unanswered, lats.size(), pct(0.50), pct(0.99), pct(0.999),
+         lats.empty() ? 0.0 : (double)lats.back(), late_ms, late.load(), lats.size() / seconds);
+  for (auto& s : st) { close(s.fd_in); close(s.fd_out); }
+  return 0;
+}

@@ -1,64 +1,81 @@
 #!/usr/bin/env python3
-"""End-to-end capacity of the Python TCP front-end (server.ManyStreamServer + libvapx) with the reference's wire format:
-K client processes drive S dialogue streams closed-loop (send one frame = hop/160 packets of 2560 B, wait for the 12.9 KB
-result packet, repeat) as fast as the server answers.  Prints stream-frames/s and the real-time stream count that equals.
-Every client runs the same fixed number of rounds: the server pairs the k-th output connection with the k-th stream, so a
-client may be listening to another client's streams and all of them have to send the same number of frames.
-Usage: tools/server_load.py [streams] [client procs] [rounds]"""
-import multiprocessing as mp
-import socket
+"""End-to-end capacity of the TCP front-ends with the reference's wire format, driven by the native real-time load
+generator (tools/loadgen: S dialogue clients sending 10 ms packets in real time, frame boundaries spread over the frame
+period; latency = last byte of a frame sent -> complete result packet received).
+
+  tools/server_load.py --streams 4096 --seconds 20                 native front-end (libvapx vapx_ingest_*) + engine on the GPU
+  tools/server_load.py --streams 1024 --python                     the Python twin (server.ManyStreamServer)
+  tools/server_load.py --streams 256 --fake                        native front-end over a trivial step function (no GPU)
+
+Prints one JSON line: the load generator's view (frames answered, latency percentiles) + the server's own counters.
+"""
+import argparse
+import json
+import os
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
 
-sys.path.insert(0, __file__.rsplit("/", 2)[0])
-
-
-def client(args):
-    port_in, port_out, n, hop, rounds, seed = args
-    from vap_realtime_amd import synth, wire
-    audio = synth.dialogue_batch([seed], hop * 8)[0].astype(np.float64)          # [2, hop*8]
-    frames = [wire.encode_input(audio[0, f * hop:(f + 1) * hop], audio[1, f * hop:(f + 1) * hop]) for f in range(8)]
-    ins, outs = [], []
-    for _ in range(n):
-        s = socket.create_connection(("127.0.0.1", port_in)); s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1); ins.append(s)
-    time.sleep(0.5)
-    for _ in range(n):
-        s = socket.create_connection(("127.0.0.1", port_out)); outs.append(s)
-    time.sleep(1.0)
-    done, t0 = 0, time.time()
-    for f in range(rounds):
-        for s in ins:
-            s.sendall(frames[f % 8])
-        for s in outs:
-            hdr = b""
-            while len(hdr) < 4:
-                hdr += s.recv(4 - len(hdr))
-            need = int.from_bytes(hdr, "little")
-            while need > 0:
-                need -= len(s.recv(min(need, 1 << 16)))
-        done += n
-    return done, time.time() - t0
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def main():
-    S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    K = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-    rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 300
-    from vap_realtime_amd import realtime, weights as W
-    from vap_realtime_amd.server import ManyStreamServer
-    cpc, vap_sd = W.synthetic_weights(0, 20)
-    vap = realtime.ManyStreamVAP(cpc, vap_sd, 20, 2.5, n_streams=S)
-    srv = ManyStreamServer(vap, port_in=0, port_out=0, max_wait_s=0.002).start()
-    per = S // K
-    with mp.get_context("spawn").Pool(K) as pool:
-        res = pool.map(client, [(srv.port_in, srv.port_out, per, 800, rounds, 100 + i) for i in range(K)])
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--streams", type=int, default=256)
+    ap.add_argument("--hz", type=int, default=20)
+    ap.add_argument("--ctx-sec", type=float, default=2.5)
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--warm", type=float, default=4.0)
+    ap.add_argument("--packet-ms", type=int, default=10)
+    ap.add_argument("--max-wait-ms", type=float, default=2.0)
+    ap.add_argument("--min-batch", type=int, default=0)
+    ap.add_argument("--max-batch", type=int, default=0)
+    ap.add_argument("--rx-threads", type=int, default=4)
+    ap.add_argument("--tx-threads", type=int, default=4)
+    ap.add_argument("--client-threads", type=int, default=8)
+    ap.add_argument("--python", action="store_true", help="serve with the Python front-end instead of the native one")
+    ap.add_argument("--fake", action="store_true", help="native front-end over a trivial step function (plumbing only, no GPU)")
+    args = ap.parse_args()
+    loadgen = os.path.join(ROOT, "tools", "loadgen")
+    if not os.path.exists(loadgen):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "vap-realtime_amd", "csrc"), "../../tools/loadgen"])
+    S = args.streams
+    from vap_realtime_amd import engine, ingest
+    srv = None
+    if args.fake:
+        def step(ids, audio, out):
+            out[:, 0:2] = np.abs(audio).mean(axis=2)
+            return 0
+        srv = ingest.NativeServer.over_function(step, S, args.hz, max_batch=args.max_batch or S, max_wait_s=args.max_wait_ms * 1e-3,
+                                                min_batch=args.min_batch, rx_threads=args.rx_threads, tx_threads=args.tx_threads)
+        kind = "native front-end over a trivial step function"
+    else:
+        from vap_realtime_amd import realtime, weights as W
+        cpc, vap_sd = W.synthetic_weights(0, args.hz)
+        if args.python:
+            from vap_realtime_amd.server import ManyStreamServer
+            vap = realtime.ManyStreamVAP(cpc, vap_sd, args.hz, args.ctx_sec, n_streams=S, max_batch=args.max_batch or None)
+            srv = ManyStreamServer(vap, port_in=0, port_out=0, max_wait_s=args.max_wait_ms * 1e-3).start()
+            kind = "Python front-end (server.ManyStreamServer)"
+        else:
+            eng = engine.Engine(W.pack_blob(cpc, vap_sd), args.hz, args.ctx_sec, max_streams=S, max_batch=args.max_batch or None)
+            srv = ingest.NativeServer(eng, port_in=0, port_out=0, max_wait_s=args.max_wait_ms * 1e-3, min_batch=args.min_batch,
+                                      rx_threads=args.rx_threads, tx_threads=args.tx_threads)
+            kind = "native front-end (vapx_ingest_*) + engine"
+    cmd = [loadgen, "--port-in", str(srv.port_in), "--port-out", str(srv.port_out), "--streams", str(S), "--hz", str(args.hz),
+           "--seconds", str(args.seconds), "--warm", str(args.warm), "--packet-ms", str(args.packet_ms), "--threads", str(args.client_threads)]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=args.seconds + args.warm + 120).stdout.decode()
+    res = json.loads(out.strip().splitlines()[-1])
+    res["server"] = kind
+    if hasattr(srv, "stats"):
+        res["server_stats"] = srv.stats()
+    res["realtime_streams_served"] = res["stream_frames_per_s"] / args.hz
     srv.stop()
-    frames = sum(r[0] for r in res)
-    dt = max(r[1] for r in res)
-    print(f"{per * K} streams over {K} client processes: {frames / dt:.0f} stream-frames/s end to end "
-          f"(= {frames / dt / 20:.0f} real-time 20 Hz streams through one Python server process)")
+    print(json.dumps(res))
 
 
 if __name__ == "__main__":
