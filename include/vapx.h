@@ -199,6 +199,16 @@ int vapx_encode_audio(vapx_handle h, int32_t n, const int32_t* stream_ids, const
 int vapx_transformer(vapx_handle h, int32_t n, int32_t rows, const float* x, float* o, float* x12, float* comb,
                      int32_t stage, void* hip_stream);
 
+/* The head callables process_vap applies to tensors of any row count (vap_main.py:290-307); device pointers, rows x 256 fp32:
+ *   vapx_vap_head       logits = vap_head(x)            Linear(256, 256) + bias   (vap_main.py:131,290)   [rows][256]
+ *   vapx_va_classifier  y = va_classifier(x)            Linear(256, 1) + bias, BEFORE the sigmoid (:142,292-293)   [rows]
+ *   vapx_softmax256     probs = logits.softmax(-1)      (:295)
+ *   vapx_aggregate      objective.probs_next_speaker_aggregate(probs, from_bin, to_bin) (objective.py:186-206)   [rows][2] */
+int vapx_vap_head(vapx_handle h, int64_t rows, const float* x, float* logits, void* hip_stream);
+int vapx_va_classifier(vapx_handle h, int64_t rows, const float* x, float* y, void* hip_stream);
+int vapx_softmax256(int64_t rows, const float* x, float* y, void* hip_stream);
+int vapx_aggregate(int64_t rows, const float* probs, int32_t from_bin, int32_t to_bin, float* out, void* hip_stream);
+
 /* Copy an internal scratch buffer of the LAST vapx_step to the host (per-layer parity tests).
  * name: "h0".."h3","z","lstm_out","e","x0","o","stereo0".."stereo2"; returns the number of
  * floats written (<= max_floats) or a negative error.  "h2"/"h3" need VAPX_FLAG_UNFUSED_CONV and

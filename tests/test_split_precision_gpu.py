@@ -130,3 +130,35 @@ def test_split_f16_five_hz_and_odd_batch_against_the_oracle():
         for k in ("p_now", "p_future", "vad", "logits"):
             np.testing.assert_allclose(got[k], want[k], rtol=0, atol=TOL, err_msg=f"{k} frame {f}")
     eng.close()
+
+
+def test_split_f16_operand_overflow_is_reported_per_stream_and_recoverable():
+    """The f16 operands of the split path bound activations to |x| < 65504: a context row of magnitude 1e6 (an input the
+    fp32-MFMA path digests) overflows the hi part of the raw-row cross K / V operand.  The engine must say so — VAPX_E_NUMERIC
+    for THAT stream only, the other stream of the batch unaffected — and vapx_reset_stream must bring the stream back."""
+    from vap_realtime_amd import engine, weights as W
+    c = Case("multi3")
+    blob = W.pack_blob(c.cpc_sd, c.vap_sd)
+    f32 = engine.Engine(blob, c.frame_hz, c.ctx_sec, max_streams=2)
+    f16 = engine.Engine(blob, c.frame_hz, c.ctx_sec, max_streams=2, split_f16=True)
+    frames = [np.ascontiguousarray(c.new_samples(f)[:2]) for f in range(8)]
+    for f in range(5):
+        f32.step(frames[f]); f16.step(frames[f])
+    for eng in (f32, f16):
+        st = eng.get_state(1)
+        st["ring"][:, :st["n_frames"]] *= 1e6 / max(1e-9, float(np.abs(st["ring"]).max()))      # rows of magnitude 1e6
+        eng.set_state(1, st)
+    ok = f32.step(frames[5])
+    assert np.isfinite(ok[:, :10]).all() and not ok[:, engine.OUT_STATUS].any()                 # fp32 MFMA: no such limit
+    with pytest.raises(engine.VapxError, match="non-finite outputs for batch slot 1"):
+        f16.step(frames[5])
+    assert f16.bad_slots() == [1]
+    out = f16.step(frames[6], on_numeric="status")
+    assert out[:, engine.OUT_STATUS].tolist() == [0.0, 1.0]
+    want = f32.step(frames[6])
+    np.testing.assert_allclose(out[0, :272], want[0, :272], rtol=0, atol=3e-5)                   # the healthy stream is untouched
+    f16.reset_stream(1)
+    out = f16.step(frames[7])
+    assert np.isfinite(out[:, :10]).all() and not out[:, engine.OUT_STATUS].any()
+    assert out[1, engine.OUT_NVALID] == 1
+    f32.close(); f16.close()

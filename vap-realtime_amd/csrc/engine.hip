@@ -446,6 +446,47 @@ __global__ void add_kernel(float* o, const float* a, const float* b, long n) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) o[i] = a[i] + b[i];
 }
+// ---- level-1 head surface (vap_main.py:290-307 calls these on tensors of ANY row count): one wave per row ----
+// y[r] = x[r] . w + b                                   (va_classifier: Linear(256, 1), vap_main.py:142,292-293)
+__global__ void rowdot_kernel(const float* x, const float* w, const float* bias, float* y, long rows) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  f32x4 xv = *(const f32x4*)(x + r * 256 + lane * 4), wv = *(const f32x4*)(w + lane * 4);
+  const float d = wave_sum(xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3]);
+  if (lane == 0) y[r] = d + bias[0];
+}
+// softmax over the 256 classes of a row (probs = logits.softmax(-1), vap_main.py:295)
+__global__ void softmax256_kernel(const float* x, float* y, long rows) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  f32x4 v = *(const f32x4*)(x + r * 256 + lane * 4);
+  const float mx = wave_max(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+  f32x4 e = {expf(v[0] - mx), expf(v[1] - mx), expf(v[2] - mx), expf(v[3] - mx)};
+  const float inv = 1.0f / wave_sum(e[0] + e[1] + e[2] + e[3]);
+  *(f32x4*)(y + r * 256 + lane * 4) = e * inv;
+}
+// ObjectiveVAP.probs_next_speaker_aggregate (objective.py:186-206): class i <-> 8 bits, speaker c owns bits 4c..4c+3;
+// p[c] = sum_i probs[i] * #set bits of i among bins [from, to] of speaker c;  p /= p0 + p1 + 1e-5
+__global__ void aggregate_kernel(const float* probs, float* out, long rows, int from_bin, int to_bin) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  f32x4 p = *(const f32x4*)(probs + r * 256 + lane * 4);
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = lane * 4 + u;
+    int c0 = 0, c1 = 0;
+    for (int b = from_bin; b <= to_bin; ++b) { c0 += (i >> b) & 1; c1 += (i >> (4 + b)) & 1; }
+    a0 += p[u] * (float)c0;
+    a1 += p[u] * (float)c1;
+  }
+  a0 = wave_sum(a0); a1 = wave_sum(a1);
+  if (lane == 0) { const float d = a0 + a1 + 1e-5f; out[r * 2] = a0 / d; out[r * 2 + 1] = a1 / d; }
+}
+
 // compact [B*2][T][256] scratch rows (t < rows) into [B*2][rows][256]
 __global__ void compact_rows_kernel(float* dst, const float* src, int T, int rows, long nrows_out) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // float4 index
@@ -1126,6 +1167,36 @@ int vapx_profile_read(vapx_handle h, double* total_ms, int64_t* launches, int32_
   }
   h->prof_recs.clear();
   return VAPX_OK;
+}
+
+int vapx_vap_head(vapx_handle h, int64_t rows, const float* x, float* logits, void* hip_stream) {
+  if (!h || !x || !logits || rows < 1) return VAPX_E_INVAL;
+  if (h->cfg.mode != VAPX_MODE_VAP) return fail(h, VAPX_E_INVAL, "this weight set has no vap_head (bc / nod variant)");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  GemmArgs g = gemm_args(x, contiguous_rows(256), h->W("head.w"), (int)rows, 256, 256, logits, contiguous_rows(256));
+  g.bias = h->W("head.b");
+  HIPCHK(h, launch_gemm_f32(g, EPI_STORE, 0, (hipStream_t)hip_stream));
+  return VAPX_OK;
+}
+
+int vapx_va_classifier(vapx_handle h, int64_t rows, const float* x, float* y, void* hip_stream) {
+  if (!h || !x || !y || rows < 1) return VAPX_E_INVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)hip_stream, x, h->W("vad.w"), h->W("vad.b"), y, (long)rows);
+  HIPCHK(h, hipGetLastError());
+  return VAPX_OK;
+}
+
+int vapx_softmax256(int64_t rows, const float* x, float* y, void* hip_stream) {
+  if (!x || !y || rows < 1) return VAPX_E_INVAL;
+  hipLaunchKernelGGL(softmax256_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)hip_stream, x, y, (long)rows);
+  return hipGetLastError() == hipSuccess ? VAPX_OK : VAPX_E_HIP;
+}
+
+int vapx_aggregate(int64_t rows, const float* probs, int32_t from_bin, int32_t to_bin, float* out, void* hip_stream) {
+  if (!probs || !out || rows < 1 || from_bin < 0 || to_bin > 3 || from_bin > to_bin) return VAPX_E_INVAL;
+  hipLaunchKernelGGL(aggregate_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)hip_stream, probs, out, (long)rows, from_bin, to_bin);
+  return hipGetLastError() == hipSuccess ? VAPX_OK : VAPX_E_HIP;
 }
 
 int vapx_gemm(void* hip_stream, int32_t M, int32_t N, int32_t K, const float* A, const float* W, float* C, int32_t epi,

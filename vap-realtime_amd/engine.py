@@ -29,7 +29,8 @@ EXPORTS = ("vapx_abi_version", "vapx_blob_floats", "vapx_create", "vapx_destroy"
            "vapx_transformer", "vapx_peek", "vapx_gemm", "vapx_last_error", "vapx_profile_enable",
            "vapx_profile_read", "vapx_bad_slots", "vapx_host_alloc", "vapx_host_free", "vapx_reset_carry", "vapx_get_config",
            "vapx_ingest_open", "vapx_ingest_open_fn", "vapx_ingest_ports", "vapx_ingest_stats_read", "vapx_ingest_close",
-           "vapx_wire_decode_input", "vapx_wire_encode_result")
+           "vapx_wire_decode_input", "vapx_wire_encode_result", "vapx_vap_head", "vapx_va_classifier", "vapx_softmax256",
+           "vapx_aggregate")
 PROF_CLASSES = {0: "gemm_store", 1: "gemm_gelu", 2: "gemm_resid", 3: "gemm_resid_ln", 4: "gemm_cn_relu",
                 5: "conv_tail", 6: "ffn_block", 7: "last_row", 8: "conv0", 9: "lstm", 10: "gather_ln", 11: "attention", 12: "head"}
 
@@ -116,6 +117,14 @@ def load_library(path: Optional[str] = None):
     lib.vapx_ingest_stats_read.argtypes = [vp, vp, i32]
     lib.vapx_ingest_close.restype = None
     lib.vapx_ingest_close.argtypes = [vp]
+    lib.vapx_vap_head.restype = i32
+    lib.vapx_vap_head.argtypes = [vp, C.c_int64, f32p, f32p, vp]
+    lib.vapx_va_classifier.restype = i32
+    lib.vapx_va_classifier.argtypes = [vp, C.c_int64, f32p, f32p, vp]
+    lib.vapx_softmax256.restype = i32
+    lib.vapx_softmax256.argtypes = [C.c_int64, f32p, f32p, vp]
+    lib.vapx_aggregate.restype = i32
+    lib.vapx_aggregate.argtypes = [C.c_int64, f32p, i32, i32, f32p, vp]
     lib.vapx_wire_decode_input.restype = C.c_int64
     lib.vapx_wire_decode_input.argtypes = [vp, C.c_size_t, C.c_double, vp, vp, vp, vp]
     lib.vapx_wire_encode_result.restype = C.c_int64

@@ -149,14 +149,50 @@ class ManyStreamVAP:
 # level-1 surface: what VAPRealTime.process_vap calls on self.vap (vap_main.py:272-307)
 # ------------------------------------------------------------------------------------------------
 class _Objective:
+    """``vap.objective``: only ``probs_next_speaker_aggregate`` is on the path (vap_main.py:297-307); a HIP kernel."""
+
+    def __init__(self, lib):
+        self.lib = lib
+
     def probs_next_speaker_aggregate(self, probs, from_bin: int = 0, to_bin: int = 3, scale_with_bins: bool = False):
-        """objective.py:186-206 on a torch tensor [B,n,256] (device-side, tiny)."""
+        """objective.py:186-206 on a torch CUDA tensor [..., 256] -> [..., 2]."""
         import torch
-        idx = torch.arange(256, device=probs.device)
-        bits = ((idx[:, None] >> torch.arange(8, device=probs.device)[None, :]) & 1).to(probs.dtype).view(256, 2, 4)
-        abp = bits[:, :, from_bin:to_bin + 1].sum(-1)
-        p_all = torch.einsum("bid,dc->bic", probs, abp)
-        return p_all / (p_all.sum(-1, keepdim=True) + 1e-5)
+        if scale_with_bins:
+            raise NotImplementedError("scale_with_bins is never used by the realtime programs")
+        p = probs.float().contiguous()
+        rows = p.numel() // 256
+        out = torch.empty(*p.shape[:-1], 2, device=p.device)
+        rc = self.lib.vapx_aggregate(rows, p.data_ptr(), from_bin, to_bin, out.data_ptr(), torch.cuda.current_stream().cuda_stream or None)
+        if rc != 0:
+            raise _engine.VapxError(f"vapx_aggregate failed ({rc})")
+        return out
+
+
+_LOGITS_CLS = None
+
+
+def _logits_cls():
+    """torch.Tensor subclass returned by ``VapGPT.vap_head``: ``logits.softmax(dim=-1)`` (vap_main.py:295) runs the HIP row
+    softmax; every other operation is the plain tensor's."""
+    global _LOGITS_CLS
+    if _LOGITS_CLS is None:
+        import torch
+
+        class VapLogits(torch.Tensor):
+            def softmax(self, dim=-1, dtype=None):
+                t = self.as_subclass(torch.Tensor)
+                if dtype is not None or dim not in (-1, t.dim() - 1) or not t.is_cuda or t.shape[-1] != 256 or t.dtype != torch.float32:
+                    return t.softmax(dim, dtype=dtype)
+                t = t.contiguous()
+                y = torch.empty_like(t)
+                rc = _engine.load_library().vapx_softmax256(t.numel() // 256, t.data_ptr(), y.data_ptr(),
+                                                            torch.cuda.current_stream().cuda_stream or None)
+                if rc != 0:
+                    raise _engine.VapxError(f"vapx_softmax256 failed ({rc})")
+                return y
+
+        _LOGITS_CLS = VapLogits
+    return _LOGITS_CLS
 
 
 class VapGPT:
@@ -169,10 +205,7 @@ class VapGPT:
         self.engine = _engine.Engine(_weights.pack_blob(cpc_sd, vap_sd, mode), frame_rate, context_len_sec,
                                      max_streams=max_batch, mode=mode, device_id=device_id)
         self.device = torch.device("cuda", device_id)
-        self.objective = _Objective()
-        f = lambda k: torch.as_tensor(np.asarray(vap_sd[k], dtype=np.float32)).to(self.device)
-        self._head_w, self._head_b = f("vap_head.weight"), f("vap_head.bias")
-        self._va_w, self._va_b = f("va_classifier.weight"), f("va_classifier.bias")
+        self.objective = _Objective(self.engine.lib)
 
     def to(self, device):
         return self
@@ -193,13 +226,19 @@ class VapGPT:
         return e[:, 0:1].contiguous(), e[:, 1:2].contiguous()
 
     def ar_channel(self, x, attention: bool = False):
-        """GPT.forward (1 self-attention layer), [B,n,256] -> {"x": [B,n,256]} (vap_main.py:285-286)."""
+        """GPT.forward (1 self-attention layer), [B,n,256] -> {"x": [B,n,256]} (vap_main.py:285-286).  The two towers share
+        weights and layer 0 has no cross-channel term, so a batch of B inputs rides as ceil(B/2) (stream, channel) pairs:
+        no input is computed twice."""
         torch = self._torch
         B, n, _ = x.shape
-        xin = torch.stack([x, x], dim=1).float().contiguous()        # the towers share weights
-        o = torch.empty(B, 2, n, 256, device=self.device)
-        self.engine.transformer_device(B, n, xin.data_ptr(), o_ptr=o.data_ptr(), stage=1, stream=self._stream())
-        return {"x": o[:, 0].contiguous()}
+        x = x.float()
+        if B % 2:
+            x = torch.cat([x, x[-1:]], dim=0)                         # odd batch: one padding row
+        P = x.shape[0] // 2
+        xin = x.reshape(P, 2, n, 256).contiguous()
+        o = torch.empty(P, 2, n, 256, device=self.device)
+        self.engine.transformer_device(P, n, xin.data_ptr(), o_ptr=o.data_ptr(), stage=1, stream=self._stream())
+        return {"x": o.reshape(2 * P, n, 256)[:B].contiguous()}
 
     def ar(self, x1, x2, attention: bool = False):
         """GPTStereo.forward (3 self+cross layers + Combinator) (vap_main.py:287)."""
@@ -245,10 +284,22 @@ class VapGPT:
     __call__ = forward
 
     def vap_head(self, t):
-        return self._torch.nn.functional.linear(t, self._head_w, self._head_b)
+        """Linear(256, 256) + bias on any [..., 256] tensor (vap_main.py:131,290): the engine's fp32-MFMA GEMM."""
+        torch = self._torch
+        x = t.float().contiguous()
+        y = torch.empty_like(x)
+        self.engine._check(self.engine.lib.vapx_vap_head(self.engine._h, x.numel() // 256, x.data_ptr(), y.data_ptr(), self._stream() or None),
+                           "vapx_vap_head")
+        return y.as_subclass(_logits_cls())
 
     def va_classifier(self, t):
-        return self._torch.nn.functional.linear(t, self._va_w, self._va_b)
+        """Linear(256, 1) + bias -> [..., 1] (vap_main.py:142,292-293); the caller applies the sigmoid."""
+        torch = self._torch
+        x = t.float().contiguous()
+        y = torch.empty(*x.shape[:-1], 1, device=x.device)
+        self.engine._check(self.engine.lib.vapx_va_classifier(self.engine._h, x.numel() // 256, x.data_ptr(), y.data_ptr(), self._stream() or None),
+                           "vapx_va_classifier")
+        return y
 
 
 # ------------------------------------------------------------------------------------------------

@@ -260,6 +260,7 @@ def blob_entries(K: int, mode: str) -> List[Tuple[str, int]]:
     e.append(("comb.waT", DIM * DIM)); e.append(("comb.wbT", DIM * DIM))    # [K][N] (head kernel)
     e.append(("comb.g", DIM)); e.append(("comb.b", DIM))
     e.append(("head.wT", N_CLASSES * DIM)); e.append(("head.b", N_CLASSES))  # [K][N]
+    e.append(("head.w", N_CLASSES * DIM))                                    # [N][K] (GEMM path of the level-1 vap_head)
     e.append(("vad.w", DIM)); e.append(("vad.b", 64))
     # auxiliary heads (bc: 3 rows, nod: 4 rows + 1 row); always present, zero when unused
     e.append(("aux.w", 8 * DIM)); e.append(("aux.b", 64))
@@ -419,6 +420,7 @@ def pack_blob(cpc_sd: Dict[str, np.ndarray], vap_sd: Dict[str, np.ndarray], mode
     put("comb.b", A(vap_sd["ar.combinator.ln.bias"]))
     if "vap_head.weight" in vap_sd:
         put("head.wT", A(vap_sd["vap_head.weight"]).T)
+        put("head.w", A(vap_sd["vap_head.weight"]))
         put("head.b", A(vap_sd["vap_head.bias"]))
     put("vad.w", A(vap_sd["va_classifier.weight"]))
     put("vad.b", A(vap_sd["va_classifier.bias"]))
