@@ -39,9 +39,8 @@ def _tiled_run(name, S, keys, extra=None, max_frames=None, seed=0):
             worst[k] = max(worst.get(k, 0.0), float(np.abs(got - want).max()))
         if extra is not None:
             extra(c, f, o, src, worst)
-        first = o["p_now"][:ns] if "p_now" in keys else o["vad"][:ns]
-        allr = o["p_now"] if "p_now" in keys else o["vad"]
-        spread = max(spread, float(np.abs(allr - first[src]).max()))
+        probe = "p_now" if "p_now" in keys else "aux"
+        spread = max(spread, float(np.abs(o[probe] - o[probe][:ns][src]).max()))
     eng.close()
     print(f"{name} x {S} slots: worst |hip - reference golden| = {worst}; replica spread {spread:.2e}")
     for k, v in worst.items():
@@ -83,5 +82,5 @@ def _nod_extra(c, f, o, src, worst):
 
 def test_bc_and_nod_heads_at_4096_streams():
     """C5 shape: the bc and nod variants at 4096 streams (nod runs the full last layer + the all-rows p_bc)."""
-    _tiled_run("bc20", 4096, ("vad",), extra=_bc_extra)
-    _tiled_run("nod20", 4096, ("vad",), extra=_nod_extra)
+    _tiled_run("bc20", 4096, ("e",), extra=_bc_extra)       # (the bc / nod programs never fill result_vad: no golden for it)
+    _tiled_run("nod20", 4096, ("e",), extra=_nod_extra)
