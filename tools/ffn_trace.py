@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Timeline of ffn_block_kernel workgroups from the s_memtime phase stamps (engine env VAPX_FFN_TRACE=<file>, layer-0 FFN
+block of the last step).  Usage: VAPX_FFN_TRACE=/tmp/t.bin python bench.py --streams S --configs= ... ; tools/ffn_trace.py /tmp/t.bin
+s_memtime ticks at a constant 100 MHz on gfx950 (10 ns)."""
+import sys
+
+import numpy as np
+
+NAMES = ["entry", "tile staged+LN", "ffn1.0 mm", "gelu.0", "h->LDS.0", "ffn2.0 mm", "ffn1.1 mm", "gelu.1", "h->LDS.1", "ffn2.1 mm",
+         "ffn1.2 mm", "gelu.2", "h->LDS.2", "ffn2.2 mm", "resid add", "x_out store", "x->LDS", "kvx0 mm", "kvx0 store", "kvx1 mm",
+         "kvx1 store", "LN_self->LDS", "q mm", "q store", "k mm", "k store", "v mm", "v store"]
+t = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 32).astype(np.int64)
+tick_ns = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
+n = t.shape[0]
+valid = (t[:, :28] > 0).all(axis=1)
+t = t[valid]
+t0 = t[:, 0].min()
+start, end = (t[:, 0] - t0) * tick_ns / 1e3, (t[:, 27] - t0) * tick_ns / 1e3
+dur = end - start
+print(f"{n} workgroups ({valid.sum()} complete); kernel span {end.max():.1f} us; per-WG duration median {np.median(dur):.1f} us "
+      f"(min {dur.min():.1f}, max {dur.max():.1f})")
+order = np.argsort(start)
+q = [0, 0.25, 0.5, 0.75, 1.0]
+print("start time quantiles (us):", [round(float(np.quantile(start, x)), 1) for x in q])
+print("end   time quantiles (us):", [round(float(np.quantile(end, x)), 1) for x in q])
+d = np.diff(t[:, :28], axis=1) * tick_ns / 1e3
+print("phase durations, median over WGs (us) [p10 .. p90]:")
+mm_tot = other_tot = 0.0
+for k in range(27):
+    med = float(np.median(d[:, k]))
+    if "mm" in NAMES[k + 1]:
+        mm_tot += med
+    else:
+        other_tot += med
+    print(f"  {NAMES[k + 1]:16s} {med:7.2f}  [{np.quantile(d[:, k], 0.1):6.2f} .. {np.quantile(d[:, k], 0.9):6.2f}]")
+print(f"sum of MFMA phases {mm_tot:.1f} us, everything else {other_tot:.1f} us")
+# first-round vs later-round workgroups
+first = start < np.median(dur) * 0.5
+if (~first).any():
+    print(f"first-wave WGs: {first.sum()}, median duration {np.median(dur[first]):.1f} us; later WGs: {(~first).sum()}, median {np.median(dur[~first]):.1f} us")

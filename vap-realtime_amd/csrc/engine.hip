@@ -90,6 +90,9 @@ struct vapx_engine {
   hipEvent_t gstart = nullptr;
   int n_groups = 1;
   int ffn_tile_rows = 0;   // tuning knob (env VAPX_FFN_TILE): 32 or 64 rows per FFN-block workgroup
+  unsigned long long* ffn_trace = nullptr;   // env VAPX_FFN_TRACE=<file>: phase stamps of the layer-0 FFN block's workgroups
+  size_t ffn_trace_wgs = 0;
+  std::string ffn_trace_path;
   float* out_pinned = nullptr;
   float* audio_pinned = nullptr;          // staging for pageable host audio (callers holding vapx_host_alloc memory skip it)
   hipEvent_t audio_evt = nullptr;         // the H2D copy out of audio_pinned has completed
@@ -360,6 +363,11 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
           fa.wqkvf = nullptr; fa.n_qkv_chunks = 0; fa.wkvxf = nullptr; fa.xn_out = sc.xn;
         }
       }
+    }
+    if (h->ffn_trace && l == 0) {
+      fa.trace = h->ffn_trace;
+      h->ffn_trace_wgs = std::min<size_t>(16384, (size_t)(M + 31) / 32);
+      if ((size_t)(M + 31) / 32 > 16384) fa.trace = nullptr;
     }
     if (split) { ProfScope ps(h, CLS_FFN, st); HIPCHK(h, launch_ffn_block_f16x3(fa, st)); }
     else
@@ -665,6 +673,13 @@ void vapx_destroy(vapx_handle h) {
   for (vapx_engine* f : h->followers) { f->trunk = nullptr; f->orphaned = true; }
   (void)hipSetDevice(h->cfg.device_id);
   (void)hipDeviceSynchronize();
+  if (h->ffn_trace) {   // dump the stamps of the last traced launch: [wgs][32] u64
+    std::vector<unsigned long long> host(h->ffn_trace_wgs * 32);
+    if (!host.empty() && hipMemcpy(host.data(), h->ffn_trace, host.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+      if (FILE* f = fopen(h->ffn_trace_path.c_str(), "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
+    }
+    (void)hipFree(h->ffn_trace);
+  }
   float* fp[] = {h->w, h->ring, h->ring_qkv, h->h_state, h->c_state, h->carry, h->audio_dev, h->out_dev, h->sc.h0, h->sc.h1, h->sc.h2, h->sc.h3,
                  h->sc.z, h->sc.lstm_out, h->sc.e, h->sc.xl[0], h->sc.xl[1], h->sc.xl[2], h->sc.xl[3], h->sc.xl[4], h->sc.xn, h->sc.xmid, h->sc.att,
                  h->sc.qkv, h->sc.qx, h->sc.kvx, h->sc.ffn, h->sc.gx, h->sc.last[0], h->sc.last[1], h->sc.last[2],
@@ -782,6 +797,10 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
   CR(hipHostMalloc((void**)&h->audio_pinned, B * 2 * h->L * sizeof(float), hipHostMallocDefault));
   h->id_stamp.assign(S, 0u);
   if (const char* ev = getenv("VAPX_FFN_TILE")) h->ffn_tile_rows = atoi(ev);
+  if (const char* ev = getenv("VAPX_FFN_TRACE")) {
+    h->ffn_trace_path = ev;
+    CR(dalloc(&h->ffn_trace, (size_t)16384 * 32));
+  }
   h->n_groups = cfg->flags & 0xF;
   if (h->n_groups == 0) h->n_groups = 1;   // measured: no gain at 256 streams, +2 % at 4096 with 2
   if (h->n_groups > vapx_engine::kMaxGroups) h->n_groups = vapx_engine::kMaxGroups;

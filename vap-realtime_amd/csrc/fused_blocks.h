@@ -19,6 +19,7 @@ struct FfnArgs {
   int n_qkv_chunks;    // 3 (Q,K,V) or 2 (K,V only: pass wqkvf + 65536)
   int tile_rows;       // 32 (default) or 64 rows per workgroup
   int M;
+  unsigned long long* trace;   // optional [grid][32] s_memtime stamps of workgroup phases (env VAPX_FFN_TRACE), null in production
 };
 
 struct AttnBlockArgs {

@@ -40,6 +40,12 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5, kh = hi * 4;
   const int m0 = blockIdx.x * BM;
+  int stamp_k = 0;
+  auto STAMP = [&]() {   // phase time stamps of wave 0 (debug builds of the timeline: tools/ffn_trace.py)
+    if (g.trace && tid == 0 && stamp_k < 32) g.trace[(long)blockIdx.x * 32 + stamp_k] = __builtin_amdgcn_s_memtime();
+    ++stamp_k;
+  };
+  STAMP();
 
   // acc[mt][2] += A[BM x 256] (LDS) . Wsub^T for this wave's 64 columns; wfrag = 256x256 fragment
   // block.  Weight fragments run through an in-place register ring one 8-kc block ahead (~4k MFMA
@@ -76,6 +82,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
     }
   }
   __syncthreads();
+  STAMP();   // 1: tile staged + normalised
 
   auto mm = [&](f32x16(&acc)[MT][2], const float* A, const float* wfrag, const float* next_wfrag) {
     const float* pa = A + l31 * LDH + kh;
@@ -158,6 +165,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
     f32x16 hacc[MT][2];
     zero(hacc);
     mm(hacc, sX, g.w0f + (long)c * 65536, g.w3f + (long)c * 65536);
+    STAMP();   // 2 + 4c: FFN1 chunk MFMAs done
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -166,10 +174,13 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
         hacc[mt][1][r] = gelu_fast(hacc[mt][1][r]);
         if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
+    STAMP();   // 3 + 4c: GELU done
     __syncthreads();          // every wave is done reading the previous chunk from sH
     to_sH(hacc);
     __syncthreads();
+    STAMP();   // 4 + 4c: hidden chunk in LDS
     mm(out, sH, g.w3f + (long)c * 65536, c < 2 ? g.w0f + (long)(c + 1) * 65536 : after_ffn);
+    STAMP();   // 5 + 4c: FFN2 chunk MFMAs done
   }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -181,18 +192,23 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
       out[mt][0][r] += rp[0];
       out[mt][1][r] += rp[32];
     }
+  STAMP();   // 14: residual added
   store_global(out, g.xout, 256, 0);
+  STAMP();   // 15: x_out stored
 
   // ---- next layer's cross K,V from the RAW layer output ----
   if (g.wkvxf) {
     __syncthreads();
     to_sH(out);
     __syncthreads();
+    STAMP();   // 16
     for (int nc = 0; nc < 2; ++nc) {
       f32x16 acc[MT][2];
       zero(acc);
       mm(acc, sH, g.wkvxf + (long)nc * 65536, nc == 0 ? g.wkvxf + 65536 : (nq ? g.wqkvf : nullptr));
+      STAMP();   // 17, 19
       store_global(acc, g.kvx, 512, nc * 256);
+      STAMP();   // 18, 20
     }
   }
   // ---- next layer's self Q,K,V from LayerNorm(x) (or just the normalised rows) ----
@@ -248,11 +264,14 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
         }
       }
     __syncthreads();
+    STAMP();   // 21: LN_self rows in LDS
     for (int nc = 0; nc < nq; ++nc) {
       f32x16 acc[MT][2];
       zero(acc);
       mm(acc, sH, g.wqkvf + (long)nc * 65536, nc + 1 < nq ? g.wqkvf + (long)(nc + 1) * 65536 : nullptr);
+      STAMP();   // 22, 24, 26
       store_global(acc, g.qkv, nq * 256, nc * 256);
+      STAMP();   // 23, 25, 27
     }
   }
 }
