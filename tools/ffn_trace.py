@@ -14,9 +14,15 @@ tick_ns = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
 n = t.shape[0]
 valid = (t[:, :28] > 0).all(axis=1)
 t = t[valid]
-t0 = t[:, 0].min()
-start, end = (t[:, 0] - t0) * tick_ns / 1e3, (t[:, 27] - t0) * tick_ns / 1e3
+# absolute times from s_memrealtime (constant 100 MHz, chip-wide); the phase stamps are s_memtime (per-XCD counter whose rate
+# is calibrated per workgroup against the realtime pair)
+rt0 = t[:, 28].min()
+start, end = (t[:, 28] - rt0) * 0.01, (t[:, 29] - rt0) * 0.01          # us
 dur = end - start
+ticks = (t[:, 27] - t[:, 0]).astype(np.float64)
+us_per_tick = dur / np.maximum(ticks, 1)
+print(f"s_memtime rate: median {1.0 / np.median(us_per_tick):.1f} ticks/us")
+tick_ns = float(np.median(us_per_tick)) * 1e3
 print(f"{n} workgroups ({valid.sum()} complete); kernel span {end.max():.1f} us; per-WG duration median {np.median(dur):.1f} us "
       f"(min {dur.min():.1f}, max {dur.max():.1f})")
 order = np.argsort(start)
@@ -38,3 +44,6 @@ print(f"sum of MFMA phases {mm_tot:.1f} us, everything else {other_tot:.1f} us")
 first = start < np.median(dur) * 0.5
 if (~first).any():
     print(f"first-wave WGs: {first.sum()}, median duration {np.median(dur[first]):.1f} us; later WGs: {(~first).sum()}, median {np.median(dur[~first]):.1f} us")
+# concurrency over time: how many WGs are resident at 10 evenly spaced instants
+ts = np.linspace(0, end.max(), 12)[1:-1]
+print("resident WGs over the kernel:", [int(((start <= x) & (end > x)).sum()) for x in ts])

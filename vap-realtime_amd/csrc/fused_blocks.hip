@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
     ++stamp_k;
   };
   STAMP();
+  if (g.trace && tid == 0) g.trace[(long)blockIdx.x * 32 + 28] = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz, chip-wide
 
   // acc[mt][2] += A[BM x 256] (LDS) . Wsub^T for this wave's 64 columns; wfrag = 256x256 fragment
   // block.  Weight fragments run through an in-place register ring one 8-kc block ahead (~4k MFMA
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
       STAMP();   // 23, 25, 27
     }
   }
+  if (g.trace && tid == 0) g.trace[(long)blockIdx.x * 32 + 29] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ------------------------------------------------------------------------------------------------
