@@ -65,10 +65,11 @@ def macs_per_stream_frame(hz: int, T: int) -> dict:
         "gemm_cn_relu": 2 * (P1 * 8 + P2 * 4 + P3 * 4 + ncpc * 4) * D * D,
         "lstm": 2 * ncpc * D * 4 * D + 2 * ncpc * D * D,                # recurrence (K=256) + fused downsample
         "gemm_bias_ln_gelu": 0,
-        "gemm_store": 2 * ncpc * D * 4 * D + 2 * D * 768                # LSTM input projection + layer-0 QKV of the NEW row (others cached)
-                      + (0 if fused else rows * 2 * D * D),             # long windows: the two cross-attention query projections
-        "gemm_resid_ln": 0 if fused else rows * 5 * D * D,              # long windows: the five output projections (+ residual + LN)
-        "ffn_block": rows * D * (3 * 2 * 768 + 2 * 768 + 2 * 512),      # FFN x3 + QKV and cross-KV of layers 1, 2 (layer 3: absorbed)
+        "gemm_store": 2 * ncpc * D * 4 * D + 2 * D * 768,               # LSTM input projection + layer-0 QKV of the NEW row (others cached)
+        "gemm_resid_ln": 0,
+        # FFN x3 + QKV and cross-KV of layers 1, 2 (layer 3: absorbed); long windows: + the five attention output projections and
+        # the two cross-attention query projections, which ride in the same flat-row blocks (fused_blocks.hip, modes 1 / 2)
+        "ffn_block": rows * D * (3 * 2 * 768 + 2 * 768 + 2 * 512 + (0 if fused else 7 * D)),
         # layer 3 on one row per channel: 14 contractions (q, Wk^T q, Wv, proj, their cross twins, FFN) + two
         # 4-head single-query attentions over T rows of 256 (score + weighted sum)
         "last_row": 2 * (14 * D * D + 2 * 4 * T * D * 2),

@@ -73,6 +73,8 @@ extern "C" {
                                          layer 0 reads the rings in place */
 #define VAPX_FLAG_SPLIT_F16 512        /* opt-in: the FFN block's contractions as fp32-accurate 3-term split products on the f16
                                          matrix cores (x = hi + lo; hi.hi + lo.hi + hi.lo, fp32 accumulate); default: fp32 MFMA */
+#define VAPX_FLAG_UNFUSED_PROJ 1024    /* long windows (T > 64): attention output projections (+ residual + LN, + cross-attention query
+                                         projection) as separate GEMM launches instead of riding in the fused blocks; kept for A/B tests */
 #define VAPX_FLAG_UNFUSED_LAST_ROW 256 /* last layer's newest-row path as ten launches (gathers, M = 2B GEMMs, single-query
                                          attention) instead of the fused last_block_kernel; kept for A/B parity tests */
 #define VAPX_FLAG_UNFUSED_CONV 32     /* conv2-4 as three GEMM launches (materialises "h2","h3" for vapx_peek) */

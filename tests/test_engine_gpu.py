@@ -458,3 +458,24 @@ def test_odd_batch_sizes_hit_every_tile_tail(S):
         for k in ("p_now", "p_future", "vad", "logits", "e"):
             np.testing.assert_allclose(got[k], want[k], rtol=0, atol=TOL, err_msg=f"S={S} frame {f} {k}")
     eng.close()
+
+
+def test_long_window_fused_projections_equal_the_gemm_chain():
+    """T = 250: the attention output projections (+ residual + LN, + cross-attention query projection) ride in the fused flat-row
+    blocks (ffn_block modes 1 / 2) by default; VAPX_FLAG_UNFUSED_PROJ keeps the separate GEMM launches.  Same numbers, odd batch,
+    window still filling and then sliding."""
+    from vap_realtime_amd import engine, synth, weights as W
+    cpc, vap = W.synthetic_weights(21, 50, "vap")
+    blob = W.pack_blob(cpc, vap)
+    S, F_, hop = 5, 260, 320
+    audio = synth.noise_batch(S, hop * F_, seed=2) * np.linspace(0.3, 2.0, S, dtype=np.float32)[:, None, None]
+    fused = engine.Engine(blob, 50, 5.0, max_streams=S)
+    plain = engine.Engine(blob, 50, 5.0, max_streams=S, unfused_proj=True)
+    worst = 0.0
+    for f in range(F_):
+        a = audio[:, :, f * hop:(f + 1) * hop]
+        got, want = fused.step(a), plain.step(a)
+        worst = max(worst, float(np.abs(got[:, :272] - want[:, :272]).max()))
+    print("fused vs unfused long-window projections: worst |diff| =", worst)
+    assert worst <= 3e-5
+    fused.close(); plain.close()

@@ -294,6 +294,7 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
     const float* xin = sc.xl[l];
     float* xout = sc.xl[l + 1];
     GemmArgs g;
+    const float *pre_att = nullptr, *pre_w = nullptr, *pre_resid = nullptr;   // long window: projection fused into the FFN block
     if (l == l_begin && !(l == 0 && qkv0_ready)) {
       g = gemm_args(sc.xn, r256, Lw.wqkv, M, 768, 256, sc.qkv, r768);
       HIPCHK(h, gemm(h, g, EPI_STORE, st));
@@ -323,6 +324,22 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
         ab.wqxf = nullptr; ab.qx = nullptr; ab.xn = nullptr; ab.ring_rot = nullptr; ab.ids = nullptr;
         { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attn_block(ab, B, st)); }
       }
+    } else if (!(h->cfg.flags & (VAPX_FLAG_UNFUSED_PROJ | VAPX_FLAG_SPLIT_F16))) {
+      // long window: plain attention kernels; every projection rides in a fused flat-row block (no [rows x 256] GEMM launches)
+      AttnArgs aa{sc.qkv, sc.qkv + 256, sc.qkv + 512, sc.att, sc.bn, T, 768, 768, 0};
+      { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attention(aa, B, st)); }
+      pre_att = sc.att; pre_w = Lw.wprojf; pre_resid = xin;
+      if (l > 0) {
+        // self half: xmid = xin + att.Wproj^T ; qx = LN_src(xmid).Wq_x^T
+        FfnArgs fp;
+        memset(&fp, 0, sizeof fp);
+        fp.mode = 2; fp.M = M; fp.att = sc.att; fp.wprojf = Lw.wprojf; fp.resid = xin; fp.xmid_out = sc.xmid;
+        fp.ln_g = Lw.ln_src_g; fp.ln_b = Lw.ln_src_b; fp.wqkvf = Lw.wqxf; fp.n_qkv_chunks = 1; fp.qkv = sc.qx;
+        { ProfScope ps(h, CLS_FFN, st); HIPCHK(h, launch_ffn_block(fp, st)); }
+        AttnArgs ax{sc.qx, sc.kvx, sc.kvx + 256, sc.att, sc.bn, T, 256, 512, 1};
+        { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attention(ax, B, st)); }
+        pre_w = Lw.wprojxf; pre_resid = sc.xmid;
+      }
     } else {
     // self attention
       AttnArgs aa{sc.qkv, sc.qkv + 256, sc.qkv + 512, sc.att, sc.bn, T, 768, 768, 0};
@@ -348,6 +365,7 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
     FfnArgs fa;
     memset(&fa, 0, sizeof fa);
     fa.xmid = sc.xmid; fa.lnf_g = Lw.ln_ffn_g; fa.lnf_b = Lw.ln_ffn_b; fa.xout = xout; fa.M = M;
+    if (pre_att) { fa.mode = 1; fa.att = pre_att; fa.wprojf = pre_w; fa.resid = pre_resid; fa.xmid_out = sc.xmid; }
     fa.w0f = split ? Lw.w0h : Lw.w0f; fa.w3f = split ? Lw.w3h : Lw.w3f;
     fa.tile_rows = h->ffn_tile_rows ? h->ffn_tile_rows : (split ? 0 : 32);
     if (l + 1 < l_end) {

@@ -20,6 +20,16 @@ struct FfnArgs {
   int tile_rows;       // 32 (default) or 64 rows per workgroup
   int M;
   unsigned long long* trace;   // optional [grid][32] s_memtime stamps of workgroup phases (env VAPX_FFN_TRACE), null in production
+  // Long-window path (T > 64): the attention output projection rides in front of the block instead of a separate GEMM:
+  //   xmid = resid + att . Wproj^T   (-> xmid_out, the residual stream), then LayerNorm as usual.
+  // mode 0: xmid is read from global (fused attention block wrote it).  mode 1: pre-projection + the whole block.
+  // mode 2: pre-projection + LN(ln_g, ln_b) + the n_qkv_chunks contractions of wqkvf -> qkv only (self-attention half of a
+  //         stereo layer: LN_src + cross-attention query projection), no FFN.
+  int mode;
+  const float* att;    // [M][256] attention output (heads merged)
+  const float* wprojf; // output projection, fragment-major
+  const float* resid;  // [M][256]
+  float* xmid_out;     // [M][256]
 };
 
 struct AttnBlockArgs {

@@ -27,7 +27,7 @@ constexpr int LDH = 260;   // resident [32][256] buffer row stride (256 + 4 pad)
 // activation rows all four waves share) lives in LDS.
 // MT = 32-row sub-tiles per workgroup (1: 32 rows, 67 KB LDS, 2 workgroups/CU; 2: 64 rows, 133 KB,
 // 1 workgroup/CU but every weight fragment feeds two MFMAs -> half the L2->VGPR weight traffic).
-template <int MT>
+template <int MT, int MODE = 0>
 __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const FfnArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BM = 32 * MT;
@@ -58,7 +58,18 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
 #pragma unroll
     for (int i = 0; i < 16; ++i) ring[i] = wf[i * 64 + lane];
   };
-  fetch(g.w0f);   // the first weight fragments fly while the activation tile is loaded and normalised
+  fetch(MODE == 0 ? g.w0f : g.wprojf);   // the first weight fragments fly while the activation tile is loaded and normalised
+  if constexpr (MODE != 0) {   // raw attention rows -> sH (A operand of the output projection)
+    f32x4 xr[BM / 4];
+#pragma unroll
+    for (int k = 0; k < BM / 4; ++k) {
+      int m = m0 + (tid >> 6) + 4 * k;
+      m = m < g.M ? m : g.M - 1;
+      xr[k] = *(const f32x4*)(g.att + (long)m * 256 + lane * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < BM / 4; ++k) *(f32x4*)&sH[((tid >> 6) + 4 * k) * LDH + lane * 4] = xr[k];
+  } else
   {  // A operand of FFN1 = LayerNorm(xmid; ln_ffn), normalised while the tile is staged: every wave
      // loads whole rows (64 lanes x 16 B), so the row statistics are two wave reductions — the
      // producer (attention block) no longer writes a normalised copy to HBM at all
@@ -157,10 +168,87 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
       }
   };
 
-  // ---- feed-forward: x = xmid + gelu(xn W0^T) W3^T, hidden processed in 3 chunks of 256 ----
+  // LayerNorm over the 256 columns of the tile rows held in accumulator layout (two-pass, partials across the 4 waves via
+  // `red`) -> dst (LDS, [BM][260]) and optionally to global rows
+  auto ln_rows = [&](const f32x16(&v)[MT][2], const float* gam, const float* bet, float* dst, float* gout) {
+    float s[MT][16], mean[MT][16];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[mt][r] = half_sum(v[mt][0][r] + v[mt][1][r]);
+    __syncthreads();          // also: every wave is done reading dst / red from the previous phase
+    if (l31 == 0)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[w * BM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = s[mt][r];
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int lr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        mean[mt][r] = (red[lr] + red[BM + lr] + red[2 * BM + lr] + red[3 * BM + lr]) * (1.0f / 256.0f);
+      }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float d0 = v[mt][0][r] - mean[mt][r], d1 = v[mt][1][r] - mean[mt][r];
+        s[mt][r] = half_sum(d0 * d0 + d1 * d1);
+      }
+    if (l31 == 0)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[w * BM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = s[mt][r];
+    __syncthreads();
+    const float g0 = gam[ccol], g1 = gam[ccol + 32], b0 = bet[ccol], b1 = bet[ccol + 32];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int lr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float var = (red[lr] + red[BM + lr] + red[2 * BM + lr] + red[3 * BM + lr]) * (1.0f / 256.0f);
+        float rstd = rsqrtf(var + 1e-5f);
+        const float y0 = (v[mt][0][r] - mean[mt][r]) * rstd * g0 + b0;
+        const float y1 = (v[mt][1][r] - mean[mt][r]) * rstd * g1 + b1;
+        dst[lr * LDH + ccol] = y0;
+        dst[lr * LDH + ccol + 32] = y1;
+        if (gout && m0 + lr < g.M) {
+          gout[(long)(m0 + lr) * 256 + ccol] = y0;
+          gout[(long)(m0 + lr) * 256 + ccol + 32] = y1;
+        }
+      }
+    __syncthreads();
+  };
+  auto add_rows = [&](f32x16(&v)[MT][2], const float* src) {   // v += src tile (global [M][256] rows)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        m = m < g.M ? m : g.M - 1;
+        const float* rp = src + (long)m * 256 + ccol;
+        v[mt][0][r] += rp[0];
+        v[mt][1][r] += rp[32];
+      }
+  };
+
   const int nq = g.wqkvf ? g.n_qkv_chunks : 0;
   const float* after_ffn = g.wkvxf ? g.wkvxf : (nq ? g.wqkvf : nullptr);
   f32x16 out[MT][2];
+  if constexpr (MODE != 0) {
+    // ---- attention output projection + residual: xmid = resid + att . Wproj^T (the separate GEMM of the long-window path) ----
+    zero(out);
+    mm(out, sH, g.wprojf, MODE == 1 ? g.w0f : after_ffn);
+    add_rows(out, g.resid);
+    store_global(out, g.xmid_out, 256, 0);
+    if constexpr (MODE == 1) ln_rows(out, g.lnf_g, g.lnf_b, sX, nullptr);   // A operand of FFN1
+  }
+  if constexpr (MODE != 2) {
+  // ---- feed-forward: x = xmid + gelu(xn W0^T) W3^T, hidden processed in 3 chunks of 256 ----
   zero(out);
   for (int c = 0; c < 3; ++c) {
     f32x16 hacc[MT][2];
@@ -183,16 +271,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
     mm(out, sH, g.w3f + (long)c * 65536, c < 2 ? g.w0f + (long)(c + 1) * 65536 : after_ffn);
     STAMP();   // 5 + 4c: FFN2 chunk MFMAs done
   }
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      m = m < g.M ? m : g.M - 1;
-      const float* rp = g.xmid + (long)m * 256 + ccol;
-      out[mt][0][r] += rp[0];
-      out[mt][1][r] += rp[32];
-    }
+  add_rows(out, MODE == 0 ? g.xmid : g.xmid_out);   // (mode 1: this workgroup's own xmid rows, written above)
   STAMP();   // 14: residual added
   store_global(out, g.xout, 256, 0);
   STAMP();   // 15: x_out stored
@@ -212,59 +291,10 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
       STAMP();   // 18, 20
     }
   }
+  }   // MODE != 2
   // ---- next layer's self Q,K,V from LayerNorm(x) (or just the normalised rows) ----
   if (nq || g.xn_out) {
-    float s[MT][16], mean[MT][16];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[mt][r] = half_sum(out[mt][0][r] + out[mt][1][r]);
-    __syncthreads();          // also: every wave is done reading sH (cross K,V)
-    if (l31 == 0)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[w * BM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = s[mt][r];
-    __syncthreads();
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int lr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        mean[mt][r] = (red[lr] + red[BM + lr] + red[2 * BM + lr] + red[3 * BM + lr]) * (1.0f / 256.0f);
-      }
-    __syncthreads();
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float d0 = out[mt][0][r] - mean[mt][r], d1 = out[mt][1][r] - mean[mt][r];
-        s[mt][r] = half_sum(d0 * d0 + d1 * d1);
-      }
-    if (l31 == 0)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[w * BM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = s[mt][r];
-    __syncthreads();
-    const float g0 = g.ln_g[ccol], g1 = g.ln_g[ccol + 32], b0 = g.ln_b[ccol], b1 = g.ln_b[ccol + 32];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int lr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        float var = (red[lr] + red[BM + lr] + red[2 * BM + lr] + red[3 * BM + lr]) * (1.0f / 256.0f);
-        float rstd = rsqrtf(var + 1e-5f);
-        const float y0 = (out[mt][0][r] - mean[mt][r]) * rstd * g0 + b0;
-        const float y1 = (out[mt][1][r] - mean[mt][r]) * rstd * g1 + b1;
-        sH[lr * LDH + ccol] = y0;
-        sH[lr * LDH + ccol + 32] = y1;
-        if (g.xn_out && m0 + lr < g.M) {
-          g.xn_out[(long)(m0 + lr) * 256 + ccol] = y0;
-          g.xn_out[(long)(m0 + lr) * 256 + ccol + 32] = y1;
-        }
-      }
-    __syncthreads();
+    ln_rows(out, g.ln_g, g.ln_b, sH, g.xn_out);
     STAMP();   // 21: LN_self rows in LDS
     for (int nc = 0; nc < nq; ++nc) {
       f32x16 acc[MT][2];
@@ -865,8 +895,20 @@ hipError_t launch_ffn_block(const FfnArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)ffn_block_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  const int mt = a.tile_rows == 64 ? 2 : 1;
+  const int mt = (a.tile_rows == 64 && a.mode == 0) ? 2 : 1;
   const size_t lds = (size_t)(2 * 32 * mt * LDH + 4 * 32 * mt) * sizeof(float);
+  if (a.mode == 1 || a.mode == 2) {
+    static bool attr2 = false;
+    if (!attr2) {
+      (void)hipFuncSetAttribute((const void*)ffn_block_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)ffn_block_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr2 = true;
+    }
+    if (!a.att || !a.wprojf || !a.resid || !a.xmid_out) return hipErrorInvalidValue;
+    if (a.mode == 1) hipLaunchKernelGGL((ffn_block_kernel<1, 1>), dim3((a.M + 31) / 32), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((ffn_block_kernel<1, 2>), dim3((a.M + 31) / 32), dim3(256), lds, st, a);
+    return hipGetLastError();
+  }
   if (mt == 2) hipLaunchKernelGGL(ffn_block_kernel<2>, dim3((a.M + 63) / 64), dim3(256), lds, st, a);
   else hipLaunchKernelGGL(ffn_block_kernel<1>, dim3((a.M + 31) / 32), dim3(256), lds, st, a);
   return hipGetLastError();
