@@ -13,12 +13,12 @@ mkdir -p $OUT $RAW
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --workload $WL --configs= --no-latency --no-cpu-baseline --paced-sec 0 --steps $STEPS --warmup 1"
 $BENCH > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats -d $RAW/stats -o run -- $BENCH > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats -f csv -d $RAW/stats -o run -- $BENCH > $OUT/stats.log 2>&1
 cp $(find $RAW/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
 rm -rf $RAW/stats
 pass() {  # name, counters...
   local name=$1; shift
-  rocprofv3 --pmc "$@" -d $RAW/$name -o run -- $BENCH > $OUT/$name.log 2>&1
+  rocprofv3 --pmc "$@" -f csv -d $RAW/$name -o run -- $BENCH > $OUT/$name.log 2>&1
   local csv=$(find $RAW/$name -name "*counter_collection.csv" | head -1)
   if [ -n "$csv" ]; then python $REPO/tools/pmc_summary.py $csv kernel > $OUT/$name.txt; else echo "no counter csv" > $OUT/$name.txt; fi
   tail -3 $OUT/$name.log > $OUT/$name.log.tail; rm -f $OUT/$name.log
