@@ -253,7 +253,8 @@ int vapx_profile_read(vapx_handle h, double* total_ms, int64_t* launches, int32_
  *     the k-th output connection hears the k-th input stream; broadcast = 1 sends every result to every output
  *     connection (the reference's behaviour; default for a 1-stream engine);
  *   - a tick runs when min_batch streams are ready (0: all connected ones), or max_wait_us after the first became ready
- *     (ragged batches: only the ready streams are stepped);
+ *     (ragged batches: only the ready streams are stepped), but never sooner than the pacing rule allows (target_util_pct:
+ *     small back-to-back batches would keep the GPU 100 % busy at its least efficient operating point);
  *   - output sockets are non-blocking like the reference's (:346-347): a listener that cannot take a whole packet is dropped;
  *   - a stream whose results are not finite (VAPX_OUT_STATUS) is reset and skipped for that tick, the others are served.
  * The engine handle must outlive the front-end and must not be stepped by anyone else while it runs. */
@@ -271,6 +272,9 @@ typedef struct vapx_ingest_config {
   int32_t broadcast;        /* -1 = auto (1 for a single-stream engine), 0, 1 */
   int32_t bind_any;         /* 0 = 127.0.0.1 like the reference, 1 = 0.0.0.0 */
   double gain;              /* audio_gain, 1.0 = off */
+  int32_t target_util_pct;  /* pacing: the next tick starts no earlier than (previous tick's start + its duration * 100 / pct), so the
+                               engine stays at most pct % busy and batches grow instead of the queue (0 = 75; 100 = back-to-back) */
+  int32_t reserved;
 } vapx_ingest_config;
 
 typedef struct vapx_ingest_stats {

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--max-wait-ms", type=float, default=2.0)
     ap.add_argument("--min-batch", type=int, default=0)
     ap.add_argument("--max-batch", type=int, default=0)
+    ap.add_argument("--target-util", type=float, default=0.75)
     ap.add_argument("--rx-threads", type=int, default=4)
     ap.add_argument("--tx-threads", type=int, default=4)
     ap.add_argument("--client-threads", type=int, default=8)
@@ -64,7 +65,7 @@ def main():
         else:
             eng = engine.Engine(W.pack_blob(cpc, vap_sd), args.hz, args.ctx_sec, max_streams=S, max_batch=args.max_batch or None)
             srv = ingest.NativeServer(eng, port_in=0, port_out=0, max_wait_s=args.max_wait_ms * 1e-3, min_batch=args.min_batch,
-                                      rx_threads=args.rx_threads, tx_threads=args.tx_threads)
+                                      rx_threads=args.rx_threads, tx_threads=args.tx_threads, target_util=args.target_util)
             kind = "native front-end (vapx_ingest_*) + engine"
     cmd = [loadgen, "--port-in", str(srv.port_in), "--port-out", str(srv.port_out), "--streams", str(S), "--hz", str(args.hz),
            "--seconds", str(args.seconds), "--warm", str(args.warm), "--packet-ms", str(args.packet_ms), "--threads", str(args.client_threads)]

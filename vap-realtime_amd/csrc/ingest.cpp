@@ -539,6 +539,8 @@ void tick_main(vapx_ingest* g) {
   double first_ready = 0.0;
   int jsel = 0;
   const double max_wait = (g->cfg.max_wait_us > 0 ? g->cfg.max_wait_us : 2000) * 1e-6;
+  const double util = (g->cfg.target_util_pct > 0 ? std::min(g->cfg.target_util_pct, 100) : 75) * 0.01;
+  double earliest_next = 0.0;              // pacing: previous tick's start + its duration / util
   while (!g->stop.load()) {
     std::vector<Ready> fresh;
     std::vector<std::pair<int, int>> resets;
@@ -567,6 +569,11 @@ void tick_main(vapx_ingest* g) {
     want = std::max(1, std::min(want, std::min(connected > 0 ? connected : 1, g->max_batch)));
     const double now = mono_now();
     if ((int)pending.size() < want && now - first_ready < max_wait) continue;
+    if (now < earliest_next && (int)pending.size() < g->max_batch) {   // let the batch grow instead of the queue
+      std::unique_lock<std::mutex> lk(g->ready_mu);
+      if (g->ready.empty()) g->ready_cv.wait_for(lk, std::chrono::microseconds((long)((earliest_next - now) * 1e6) + 1));
+      continue;
+    }
 
     Job& job = g->jobs[jsel];
     {
@@ -598,7 +605,9 @@ void tick_main(vapx_ingest* g) {
     }
     const double t0 = mono_now();
     const int rc = g->step(g->user, n, g->batch_ids.data(), g->batch_audio, job.out);
-    g->step_us.fetch_add((int64_t)((mono_now() - t0) * 1e6));
+    const double t1 = mono_now();
+    earliest_next = t0 + (t1 - t0) / util;
+    g->step_us.fetch_add((int64_t)((t1 - t0) * 1e6));
     g->ticks.fetch_add(1);
     g->batch_sum.fetch_add(n);
     if (rc != 0 && rc != VAPX_E_NUMERIC) {   // the step itself failed: nothing to send; free the frames and keep serving

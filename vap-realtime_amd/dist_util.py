@@ -19,11 +19,22 @@ def init(backend: str, device=None):
         return None
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    kw = {}
-    if device is not None and backend == "nccl":
-        kw["device_id"] = device
-    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    if "MASTER_PORT" not in os.environ:
+        raise RuntimeError("MASTER_PORT is not set: launch the ranks with torch.distributed.run (bench.py --gpus N does that itself)")
+    if backend == "nccl":
+        # RCCL for CUDA tensors (the barrier / max-over-ranks of the bench), gloo for CPU tensors (shard bookkeeping); if RCCL
+        # cannot come up in this environment the control plane still works over gloo — there is no collective on the data path
+        try:
+            kw = {"device_id": device} if device is not None else {}
+            dist.init_process_group("cpu:gloo,cuda:nccl", rank=rank, world_size=world, **kw)
+        except Exception as e:                                    # noqa: BLE001
+            import sys
+            print(f"[dist_util] RCCL init failed ({e}); falling back to gloo for the bench's barrier", file=sys.stderr)
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return dist
 
 
@@ -78,10 +89,22 @@ def pin_rank_to_cores(local_rank: int, local_world: int):
 
 
 def barrier(dist, device_sync=None):
+    """Device synchronise, rendezvous of all ranks, device synchronise.  With a CUDA backend the rendezvous is an all-reduce
+    of one CUDA scalar (RCCL over xGMI), otherwise a CPU barrier."""
     if device_sync:
         device_sync()
     if dist is not None:
-        dist.barrier()
+        done = False
+        try:
+            import torch
+            if torch.cuda.is_available() and "nccl" in str(dist.get_backend()):
+                t = torch.ones(1, device="cuda")
+                dist.all_reduce(t)
+                done = True
+        except Exception:                                         # noqa: BLE001
+            done = False
+        if not done:
+            dist.barrier()
     if device_sync:
         device_sync()
 
@@ -90,7 +113,10 @@ def max_over_ranks(dist, value: float, device: Optional[str] = None) -> float:
     if dist is None:
         return value
     import torch
-    t = torch.tensor([value], dtype=torch.float64, device=device or "cpu")
+    dev = device or "cpu"
+    if dev != "cpu" and "nccl" not in str(dist.get_backend()):
+        dev = "cpu"
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -100,6 +126,8 @@ def gather_ints(dist, values, device: Optional[str] = None):
     if dist is None:
         return [list(values)]
     import torch
+    if device and device != "cpu" and "nccl" not in str(dist.get_backend()):
+        device = "cpu"
     t = torch.tensor(list(values), dtype=torch.int64, device=device or "cpu")
     out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)

@@ -24,7 +24,8 @@ MODE = _engine.MODE
 class _IngestConfig(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("port_in", C.c_int32), ("port_out", C.c_int32), ("rx_threads", C.c_int32),
                 ("tx_threads", C.c_int32), ("max_wait_us", C.c_int32), ("min_batch", C.c_int32), ("reset_on_connect", C.c_int32),
-                ("broadcast", C.c_int32), ("bind_any", C.c_int32), ("gain", C.c_double)]
+                ("broadcast", C.c_int32), ("bind_any", C.c_int32), ("gain", C.c_double), ("target_util_pct", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class _IngestStats(C.Structure):
@@ -41,10 +42,10 @@ _RESET_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32)
 class NativeServer:
     def __init__(self, eng: "_engine.Engine", port_in: int = 50007, port_out: int = 50008, gain: float = 1.0, max_wait_s: float = 0.002,
                  min_batch: int = 0, reset_on_connect: bool = True, broadcast: Optional[bool] = None, rx_threads: int = 0,
-                 tx_threads: int = 0, bind_any: bool = False):
+                 tx_threads: int = 0, bind_any: bool = False, target_util: float = 0.75):
         self.lib = _engine.load_library()
         self._keep = [eng]
-        cfg = self._cfg(port_in, port_out, gain, max_wait_s, min_batch, reset_on_connect, broadcast, rx_threads, tx_threads, bind_any)
+        cfg = self._cfg(port_in, port_out, gain, max_wait_s, min_batch, reset_on_connect, broadcast, rx_threads, tx_threads, bind_any, target_util)
         h = C.c_void_p()
         rc = self.lib.vapx_ingest_open(eng._h, C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -53,15 +54,16 @@ class NativeServer:
         self._ports()
 
     @staticmethod
-    def _cfg(port_in, port_out, gain, max_wait_s, min_batch, reset_on_connect, broadcast, rx_threads, tx_threads, bind_any):
+    def _cfg(port_in, port_out, gain, max_wait_s, min_batch, reset_on_connect, broadcast, rx_threads, tx_threads, bind_any, target_util=0.75):
         return _IngestConfig(C.sizeof(_IngestConfig), port_in, port_out, rx_threads, tx_threads, int(max_wait_s * 1e6), min_batch,
-                             1 if reset_on_connect else 0, -1 if broadcast is None else int(bool(broadcast)), int(bool(bind_any)), gain)
+                             1 if reset_on_connect else 0, -1 if broadcast is None else int(bool(broadcast)), int(bool(bind_any)), gain,
+                             int(round(target_util * 100)), 0)
 
     @classmethod
     def over_function(cls, step: Callable, n_streams: int, frame_hz: int = 20, mode: str = "vap", max_batch: Optional[int] = None,
                       reset: Optional[Callable] = None, port_in: int = 0, port_out: int = 0, gain: float = 1.0, max_wait_s: float = 0.002,
                       min_batch: int = 0, reset_on_connect: bool = True, broadcast: Optional[bool] = None, rx_threads: int = 0,
-                      tx_threads: int = 0):
+                      tx_threads: int = 0, target_util: float = 1.0):
         """``step(ids int32[n], audio float32[n,2,hop], out float32[n,OUT_STRIDE]) -> int`` fills ``out`` in place;
         ``reset(stream_id)`` gets negative ids (``-(id+1)``) for carry-only resets."""
         self = cls.__new__(cls)
@@ -85,7 +87,7 @@ class NativeServer:
                 reset(int(sid))
 
         self._keep = [_STEP_FN(_step), _RESET_FN(_reset)]
-        cfg = cls._cfg(port_in, port_out, gain, max_wait_s, min_batch, reset_on_connect, broadcast, rx_threads, tx_threads, False)
+        cfg = cls._cfg(port_in, port_out, gain, max_wait_s, min_batch, reset_on_connect, broadcast, rx_threads, tx_threads, False, target_util)
         h = C.c_void_p()
         rc = self.lib.vapx_ingest_open_fn(C.cast(self._keep[0], C.c_void_p), C.cast(self._keep[1], C.c_void_p), None, n_streams,
                                           max_batch or n_streams, frame_hz, MODE[mode], C.byref(cfg), C.byref(h))
