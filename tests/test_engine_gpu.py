@@ -479,3 +479,30 @@ def test_long_window_fused_projections_equal_the_gemm_chain():
     print("fused vs unfused long-window projections: worst |diff| =", worst)
     assert worst <= 3e-5
     fused.close(); plain.close()
+
+
+@pytest.mark.parametrize("hz,ctx", [(20, 5.0), (20, 7.5), (10, 10.0)])
+def test_mid_length_windows_against_the_oracle(hz, ctx):
+    """Windows between the fused-block limit (64) and 256 rows — the reference's published bc (20 Hz / 5 s, T = 100) and nod
+    (10 Hz / 10 s, T = 100) settings, and T = 150 (5 key tiles: a partly used second chunk of the online softmax) — run the
+    long-window attention kernel + flat-row projection blocks; window filling, full, and sliding."""
+    from oracle.vap_oracle import ServerFramer, VapOracle
+    from vap_realtime_amd import engine, synth, weights as W
+    cpc, vap = W.synthetic_weights(13, hz, "vap")
+    o = VapOracle(cpc, vap, hz, ctx)
+    T, hop = int(ctx * hz), 16000 // hz
+    S, F_ = 2, T + 12
+    audio = synth.dialogue_batch([70, 71], hop * F_)
+    st, fr = o.new_state(S), ServerFramer(S, hop)
+    eng = engine.Engine(W.pack_blob(cpc, vap), hz, ctx, max_streams=S)
+    assert eng.T == T
+    worst = 0.0
+    for f in range(F_):
+        new = audio[:, :, f * hop:(f + 1) * hop]
+        want = o.step(fr.frame(new), st)
+        got = engine.split_outputs(eng.step(new))
+        for k in ("p_now", "p_future", "vad", "logits"):
+            worst = max(worst, float(np.abs(got[k] - want[k]).max()))
+    print(f"T={T} @ {hz} Hz: worst |hip - oracle| = {worst:.2e}")
+    assert worst <= TOL
+    eng.close()

@@ -2,6 +2,8 @@
 // gather + LayerNorm, causal ALiBi attention, combinator + heads.
 #include "vap_kernels.h"
 
+#include <cstdlib>
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -544,6 +546,150 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// 4a. long windows (64 < T <= 256), second generation: one workgroup per (stream, channel, head) with EIGHT waves — one
+//     32-query tile each — so that every SIMD hosts two waves whose MFMA and softmax / load phases overlap (the first
+//     generation above runs one wave per SIMD with up to 476 registers: nothing hides its exp / max / rescale phases or the
+//     K / V staging).  Register budget <= 256: the key tiles of a query tile are processed in chunks of <= 4 with an
+//     online (running max / sum) softmax, so only 4 score accumulators are live.  Triangular work is balanced per SIMD:
+//     waves w and w + 4 share a SIMD and take query tiles w and 7 - w (w + 1 and 8 - w key tiles: 9 per SIMD).
+// ------------------------------------------------------------------------------------------------
+// NT (1..4) key tiles jt0 .. jt0 + NT - 1 against the wave's query tile; (m, l, o0, o1) = running max / sum / O^T
+template <int NT>
+__device__ __forceinline__ void attn_chunk(const float* Ks, const float* Vs, const f32x4 (&qf)[8], int jt0, int i, int n, int l31, int hi,
+                                           float slope, float& m, float& l, f32x16& o0, f32x16& o1) {
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const float* ka = &Ks[((jt0 + t) * 32 + l31) * KV_LD + hi * 4];
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) {
+      f32x4 av = *(const f32x4*)(ka + kc * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], qf[kc][s], acc[t], 0, 0, 0);
+    }
+  }
+  float cm = -1e30f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = (jt0 + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      float sc = acc[t][r] + slope * (float)j;
+      sc = ((j <= i) && (j < n)) ? sc : -1e30f;
+      acc[t][r] = sc;
+      cm = fmaxf(cm, sc);
+    }
+  cm = fmaxf(cm, __shfl_xor(cm, 32));
+  const float mn = fmaxf(m, cm);
+  const float alpha = expf(m - mn);       // m = -1e30 on the first chunk: exp(-huge) = 0, and l, o are 0 anyway
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float sc = acc[t][r];
+      const float pv = sc > -1e29f ? expf(sc - mn) : 0.f;
+      acc[t][r] = pv;
+      sum += pv;
+    }
+  sum += __shfl_xor(sum, 32);
+  l = l * alpha + sum;
+  m = mn;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float* va = &Vs[((jt0 + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * KV_LD + l31];
+      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[0], acc[t][r], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32], acc[t][r], o1, 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(512) void attention_long_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float kv[];
+  const int T = a.T;
+  const int n_tiles = (T + 31) >> 5;                 // <= 8
+  float* Ks = kv;
+  float* Vs = kv + (long)n_tiles * 32 * KV_LD;
+  const int h = blockIdx.x & 3, bc = blockIdx.x >> 2, b = bc >> 1;
+  const int n = a.bn[b];
+  const int kvbc = a.swap_kv ? (bc ^ 1) : bc;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const float* kp = a.k + (long)kvbc * T * a.ldkv + h * 64;
+  const float* vp = a.v + (long)kvbc * T * a.ldkv + h * 64;
+  const int nt_valid = (n + 31) >> 5;                // key / query tiles that contain valid rows
+  // this wave's query tile (waves w and w + 4 share a SIMD: light + heavy tile)
+  const int it = w < 4 ? w : 11 - w;
+  const bool active = it < nt_valid;
+  const int i = it * 32 + l31;
+  // Q fragments first (B operand: query row i, k-slots kc*8 + 4*hi .. +3, pre-scaled by 1/16): in flight under the staging
+  f32x4 qf[8];
+  {
+    const int iq = i < n ? i : n - 1;
+    const float* qp = a.q + ((long)bc * T + iq) * a.ldq + h * 64 + hi * 4;
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) qf[kc] = *(const f32x4*)(qp + kc * 8);
+  }
+  for (int idx = tid; idx < nt_valid * 32 * 16; idx += 512) {
+    const int j = idx >> 4, q = (idx & 15) * 4;
+    f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = kk;
+    if (j < n) {
+      kk = *(const f32x4*)(kp + (long)j * a.ldkv + q);
+      vv = *(const f32x4*)(vp + (long)j * a.ldkv + q);
+    }
+    *(f32x4*)&Ks[j * KV_LD + q] = kk;
+    *(f32x4*)&Vs[j * KV_LD + q] = vv;
+  }
+#pragma unroll
+  for (int kc = 0; kc < 8; ++kc) qf[kc] *= 0.0625f;
+  __syncthreads();
+  if (it >= n_tiles) return;
+  float* op = a.out + ((long)bc * T + i) * 256 + h * 64;
+  if (!active) {                                     // whole tile beyond the valid rows: deterministic zeros
+    if (i < T) {
+#pragma unroll
+      for (int d = 0; d < 8; ++d) *(f32x4*)(op + hi * 32 + d * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    return;
+  }
+  const float slope = exp2f(-2.0f * (float)(h + 1));  // [1/4, 1/16, 1/64, 1/256]
+  float m = -1e30f, l = 0.f;
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  switch (it) {
+    case 0: attn_chunk<1>(Ks, Vs, qf, 0, i, n, l31, hi, slope, m, l, o0, o1); break;
+    case 1: attn_chunk<2>(Ks, Vs, qf, 0, i, n, l31, hi, slope, m, l, o0, o1); break;
+    case 2: attn_chunk<3>(Ks, Vs, qf, 0, i, n, l31, hi, slope, m, l, o0, o1); break;
+    default:
+      attn_chunk<4>(Ks, Vs, qf, 0, i, n, l31, hi, slope, m, l, o0, o1);
+      switch (it) {
+        case 4: attn_chunk<1>(Ks, Vs, qf, 4, i, n, l31, hi, slope, m, l, o0, o1); break;
+        case 5: attn_chunk<2>(Ks, Vs, qf, 4, i, n, l31, hi, slope, m, l, o0, o1); break;
+        case 6: attn_chunk<3>(Ks, Vs, qf, 4, i, n, l31, hi, slope, m, l, o0, o1); break;
+        case 7: attn_chunk<4>(Ks, Vs, qf, 4, i, n, l31, hi, slope, m, l, o0, o1); break;
+        default: break;
+      }
+  }
+  if (i < T) {
+    const float sc = i < n ? 1.0f / l : 0.f;           // rows beyond the valid window: deterministic zeros
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      f32x4 v0 = {o0[rr * 4 + 0], o0[rr * 4 + 1], o0[rr * 4 + 2], o0[rr * 4 + 3]};
+      f32x4 v1 = {o1[rr * 4 + 0], o1[rr * 4 + 1], o1[rr * 4 + 2], o1[rr * 4 + 3]};
+      *(f32x4*)(op + rr * 8 + hi * 4) = v0 * sc;
+      *(f32x4*)(op + 32 + rr * 8 + hi * 4) = v1 * sc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 4b. last-row path of the final layer.  Only the newest row of the last stereo layer reaches the
 //     heads (vap_main.py:316-317 takes [-1]); its K/V still need every row, but Q, the attention
 //     output, both projections and the FFN are needed for ONE row per (stream, channel).  Exact.
@@ -851,8 +997,16 @@ hipError_t launch_attention(const AttnArgs& a, int B, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)attention_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
+  static const bool gen1 = getenv("VAPX_ATTN_GEN1") != nullptr;   // A/B: the first-generation 4-wave kernel
   if (n_tiles <= 2) hipLaunchKernelGGL(attention_mfma_kernel<2>, dim3(B * 2 * 4), dim3(64 * nw), lds, st, a);
-  else if (n_tiles <= 8) hipLaunchKernelGGL(attention_mfma_kernel<8>, dim3(B * 2 * 4), dim3(64 * nw), lds, st, a);
+  else if (n_tiles <= 8 && !gen1) {
+    static bool attr3 = false;
+    if (!attr3) {
+      (void)hipFuncSetAttribute((const void*)attention_long_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr3 = true;
+    }
+    hipLaunchKernelGGL(attention_long_kernel, dim3(B * 2 * 4), dim3(512), lds, st, a);
+  } else if (n_tiles <= 8) hipLaunchKernelGGL(attention_mfma_kernel<8>, dim3(B * 2 * 4), dim3(64 * nw), lds, st, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
