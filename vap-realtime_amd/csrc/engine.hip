@@ -90,6 +90,7 @@ struct vapx_engine {
   hipEvent_t gstart = nullptr;
   int n_groups = 1;
   int ffn_tile_rows = 0;   // tuning knob (env VAPX_FFN_TILE): 32 or 64 rows per FFN-block workgroup
+  bool force_long = false;   // experiment knob (env VAPX_FORCE_LONG): short windows through the long-window kernel chain
   unsigned long long* ffn_trace = nullptr;   // env VAPX_FFN_TRACE=<file>: phase stamps of the layer-0 FFN block's workgroups
   size_t ffn_trace_wgs = 0;
   std::string ffn_trace_path;
@@ -303,7 +304,7 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
         HIPCHK(h, gemm(h, g, EPI_STORE, st));
       }
     }
-    if (T <= 64) {
+    if (T <= 64 && !h->force_long) {
       // fused: attention + output projection + residual + LayerNorm (+ cross-attention queries)
       AttnBlockArgs ab;
       memset(&ab, 0, sizeof ab);
@@ -815,6 +816,7 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
   CR(hipHostMalloc((void**)&h->audio_pinned, B * 2 * h->L * sizeof(float), hipHostMallocDefault));
   h->id_stamp.assign(S, 0u);
   if (const char* ev = getenv("VAPX_FFN_TILE")) h->ffn_tile_rows = atoi(ev);
+  if (getenv("VAPX_FORCE_LONG")) { h->force_long = true; h->cfg.flags |= VAPX_FLAG_MATERIALIZE_X0; }
   if (const char* ev = getenv("VAPX_FFN_TRACE")) {
     h->ffn_trace_path = ev;
     CR(dalloc(&h->ffn_trace, (size_t)16384 * 32));

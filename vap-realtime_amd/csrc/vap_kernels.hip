@@ -583,14 +583,14 @@ __device__ __forceinline__ void attn_chunk(const float* Ks, const float* Vs, con
     }
   cm = fmaxf(cm, __shfl_xor(cm, 32));
   const float mn = fmaxf(m, cm);
-  const float alpha = expf(m - mn);       // m = -1e30 on the first chunk: exp(-huge) = 0, and l, o are 0 anyway
+  const float alpha = __expf(m - mn);       // m = -1e30 on the first chunk: exp(-huge) = 0, and l, o are 0 anyway
   float sum = 0.f;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float sc = acc[t][r];
-      const float pv = sc > -1e29f ? expf(sc - mn) : 0.f;
+      const float pv = sc > -1e29f ? __expf(sc - mn) : 0.f;   // v_exp_f32 path: arguments <= 0, |rel err| ~1e-6
       acc[t][r] = pv;
       sum += pv;
     }
