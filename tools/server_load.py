@@ -69,7 +69,11 @@ def main():
             kind = "native front-end (vapx_ingest_*) + engine"
     cmd = [loadgen, "--port-in", str(srv.port_in), "--port-out", str(srv.port_out), "--streams", str(S), "--hz", str(args.hz),
            "--seconds", str(args.seconds), "--warm", str(args.warm), "--packet-ms", str(args.packet_ms), "--threads", str(args.client_threads)]
-    out = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=args.seconds + args.warm + 120).stdout.decode()
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE)
+    if hasattr(srv, "stats"):                       # server-side latency window = the load generator's measured window
+        time.sleep(args.warm + 1.0)
+        srv.stats(reset_latency_window=True)
+    out = proc.communicate(timeout=args.seconds + args.warm + 120)[0].decode()
     res = json.loads(out.strip().splitlines()[-1])
     res["server"] = kind
     if hasattr(srv, "stats"):

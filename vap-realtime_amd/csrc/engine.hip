@@ -90,6 +90,7 @@ struct vapx_engine {
   hipEvent_t gstart = nullptr;
   int n_groups = 1;
   int ffn_tile_rows = 0;   // tuning knob (env VAPX_FFN_TILE): 32 or 64 rows per FFN-block workgroup
+  int group0_streams = 0;    // experiment knob (env VAPX_GROUP0_STREAMS): size of the first of two overlap groups
   bool force_long = false;   // experiment knob (env VAPX_FORCE_LONG): short windows through the long-window kernel chain
   unsigned long long* ffn_trace = nullptr;   // env VAPX_FFN_TRACE=<file>: phase stamps of the layer-0 FFN block's workgroups
   size_t ffn_trace_wgs = 0;
@@ -816,6 +817,7 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
   CR(hipHostMalloc((void**)&h->audio_pinned, B * 2 * h->L * sizeof(float), hipHostMallocDefault));
   h->id_stamp.assign(S, 0u);
   if (const char* ev = getenv("VAPX_FFN_TILE")) h->ffn_tile_rows = atoi(ev);
+  if (const char* ev = getenv("VAPX_GROUP0_STREAMS")) h->group0_streams = atoi(ev);
   if (getenv("VAPX_FORCE_LONG")) { h->force_long = true; h->cfg.flags |= VAPX_FLAG_MATERIALIZE_X0; }
   if (const char* ev = getenv("VAPX_FFN_TRACE")) {
     h->ffn_trace_path = ev;
@@ -898,7 +900,12 @@ int vapx_step(vapx_handle h, int32_t n, const int32_t* stream_ids, const float* 
     for (int g = 0; g < G; ++g) HIPCHK(h, hipStreamWaitEvent(h->gstream[g], h->gstart, 0));
   }
   for (int g = 0; g < G; ++g) {
-    const int b0 = (int)((long)n * g / G), b1 = (int)((long)n * (g + 1) / G), nb = b1 - b0;
+    int b0 = (int)((long)n * g / G), b1 = (int)((long)n * (g + 1) / G);
+    if (G == 2 && h->group0_streams > 0 && h->group0_streams < n) {   // uneven split (experiment knob VAPX_GROUP0_STREAMS)
+      b0 = g == 0 ? 0 : h->group0_streams;
+      b1 = g == 0 ? h->group0_streams : n;
+    }
+    const int nb = b1 - b0;
     hipStream_t gs = G > 1 ? h->gstream[g] : st;
     const Scratch sc = h->sc.slice(b0, h->P, h->ncpc, h->T);
     const int* gids = ids ? ids + b0 : nullptr;

@@ -569,7 +569,9 @@ void tick_main(vapx_ingest* g) {
     want = std::max(1, std::min(want, std::min(connected > 0 ? connected : 1, g->max_batch)));
     const double now = mono_now();
     if ((int)pending.size() < want && now - first_ready < max_wait) continue;
-    if (now < earliest_next && (int)pending.size() < g->max_batch) {   // let the batch grow instead of the queue
+    // pacing: let the batch grow instead of the queue — but never hold a frame longer than max_wait for it (under overload
+    // the oldest frame is already older than that and ticks run back to back)
+    if (now < earliest_next && (int)pending.size() < g->max_batch && now - first_ready < max_wait) {
       std::unique_lock<std::mutex> lk(g->ready_mu);
       if (g->ready.empty()) g->ready_cv.wait_for(lk, std::chrono::microseconds((long)((earliest_next - now) * 1e6) + 1));
       continue;
