@@ -121,6 +121,7 @@ int main(int argc, char** argv) {
       q.pop();
       if (e.t >= t_end) continue;
       double n = now_s();
+      if (n - e.t > period) e.t = n;          // fell behind (blocked by back-pressure): re-base, a microphone cannot burst either
       while (n < e.t) {
         if (e.t - n > 2e-4) usleep((useconds_t)((e.t - n) * 5e5));
         n = now_s();

@@ -720,6 +720,19 @@ int vapx_ingest_open(vapx_handle engine, const vapx_ingest_config* cfg, vapx_ing
   g->engine = engine;
   g->step = engine_step; g->reset = engine_reset; g->user = g;
   g->S = ec.max_streams; g->max_batch = ec.max_batch; g->hz = ec.frame_hz; g->mode = ec.mode;
+  {  // warm the engine up before the first client connects: the first vapx_step of a process loads the code objects and sizes
+     // the runtime's pools (hundreds of ms) — paid here on silence, then every touched stream is reset
+    const int nw = ec.max_batch, hop = 16000 / ec.frame_hz;
+    float* a = (float*)vapx_host_alloc((size_t)nw * 2 * hop * sizeof(float));
+    float* o = (float*)vapx_host_alloc((size_t)nw * VAPX_OUT_STRIDE * sizeof(float));
+    if (a && o) {
+      memset(a, 0, (size_t)nw * 2 * hop * sizeof(float));
+      for (int k = 0; k < 3; ++k) (void)vapx_step(engine, nw, nullptr, a, hop, o, VAPX_AUDIO_HOST | VAPX_OUT_HOST, nullptr);
+      for (int i = 0; i < nw; ++i) (void)vapx_reset_stream(engine, i);
+    }
+    vapx_host_free(a);
+    vapx_host_free(o);
+  }
   rc = open_common(g, cfg);
   if (rc != VAPX_OK) { vapx_ingest_close(g); return rc; }
   *out = g;
