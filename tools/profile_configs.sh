@@ -1,17 +1,18 @@
 #!/bin/bash
 # rocprofv3 evidence for one bench workload: kernel-trace stats + PMC passes (each counter group in its own run, as
 # MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE cannot share a pass).  Usage (on the GPU box, repo root):
-#   tools/profile_configs.sh <workload: c2|s4096_20hz|c3|c5> <tag> [steps]
+#   tools/profile_configs.sh <workload: c2|s4096_20hz|c3|c5> <tag> [steps] [extra bench args] [output suffix]
 # Keeps only the small summaries (the raw per-dispatch CSVs are hundreds of MB) under gpurun_out/prof_<tag>_<workload>/:
 #   bench.json, kernel_stats.csv, pmc_sq.txt, pmc_mops.txt, pmc_fetch.txt, pmc_write.txt   (means per dispatch, per kernel)
 set -u
-WL=$1; TAG=$2; STEPS=${3:-4}
+WL=$1; TAG=$2; STEPS=${3:-4}; EXTRA=${4:-}
 REPO=$PWD
-OUT=$REPO/gpurun_out/prof_${TAG}_${WL}
+SUF=${5:-}
+OUT=$REPO/gpurun_out/prof_${TAG}_${WL}${SUF}
 RAW=/tmp/prof_raw_$$
 mkdir -p $OUT $RAW
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --workload $WL --configs= --no-latency --no-cpu-baseline --paced-sec 0 --steps $STEPS --warmup 1"
+BENCH="python $REPO/bench.py --workload $WL --configs= --no-latency --no-cpu-baseline --paced-sec 0 --steps $STEPS --warmup 1 $EXTRA"
 $BENCH > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -f csv -d $RAW/stats -o run -- $BENCH > $OUT/stats.log 2>&1
 cp $(find $RAW/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
