@@ -100,7 +100,7 @@ int main(int argc, char** argv) {
   usleep(300000);
 
   std::atomic<bool> stop{false};
-  std::atomic<long> frames_sent{0}, frames_answered{0}, late{0};
+  std::atomic<long> frames_sent{0}, frames_answered{0}, late{0}, slipped{0};
   std::mutex lat_mu;
   std::vector<float> lats;
   lats.reserve((size_t)(S * hz * seconds * 1.1));
@@ -121,7 +121,7 @@ int main(int argc, char** argv) {
       q.pop();
       if (e.t >= t_end) continue;
       double n = now_s();
-      if (n - e.t > period) e.t = n;          // fell behind (blocked by back-pressure): re-base, a microphone cannot burst either
+      if (n - e.t > 0.5 * period / packets_per_frame + 2e-3) { e.t = n; slipped.fetch_add(1); }   // fell behind: re-base — a microphone cannot burst either
       while (n < e.t) {
         if (e.t - n > 2e-4) usleep((useconds_t)((e.t - n) * 5e5));
         n = now_s();
@@ -206,9 +206,9 @@ int main(int argc, char** argv) {
   for (auto& s : st) unanswered += (long)s.sent.size();
   printf("{\"streams\": %d, \"frame_hz\": %d, \"packet_ms\": %d, \"seconds_measured\": %.1f, \"frames_sent\": %ld, \"frames_answered\": %ld, "
          "\"unanswered_at_end\": %ld, \"latency_samples\": %zu, \"lat_p50_ms\": %.3f, \"lat_p99_ms\": %.3f, \"lat_p999_ms\": %.3f, \"lat_max_ms\": %.3f, "
-         "\"late_over_%.0fms\": %ld, \"stream_frames_per_s\": %.1f}\n",
+         "\"late_over_%.0fms\": %ld, \"schedule_slips\": %ld, \"stream_frames_per_s\": %.1f}\n",
          S, hz, packet_ms, seconds, frames_sent.load(), frames_answered.load(), unanswered, lats.size(), pct(0.50), pct(0.99), pct(0.999),
-         lats.empty() ? 0.0 : (double)lats.back(), late_ms, late.load(), lats.size() / seconds);
+         lats.empty() ? 0.0 : (double)lats.back(), late_ms, late.load(), slipped.load(), lats.size() / seconds);
   for (auto& s : st) { close(s.fd_in); close(s.fd_out); }
   return 0;
 }

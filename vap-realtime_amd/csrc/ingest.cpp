@@ -8,8 +8,8 @@
 //   tick thread             batches the ready frames (ragged), vapx_step (host in / host out), hands rows to the senders
 //   tx threads              encode header / tail, sendmsg() with the echo arrays as iovecs (no copy), free the frame buffer
 //
-// Every stream owns NBUF frame buffers (filling / waiting / in flight / being sent), so reception never waits for the GPU
-// unless a sender outruns the engine by two whole frames; then the connection is paused (TCP back-pressure), never dropped.
+// Every stream owns NBUF frame buffers (filling / waiting / in flight / being sent + slack), so reception never waits for the GPU
+// unless a sender outruns the engine by four whole frames; then the connection is paused (TCP back-pressure), never dropped.
 #include <arpa/inet.h>
 #include <errno.h>
 #include <fcntl.h>
@@ -39,7 +39,7 @@
 
 namespace {
 
-constexpr int NBUF = 3;
+constexpr int NBUF = 5;   // frame buffers per stream: filling + waiting + in flight + two of slack for a client that bursts after a stall
 constexpr int PAIR_BYTES = 16;                 // one sample of both channels: f64 ch1, f64 ch2 (util.py:52-62)
 enum BufState : int { B_FREE = 0, B_FILLING = 1, B_READY = 2, B_INFLIGHT = 3 };
 
@@ -121,7 +121,7 @@ struct Slot {
   int fd_in = -1;
   uint32_t gen = 0;                       // bumped per connection: queued frames of a dead connection are dropped
   std::atomic<int> state[NBUF];
-  double t_ready[NBUF] = {0, 0, 0};
+  double t_ready[NBUF] = {};
   int wbuf = -1, fill = 0;                // rx thread only
   uint8_t partial[PAIR_BYTES]; int npartial = 0;
   std::vector<uint8_t> backlog;           // bytes received while no buffer was free
