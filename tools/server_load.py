@@ -70,14 +70,17 @@ def main():
     cmd = [loadgen, "--port-in", str(srv.port_in), "--port-out", str(srv.port_out), "--streams", str(S), "--hz", str(args.hz),
            "--seconds", str(args.seconds), "--warm", str(args.warm), "--packet-ms", str(args.packet_ms), "--threads", str(args.client_threads)]
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE)
+    base = {}
     if hasattr(srv, "stats"):                       # server-side latency window = the load generator's measured window
         time.sleep(args.warm + 1.0)
-        srv.stats(reset_latency_window=True)
+        base = srv.stats(reset_latency_window=True)
     out = proc.communicate(timeout=args.seconds + args.warm + 120)[0].decode()
     res = json.loads(out.strip().splitlines()[-1])
     res["server"] = kind
     if hasattr(srv, "stats"):
-        res["server_stats"] = srv.stats()
+        st = srv.stats()
+        res["server_stats"] = st
+        res["server_window"] = {k: st[k] - base.get(k, 0) for k in ("frames_done", "ticks", "overruns", "dropped_listeners", "numeric_resets")}
     res["realtime_streams_served"] = res["stream_frames_per_s"] / args.hz
     srv.stop()
     print(json.dumps(res))
