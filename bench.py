@@ -558,6 +558,7 @@ def main():
                 os.sched_setaffinity(0, range(os.cpu_count() or 1))   # the workers must not inherit this rank's core pinning
             except Exception:
                 pass
+            os.environ["OMP_NUM_THREADS"] = os.environ["MKL_NUM_THREADS"] = "1"    # inherited by the workers: one thread each, really
             with mp.get_context("spawn").Pool(P) as pool:
                 res = pool.map(_cpu_worker, [(i, hz, ctx_sec, 8.0) for i in range(P)], chunksize=1)
             agg = sum(n_ / dt_ for n_, dt_ in res)

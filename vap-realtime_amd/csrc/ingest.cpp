@@ -169,8 +169,12 @@ struct vapx_ingest {
   std::thread tick_thread;
   std::atomic<bool> stop{false};
 
-  std::mutex slots_mu;                     // slot allocation, out_all
+  std::mutex slots_mu;                     // slot allocation, out_all, listener bookkeeping
   std::vector<int> out_all;                // broadcast listeners
+  std::vector<int> lcount;                 // listeners per slot (under slots_mu)
+  int lmin = 0, lcursor = 0;               // fewest listeners on any slot; lowest slot that may still have that few
+  int ep_accept = -1;                      // the accept thread's epoll (listen sockets only)
+  std::thread accept_thread;
   std::mutex ready_mu;
   std::condition_variable ready_cv;
   std::vector<Ready> ready;                // rx -> tick
@@ -431,14 +435,38 @@ void accept_out(vapx_ingest* g) {
     g->out_conns.fetch_add(1);
     std::lock_guard<std::mutex> lk(g->slots_mu);
     if (g->broadcast) { g->out_all.push_back(fd); continue; }
-    int best = 0;
-    size_t bl = (size_t)-1;
-    for (int i = 0; i < g->S; ++i) {
-      std::lock_guard<std::mutex> l2(g->slots[i].lmu);
-      if (g->slots[i].listeners.size() < bl) { bl = g->slots[i].listeners.size(); best = i; if (bl == 0) break; }
+    // the stream with the fewest listeners, lowest index first (the k-th output connection hears the k-th stream); amortised
+    // O(1): a cursor walks the slots that still have `lmin` listeners and wraps with lmin + 1
+    int best = -1;
+    for (int pass = 0; pass < 2 && best < 0; ++pass) {
+      for (int i = g->lcursor; i < g->S; ++i)
+        if (g->lcount[i] == g->lmin) { best = i; break; }
+      if (best < 0) { ++g->lmin; g->lcursor = 0; }
     }
+    if (best < 0) best = 0;
+    g->lcursor = best + 1;
+    ++g->lcount[best];
     std::lock_guard<std::mutex> l2(g->slots[best].lmu);
     g->slots[best].listeners.push_back(fd);
+  }
+}
+
+// a dropped listener lowers its slot's count: the next output connection goes there first
+void listener_dropped(vapx_ingest* g, int slot) {
+  std::lock_guard<std::mutex> lk(g->slots_mu);
+  if (--g->lcount[slot] < g->lmin) { g->lmin = g->lcount[slot]; g->lcursor = slot; }
+  else if (g->lcount[slot] == g->lmin && slot < g->lcursor) g->lcursor = slot;
+}
+
+void accept_main(vapx_ingest* g) {
+  epoll_event evs[8];
+  while (!g->stop.load()) {
+    int n = epoll_wait(g->ep_accept, evs, 8, 100);
+    for (int i = 0; i < n; ++i) {
+      const uint64_t kind = evs[i].data.u64 & ~0xffffffffull;
+      if (kind == K_LISTEN_IN) accept_in(g);
+      else if (kind == K_LISTEN_OUT) accept_out(g);
+    }
   }
 }
 
@@ -449,9 +477,7 @@ void rx_main(vapx_ingest* g, int r) {
     int n = epoll_wait(g->ep[r], evs, 256, 100);
     for (int i = 0; i < n; ++i) {
       const uint64_t tag = evs[i].data.u64, kind = tag & ~0xffffffffull;
-      if (kind == K_LISTEN_IN) accept_in(g);
-      else if (kind == K_LISTEN_OUT) accept_out(g);
-      else if (kind == K_WAKE) {
+      if (kind == K_WAKE) {
         uint64_t v;
         ssize_t rr = read(g->wake[r], &v, 8);
         (void)rr;
@@ -520,7 +546,16 @@ void tx_main(vapx_ingest* g) {
           }
         };
         if (g->broadcast) { std::lock_guard<std::mutex> lk(g->slots_mu); send_to(g->out_all); }
-        else { std::lock_guard<std::mutex> lk(s.lmu); send_to(s.listeners); }
+        else {
+          size_t gone = 0;
+          {
+            std::lock_guard<std::mutex> lk(s.lmu);
+            const size_t before = s.listeners.size();
+            send_to(s.listeners);
+            gone = before - s.listeners.size();
+          }
+          for (size_t d = 0; d < gone; ++d) listener_dropped(g, rd.slot);   // (slots_mu is never taken under a slot's lmu here)
+        }
         g->lat.add(mono_now() - rd.t);
       }
       release_buf(g, rd.slot, rd.buf);
@@ -684,8 +719,11 @@ int open_common(vapx_ingest* g, const vapx_ingest_config* cfg) {
     g->wake.push_back(eventfd(0, EFD_NONBLOCK));
     ep_add(g->ep[r], g->wake[r], K_WAKE);
   }
-  ep_add(g->ep[0], g->lin, K_LISTEN_IN);
-  ep_add(g->ep[0], g->lout, K_LISTEN_OUT);
+  g->lcount.assign(g->S, 0);
+  g->ep_accept = epoll_create1(0);          // own thread: a connect storm must not starve the streams of a receive thread
+  ep_add(g->ep_accept, g->lin, K_LISTEN_IN);
+  ep_add(g->ep_accept, g->lout, K_LISTEN_OUT);
+  g->accept_thread = std::thread(accept_main, g);
   for (int r = 0; r < g->R; ++r) g->rx_threads.emplace_back(rx_main, g, r);
   for (int x = 0; x < g->X; ++x) g->tx_threads.emplace_back(tx_main, g);
   g->tick_thread = std::thread(tick_main, g);
@@ -776,6 +814,8 @@ void vapx_ingest_close(vapx_ingest_handle g) {
   g->job_cv.notify_all();
   g->job_done_cv.notify_all();
   for (int fd : g->wake) kick(fd);
+  if (g->accept_thread.joinable()) g->accept_thread.join();
+  if (g->ep_accept >= 0) close(g->ep_accept);
   for (auto& t : g->rx_threads) if (t.joinable()) t.join();
   if (g->tick_thread.joinable()) g->tick_thread.join();
   g->job_cv.notify_all();
