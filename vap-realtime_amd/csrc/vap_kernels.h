@@ -60,6 +60,9 @@ struct AttnArgs {
   float* out;           // [B*2*T][256]
   const int* bn;
   int T, ldq, ldkv, swap_kv;
+  const int* ring_rot;  // [B] or null.  Non-null (long-window layer 0): q/k/v are the per-stream Q|K|V RINGS (slab = slot*2+channel,
+                        // logical row i in ring slot (i + ring_rot[b]) % T) instead of chronological batch buffers
+  const int* ids;       // [B] stream slots (null: identity); only used with ring_rot
 };
 
 struct LastRowArgs {

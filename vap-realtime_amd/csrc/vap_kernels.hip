@@ -690,6 +690,134 @@ __global__ __launch_bounds__(512) void attention_long_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// 4a'. long windows, third generation: TWO workgroups per CU so that one workgroup's V staging / Q loads / output stores
+//      hide behind the other's MFMAs.  Only V sits in LDS (64 KB for 256 keys, unpadded: its reads are lane-consecutive);
+//      K fragments come straight from global / L2 as the MFMA A operand (as in attn_block_kernel), double-buffered one key
+//      tile ahead; the softmax is online per 32-key tile, so one score accumulator is live (~190 registers).  Four waves,
+//      each takes query tiles w and 7 - w (9 causal key tiles per wave: balanced).  Optional ring addressing lets layer 0
+//      read the per-stream Q|K|V rings in place (no chronological gather for long windows either).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attention_long2_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float Vs[];   // [n_tiles * 32][64]
+  const int T = a.T;
+  const int n_tiles = (T + 31) >> 5;                 // <= 8
+  const int h = blockIdx.x & 3, bc = blockIdx.x >> 2, b = bc >> 1;
+  const int n = a.bn[b];
+  const int kvbc = a.swap_kv ? (bc ^ 1) : bc;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const bool ringed = a.ring_rot != nullptr;
+  const int rot = ringed ? a.ring_rot[b] : 0;
+  const long slab_q = ringed ? ((long)(a.ids ? a.ids[b] : b) * 2 + (bc & 1)) : (long)bc;
+  const long slab_kv = ringed ? slab_q : (long)kvbc;
+  auto prow = [&](int i) { int r = i + rot; return r >= T ? r - T : r; };
+  const float* kp = a.k + slab_kv * T * a.ldkv + h * 64;
+  const float* vp = a.v + slab_kv * T * a.ldkv + h * 64;
+  const int nt_valid = (n + 31) >> 5;
+  for (int idx = tid; idx < nt_valid * 32 * 16; idx += 256) {
+    const int j = idx >> 4, q = (idx & 15) * 4;
+    f32x4 vv = {0.f, 0.f, 0.f, 0.f};
+    if (j < n) vv = *(const f32x4*)(vp + (long)prow(j) * a.ldkv + q);
+    *(f32x4*)&Vs[j * 64 + q] = vv;
+  }
+  __syncthreads();
+  const float slope = exp2f(-2.0f * (float)(h + 1));  // [1/4, 1/16, 1/64, 1/256]
+  auto load_k = [&](f32x4 (&kf)[8], int jt) {          // A operand of S^T = K.Q^T: key row jt*32 + l31, k-slots kc*8 + 4*hi ..+3
+    int j = jt * 32 + l31;
+    j = j < n ? j : n - 1;                             // rows beyond the window: clamped, masked below
+    const float* kr = kp + (long)prow(j) * a.ldkv + hi * 4;
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) kf[kc] = *(const f32x4*)(kr + kc * 8);
+  };
+  for (int pass = 0; pass < 2; ++pass) {
+    const int it = pass == 0 ? w : 7 - w;
+    if (it >= n_tiles) continue;
+    const int i = it * 32 + l31;
+    float* op = a.out + ((long)bc * T + i) * 256 + h * 64;
+    if (it >= nt_valid) {                              // whole tile beyond the valid rows: deterministic zeros
+      if (i < T) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) *(f32x4*)(op + hi * 32 + d * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      continue;
+    }
+    f32x4 qf[8], kfa[8], kfb[8];
+    {
+      const int iq = i < n ? i : n - 1;
+      const float* qp = a.q + (slab_q * T + prow(iq)) * a.ldq + h * 64 + hi * 4;
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc) qf[kc] = *(const f32x4*)(qp + kc * 8);
+    }
+    load_k(kfa, 0);
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) qf[kc] *= 0.0625f;
+    float m = -1e30f, l = 0.f;
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    auto tile = [&](const f32x4 (&kf)[8], int jt) {     // one 32-key tile: scores, online softmax update, P.V
+      f32x16 sc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[kc][s], qf[kc][s], sc, 0, 0, 0);
+      float cm = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float v = sc[r] + slope * (float)j;
+        v = ((j <= i) && (j < n)) ? v : -1e30f;
+        sc[r] = v;
+        cm = fmaxf(cm, v);
+      }
+      cm = fmaxf(cm, __shfl_xor(cm, 32));
+      const float mn = fmaxf(m, cm);
+      const float alpha = __expf(m - mn);
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = sc[r] > -1e29f ? __expf(sc[r] - mn) : 0.f;
+        sc[r] = pv;
+        sum += pv;
+      }
+      sum += __shfl_xor(sum, 32);
+      l = l * alpha + sum;
+      m = mn;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float* va = &Vs[(jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + l31];
+        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[0], sc[r], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32], sc[r], o1, 0, 0, 0);
+      }
+    };
+#pragma unroll 1
+    for (int jt = 0; jt <= it; jt += 2) {               // K fragments ping-pong one tile ahead of their use
+      if (jt + 1 <= it) load_k(kfb, jt + 1);
+      tile(kfa, jt);
+      if (jt + 1 <= it) {
+        if (jt + 2 <= it) load_k(kfa, jt + 2);
+        tile(kfb, jt + 1);
+      }
+    }
+    if (i < T) {
+      const float scl = i < n ? 1.0f / l : 0.f;         // rows beyond the valid window: deterministic zeros
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        f32x4 v0 = {o0[rr * 4 + 0], o0[rr * 4 + 1], o0[rr * 4 + 2], o0[rr * 4 + 3]};
+        f32x4 v1 = {o1[rr * 4 + 0], o1[rr * 4 + 1], o1[rr * 4 + 2], o1[rr * 4 + 3]};
+        *(f32x4*)(op + rr * 8 + hi * 4) = v0 * scl;
+        *(f32x4*)(op + 32 + rr * 8 + hi * 4) = v1 * scl;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 4b. last-row path of the final layer.  Only the newest row of the last stereo layer reaches the
 //     heads (vap_main.py:316-317 takes [-1]); its K/V still need every row, but Q, the attention
 //     output, both projections and the FFN are needed for ONE row per (stream, channel).  Exact.
@@ -998,6 +1126,16 @@ hipError_t launch_attention(const AttnArgs& a, int B, hipStream_t st) {
     attr_set = true;
   }
   static const bool gen1 = getenv("VAPX_ATTN_GEN1") != nullptr;   // A/B: the first-generation 4-wave kernel
+  static const bool gen2 = getenv("VAPX_ATTN_GEN2") != nullptr;   // A/B: the 8-wave, K+V-in-LDS kernel
+  if ((a.ring_rot && n_tiles <= 8) || (n_tiles > 2 && n_tiles <= 8 && !gen1 && !gen2)) {
+    static bool attr4 = false;
+    if (!attr4) {
+      (void)hipFuncSetAttribute((const void*)attention_long2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      attr4 = true;
+    }
+    hipLaunchKernelGGL(attention_long2_kernel, dim3(B * 2 * 4), dim3(256), (size_t)n_tiles * 32 * 64 * sizeof(float), st, a);
+    return hipGetLastError();
+  }
   if (n_tiles <= 2) hipLaunchKernelGGL(attention_mfma_kernel<2>, dim3(B * 2 * 4), dim3(64 * nw), lds, st, a);
   else if (n_tiles <= 8 && !gen1) {
     static bool attr3 = false;
