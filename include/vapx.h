@@ -69,8 +69,8 @@ extern "C" {
 
 /* vapx_config.flags */
 #define VAPX_FLAG_GROUPS_MASK 0xF     /* bits 0-3: intra-tick overlap groups (0 = default 1 = none, max 8) */
-#define VAPX_FLAG_MATERIALIZE_X0 64   /* copy the context window chronologically each tick ("x0" peekable); default for T <= 64:
-                                         layer 0 reads the rings in place */
+#define VAPX_FLAG_MATERIALIZE_X0 64   /* copy the context window chronologically each tick ("x0" peekable); default: layer 0 reads
+                                         the embedding / Q|K|V rings in place (short and long windows alike) */
 #define VAPX_FLAG_SPLIT_F16 512        /* opt-in: the FFN block's contractions as fp32-accurate 3-term split products on the f16
                                          matrix cores (x = hi + lo; hi.hi + lo.hi + hi.lo, fp32 accumulate); default: fp32 MFMA */
 #define VAPX_FLAG_UNFUSED_PROJ 1024    /* long windows (T > 64): attention output projections (+ residual + LN, + cross-attention query

@@ -297,6 +297,7 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
     float* xout = sc.xl[l + 1];
     GemmArgs g;
     const float *pre_att = nullptr, *pre_w = nullptr, *pre_resid = nullptr;   // long window: projection fused into the FFN block
+    bool pre_ring = false;
     if (l == l_begin && !(l == 0 && qkv0_ready)) {
       g = gemm_args(sc.xn, r256, Lw.wqkv, M, 768, 256, sc.qkv, r768);
       HIPCHK(h, gemm(h, g, EPI_STORE, st));
@@ -329,8 +330,14 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
     } else if (!(h->cfg.flags & (VAPX_FLAG_UNFUSED_PROJ | VAPX_FLAG_SPLIT_F16))) {
       // long window: plain attention kernels; every projection rides in a fused flat-row block (no [rows x 256] GEMM launches)
       AttnArgs aa{sc.qkv, sc.qkv + 256, sc.qkv + 512, sc.att, sc.bn, T, 768, 768, 0};
+      const bool ring0 = l == 0 && rv && rv->ring;
+      if (ring0) {   // Q|K|V straight from the per-stream rings (no chronological gather)
+        aa.q = rv->ring_qkv; aa.k = rv->ring_qkv + 256; aa.v = rv->ring_qkv + 512;
+        aa.ring_rot = sc.rot; aa.ids = rv->ids;
+      }
       { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attention(aa, B, st)); }
-      pre_att = sc.att; pre_w = Lw.wprojf; pre_resid = xin;
+      pre_att = sc.att; pre_w = Lw.wprojf; pre_resid = ring0 ? rv->ring : xin;
+      pre_ring = ring0;
       if (l > 0) {
         // self half: xmid = xin + att.Wproj^T ; qx = LN_src(xmid).Wq_x^T
         FfnArgs fp;
@@ -368,6 +375,7 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
     memset(&fa, 0, sizeof fa);
     fa.xmid = sc.xmid; fa.lnf_g = Lw.ln_ffn_g; fa.lnf_b = Lw.ln_ffn_b; fa.xout = xout; fa.M = M;
     if (pre_att) { fa.mode = 1; fa.att = pre_att; fa.wprojf = pre_w; fa.resid = pre_resid; fa.xmid_out = sc.xmid; }
+    if (pre_ring) { fa.resid_rot = sc.rot; fa.resid_ids = rv->ids; fa.resid_T = T; }
     fa.w0f = split ? Lw.w0h : Lw.w0f; fa.w3f = split ? Lw.w3h : Lw.w3f;
     fa.tile_rows = h->ffn_tile_rows ? h->ffn_tile_rows : (split ? 0 : 32);
     if (l + 1 < l_end) {
@@ -638,7 +646,10 @@ int step_group(vapx_engine* h, const Scratch& sc_own, int nb, int b0, const int*
   ga.e = sc.e; ga.xin = nullptr; ga.ids = ids; ga.bn = sc.bn; ga.bhead = sc.bhead;
   ga.x0 = sc.xl[0]; ga.xn = sc.xn; ga.gamma = h->layer[0].ln_self_g; ga.beta = h->layer[0].ln_self_b;
   ga.B = nb; ga.T = h->T; ga.rows_in = 0;
-  const bool ring_direct = h->T <= 64 && !(h->cfg.flags & VAPX_FLAG_MATERIALIZE_X0);
+  // layer 0 reads the rings in place (no chronological copy): always for the fused short-window block, and for long windows
+  // when they run the fused long-window chain (the GEMM-chain variants need x0 as a plain buffer)
+  const bool ring_direct = !(h->cfg.flags & VAPX_FLAG_MATERIALIZE_X0) &&
+                           (h->T <= 64 || !(h->cfg.flags & (VAPX_FLAG_UNFUSED_PROJ | VAPX_FLAG_SPLIT_F16)));
   ga.rot = sc.rot;
   if (ring_direct) { ProfScope ps(h, CLS_GATHER, st); HIPCHK(h, launch_ring_append(ga, st)); }
   else { ProfScope ps(h, CLS_GATHER, st); HIPCHK(h, launch_gather_ln(ga, st)); }
@@ -1176,7 +1187,7 @@ int64_t vapx_peek(vapx_handle h, const char* name, float* dst, size_t max_floats
   else if (!strcmp(name, "lstm_out")) { src = h->sc.lstm_out; n = B * 2 * h->ncpc * 256; }
   else if (!strcmp(name, "e")) { src = h->sc.e; n = B * 2 * 256; }
   else if (!strcmp(name, "x0")) {
-    if (h->T <= 64 && !(h->cfg.flags & VAPX_FLAG_MATERIALIZE_X0))
+    if (!(h->cfg.flags & VAPX_FLAG_MATERIALIZE_X0) && (h->T <= 64 || !(h->cfg.flags & (VAPX_FLAG_UNFUSED_PROJ | VAPX_FLAG_SPLIT_F16))))
       return fail(h, VAPX_E_INVAL, "\"x0\" is read straight from the ring; create the engine with VAPX_FLAG_MATERIALIZE_X0 to peek it");
     src = h->sc.xl[0]; n = B * 2 * T * 256;
   }

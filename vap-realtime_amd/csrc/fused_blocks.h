@@ -30,6 +30,11 @@ struct FfnArgs {
   const float* wprojf; // output projection, fragment-major
   const float* resid;  // [M][256]
   float* xmid_out;     // [M][256]
+  // mode 1 on layer 0 of a long window: `resid` is the per-stream embedding RING (slab = slot*2+channel, logical row i of the
+  // window in ring slot (i + resid_rot[b]) % resid_T) instead of a chronological [M][256] buffer
+  const int* resid_rot; // [B] or null
+  const int* resid_ids; // [B] stream slots (null: identity)
+  int resid_T;
 };
 
 struct AttnBlockArgs {

@@ -243,6 +243,23 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
     // ---- attention output projection + residual: xmid = resid + att . Wproj^T (the separate GEMM of the long-window path) ----
     zero(out);
     mm(out, sH, g.wprojf, MODE == 1 ? g.w0f : after_ffn);
+    if (MODE == 1 && g.resid_rot) {   // layer 0: residual rows straight from the embedding ring
+      const int T = g.resid_T;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          m = m < g.M ? m : g.M - 1;
+          const int bc = m / T, i = m - bc * T, b = bc >> 1;
+          const long slab = (long)(g.resid_ids ? g.resid_ids[b] : b) * 2 + (bc & 1);
+          int rr = i + g.resid_rot[b];
+          rr = rr >= T ? rr - T : rr;
+          const float* rp = g.resid + (slab * T + rr) * 256 + ccol;
+          out[mt][0][r] += rp[0];
+          out[mt][1][r] += rp[32];
+        }
+    } else
     add_rows(out, g.resid);
     store_global(out, g.xmid_out, 256, 0);
     if constexpr (MODE == 1) ln_rows(out, g.lnf_g, g.lnf_b, sX, nullptr);   // A operand of FFN1
