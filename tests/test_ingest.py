@@ -257,3 +257,58 @@ def test_connection_burst_and_reconnect_reuse_slots():
         for s in ins + outs:
             s.close()
         srv.close()
+
+
+def test_random_segmentation_and_reconnects_keep_every_stream_exact():
+    """Property test of the frame assembler: 24 streams send their audio cut at random byte positions (sample pairs split across
+    sends, several frames in one send), some hang up mid-frame and a new client takes the slot — every answered frame must echo
+    exactly the samples of ONE frame of ONE connection, in order, and carry that frame's numbers."""
+    hop, S, F_ = 320, 24, 7            # 50 Hz frames: more frames per byte
+    rng = np.random.default_rng(11)
+    m = Model()
+    srv = ingest.NativeServer.over_function(m.step, S, 50, reset=m.reset, max_wait_s=0.002)
+    try:
+        ins = [socket.create_connection(("127.0.0.1", srv.port_in)) for _ in range(S)]
+        _wait(lambda: srv.stats()["in_connections"] == S)
+        outs = [socket.create_connection(("127.0.0.1", srv.port_out)) for _ in range(S)]
+        _wait(lambda: srv.stats()["out_connections"] == S)
+        audio = rng.standard_normal((S, 2, hop * F_))
+        blobs = [wire.encode_input(audio[s, 0], audio[s, 1]) for s in range(S)]
+        pos = [0] * S
+        expect = [list(range(F_)) for _ in range(S)]           # frame indices each listener must see, in order
+        quitter = {5: 3 * hop * 16 + 100, 17: 1 * hop * 16 + 7}  # these hang up mid-frame (after 3 / 1 complete frames)
+        live = set(range(S))
+        while live:
+            for s in list(live):
+                limit = quitter.get(s, len(blobs[s]))
+                n = int(rng.choice([1, 7, 16, 333, 2560, 5000, 20000]))
+                n = min(n, limit - pos[s])
+                ins[s].sendall(blobs[s][pos[s]:pos[s] + n])
+                pos[s] += n
+                if pos[s] >= limit:
+                    live.discard(s)
+        for s, cut in quitter.items():
+            expect[s] = list(range(cut // (hop * 16)))
+        for s in range(S):
+            for f in expect[s]:
+                _, r = _read_result(outs[s])
+                np.testing.assert_array_equal(r["x1"], audio[s, 0, f * hop:(f + 1) * hop])
+                np.testing.assert_array_equal(r["x2"], audio[s, 1, f * hop:(f + 1) * hop])
+                want = np.abs(audio[s, :, f * hop:(f + 1) * hop].astype(np.float32)).mean(axis=1)
+                np.testing.assert_allclose(r["p_now"], want, rtol=1e-6)
+        # the quitters' partial frames vanish with the connection; a new client on the slot starts on a frame boundary
+        for s in quitter:
+            ins[s].close()
+        _wait(lambda: srv.stats()["in_connections"] == S - len(quitter))
+        for s in sorted(quitter):
+            ins[s] = socket.create_connection(("127.0.0.1", srv.port_in))       # lowest free slot first: 5, then 17
+            _wait(lambda: srv.stats()["in_connections"] >= S - len(quitter) + 1 + sorted(quitter).index(s))
+            fresh = rng.standard_normal((2, hop))
+            ins[s].sendall(wire.encode_input(fresh[0], fresh[1]))
+            _, r = _read_result(outs[s])
+            np.testing.assert_array_equal(r["x1"], fresh[0])
+        assert srv.stats()["frames_done"] == sum(len(e) for e in expect) + len(quitter)
+    finally:
+        for c in ins + outs:
+            c.close()
+        srv.close()
