@@ -506,3 +506,35 @@ def test_mid_length_windows_against_the_oracle(hz, ctx):
     print(f"T={T} @ {hz} Hz: worst |hip - oracle| = {worst:.2e}")
     assert worst <= TOL
     eng.close()
+
+
+@pytest.mark.parametrize("mode,hz,ctx", [("nod", 10, 10.0), ("bc", 20, 5.0)])
+def test_published_bc_and_nod_settings_against_the_oracle(mode, hz, ctx):
+    """The reference's README settings for the fine-tuned heads — vap_bc_main at 20 Hz / 5 s and vap_nod_main at 10 Hz / 10 s,
+    both T = 100 — run the long-window kernels; nod additionally runs the FULL last layer and emits p_bc for every window row
+    (vap_nod_main.py:276)."""
+    from oracle.vap_oracle import ServerFramer, VapOracle
+    from vap_realtime_amd import engine, synth, weights as W
+    cpc, vap = W.synthetic_weights(17, hz, mode)
+    o = VapOracle(cpc, vap, hz, ctx, mode=mode)
+    T, hop = int(ctx * hz), 16000 // hz
+    S, F_ = 2, T + 6
+    audio = synth.dialogue_batch([80, 81], hop * F_)
+    st, fr = o.new_state(S), ServerFramer(S, hop)
+    eng = engine.Engine(W.pack_blob(cpc, vap, mode), hz, ctx, max_streams=S, mode=mode)
+    worst = 0.0
+    for f in range(F_):
+        new = audio[:, :, f * hop:(f + 1) * hop]
+        want = o.step(fr.frame(new), st)
+        got = engine.split_outputs(eng.step(new))
+        n = min(f + 1, T)
+        worst = max(worst, float(np.abs(got["vad"] - want["vad"]).max()))
+        if mode == "bc":
+            worst = max(worst, float(np.abs(got["aux"][:, 1] - want["p_bc_react"]).max()), float(np.abs(got["aux"][:, 2] - want["p_bc_emo"]).max()))
+        else:
+            for k, col in (("p_nod_short", 1), ("p_nod_long", 2), ("p_nod_long_p", 3)):
+                worst = max(worst, float(np.abs(got["aux"][:, col] - want[k]).max()))
+            worst = max(worst, float(np.abs(got["logits"][:, :n] - want["p_bc"][:, :n]).max()))
+    print(f"{mode} T={T} @ {hz} Hz: worst |hip - oracle| = {worst:.2e}")
+    assert worst <= TOL
+    eng.close()
