@@ -262,3 +262,51 @@ def test_native_tcp_front_end_end_to_end_on_gpu(name):
     finally:
         srv.close()
         eng.close()
+
+
+def test_library_twin_vap_class_with_microphone_sources(tmp_path):
+    """``Vap(mode, frame_rate, context_len_sec, language, mic1, mic2, ..., cpc_model=..., device=...)`` as in
+    vap_realtime/model.py:15-257: checkpoint found by the reference's file name in a local directory, ``start_process()`` runs the
+    worker that pulls 160-sample chunks from two microphone-like objects, ``get_result()`` blocks for one dict per frame."""
+    import queue
+    import torch
+    from vap_realtime_amd import checkpoints as ck
+    from vap_realtime_amd.realtime import Vap
+    c = Case("vap20")
+    _, fname = ck.checkpoint_name("vap", c.frame_hz, c.ctx_sec, "jp")
+    (tmp_path / "asset" / "vap").mkdir(parents=True)
+    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in c.vap_sd.items()}, tmp_path / "asset" / "vap" / fname)
+    cpc_p = tmp_path / "cpc.pt"
+    torch.save({"weights": {k: torch.from_numpy(np.asarray(v)) for k, v in c.cpc_sd.items()}}, cpc_p)
+
+    class Mic:                                   # stands in for vap_realtime.input.Mic / Wav (out of scope): 160 samples per call
+        def __init__(self, x):
+            self.q = queue.Queue()
+            for k in range(0, len(x), 160):
+                self.q.put(x[k:k + 160].astype(np.float64))
+            self.started = False
+
+        def start_process(self):
+            self.started = True
+
+        def get_audio_data(self):
+            try:
+                return self.q.get(timeout=5)
+            except queue.Empty:
+                return None
+
+    n = 12
+    audio = c.audio[0, :, :c.hop * n]
+    vap = Vap("vap", c.frame_hz, c.ctx_sec, "jp", Mic(audio[0]), Mic(audio[1]), cpc_model=str(cpc_p), device="cuda",
+              search_dirs=[str(tmp_path)])
+    with pytest.raises(Exception, match="never downloads"):
+        Vap("vap", c.frame_hz, c.ctx_sec, "jp", cpc_model=str(cpc_p), search_dirs=[str(tmp_path)], force_download=True)
+    vap.start_process()
+    assert vap.mic1.started and vap.mic2.started
+    for f in range(n):
+        r = vap.get_result()                     # blocks until the worker has processed frame f
+        assert set(r) == {"t", "x1", "x2", "p_now", "p_future", "vad"} and len(r["x1"]) == c.hop
+        np.testing.assert_allclose(r["p_now"], c.z["p_now"][f][0], rtol=0, atol=TOL)
+        np.testing.assert_allclose(r["p_future"], c.z["p_future"][f][0], rtol=0, atol=TOL)
+        np.testing.assert_allclose(r["vad"], c.z["vad"][f][0], rtol=0, atol=TOL)
+    vap._stop_worker = True

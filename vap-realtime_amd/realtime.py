@@ -121,6 +121,68 @@ class VAPRealTime:
         return r
 
 
+class Vap(VAPRealTime):
+    """The library twin (``vap_realtime/model.py:15-257``): same constructor arguments, ``start_process()`` / ``worker()`` pulling
+    160-sample chunks from two microphone-like objects (anything with ``get_audio_data()`` and ``start_process()``), ``process_vap``,
+    and ``get_result()`` as a BLOCKING queue read of one result dict per processed frame (``:189-194,208-214,226-240,256-257``).
+    The checkpoint is resolved with the reference's file naming (``vap_realtime/util.py:15-56``) in local directories / the local
+    Hugging Face cache — there is no download path (``force_download`` is rejected)."""
+
+    def __init__(self, mode, frame_rate, context_len_sec, language: str = "jp", mic1=None, mic2=None, num_channels: int = 2,
+                 cpc_model: str = "~/.cache/cpc/60k_epoch4-d0f474de.pt", device="cuda", cache_dir: Optional[str] = None,
+                 force_download: bool = False, search_dirs: Sequence[str] = (".", "asset"), **engine_options):
+        import os
+        import queue
+        from . import checkpoints
+        if force_download:
+            raise _engine.VapxError("vap-realtime_amd never downloads checkpoints; place the files locally")
+        if num_channels != 2:
+            raise _engine.VapxError("the engine is built for the 2-channel models (vap_MC with other channel counts is out of scope)")
+        sd = checkpoints.load_vap_model(mode, frame_rate, context_len_sec, language, search_dirs=list(search_dirs), cache_dir=cache_dir)
+        dev = device
+        if isinstance(device, str):
+            import torch
+            dev = torch.device(device)
+        super().__init__(sd, os.path.expanduser(cpc_model), dev, frame_rate, context_len_sec,
+                         mode="vap" if mode == "vap_MC" else mode, **engine_options)
+        self.mic1, self.mic2 = mic1, mic2
+        self.result_dict_queue = queue.Queue()
+
+    def process_vap(self, x1, x2):
+        super().process_vap(x1, x2)
+        import copy
+        r = VAPRealTime.get_result(self)
+        r["t"] = time.time()
+        self.result_dict_queue.put({k: copy.copy(v) for k, v in r.items()})
+
+    def worker(self):
+        """``vap_realtime/model.py:96-119``: accumulate microphone chunks, step on every complete frame, keep the 320-sample carry."""
+        current_x1 = np.zeros(self.frame_contxt_padding)
+        current_x2 = np.zeros(self.frame_contxt_padding)
+        while not getattr(self, "_stop_worker", False):
+            x1 = self.mic1.get_audio_data()
+            x2 = self.mic2.get_audio_data()
+            if x1 is None or x2 is None:          # (a finite test source ran dry; real microphones block instead)
+                break
+            current_x1 = np.concatenate([current_x1, x1])
+            current_x2 = np.concatenate([current_x2, x2])
+            if len(current_x1) < self.audio_frame_size:
+                continue
+            self.process_vap(current_x1, current_x2)
+            current_x1 = current_x1[-self.frame_contxt_padding:]
+            current_x2 = current_x2[-self.frame_contxt_padding:]
+
+    def start_process(self):
+        import threading
+        self.mic1.start_process()
+        self.mic2.start_process()
+        self._worker_thread = threading.Thread(target=self.worker, daemon=True)
+        self._worker_thread.start()
+
+    def get_result(self):
+        return self.result_dict_queue.get()
+
+
 class ManyStreamVAP:
     """S independent streams on one GPU.  ``process(new_samples[, stream_ids])`` = one tick."""
 
