@@ -697,6 +697,7 @@ __global__ __launch_bounds__(512) void attention_long_kernel(AttnArgs a) {
 //      each takes query tiles w and 7 - w (9 causal key tiles per wave: balanced).  Optional ring addressing lets layer 0
 //      read the per-stream Q|K|V rings in place (no chronological gather for long windows either).
 // ------------------------------------------------------------------------------------------------
+template <bool PIPE>
 __global__ __launch_bounds__(256, 2) void attention_long2_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float Vs[];   // [n_tiles * 32][64]
   const int T = a.T;
@@ -756,14 +757,15 @@ __global__ __launch_bounds__(256, 2) void attention_long2_kernel(AttnArgs a) {
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    auto tile = [&](const f32x4 (&kf)[8], int jt) {     // one 32-key tile: scores, online softmax update, P.V
-      f32x16 sc;
+    auto scores = [&](f32x16& sc, const f32x4 (&kf)[8]) {   // S^T tile = K_tile . Q^T: 32 MFMAs into one accumulator
 #pragma unroll
       for (int r = 0; r < 16; ++r) sc[r] = 0.f;
 #pragma unroll
       for (int kc = 0; kc < 8; ++kc)
 #pragma unroll
         for (int s = 0; s < 4; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[kc][s], qf[kc][s], sc, 0, 0, 0);
+    };
+    auto softmax = [&](f32x16& sc, int jt) {            // online update for one 32-key tile: sc := P, returns the rescale factor
       float cm = -1e30f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -786,22 +788,85 @@ __global__ __launch_bounds__(256, 2) void attention_long2_kernel(AttnArgs a) {
       sum += __shfl_xor(sum, 32);
       l = l * alpha + sum;
       m = mn;
+      return alpha;
+    };
+    auto pv = [&](const f32x16& p, int jt, float alpha) {  // O^T = alpha O^T + V_tile^T . P^T
 #pragma unroll
       for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float* va = &Vs[(jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + l31];
-        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[0], sc[r], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32], sc[r], o1, 0, 0, 0);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[0], p[r], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32], p[r], o1, 0, 0, 0);
       }
     };
+    if constexpr (!PIPE) {
+      f32x16 sc;
 #pragma unroll 1
-    for (int jt = 0; jt <= it; jt += 2) {               // K fragments ping-pong one tile ahead of their use
-      if (jt + 1 <= it) load_k(kfb, jt + 1);
-      tile(kfa, jt);
-      if (jt + 1 <= it) {
-        if (jt + 2 <= it) load_k(kfa, jt + 2);
-        tile(kfb, jt + 1);
+      for (int jt = 0; jt <= it; jt += 2) {             // K fragments ping-pong one tile ahead of their use
+        if (jt + 1 <= it) load_k(kfb, jt + 1);
+        scores(sc, kfa);
+        float al = softmax(sc, jt);
+        pv(sc, jt, al);
+        if (jt + 1 <= it) {
+          if (jt + 2 <= it) load_k(kfa, jt + 2);
+          scores(sc, kfb);
+          al = softmax(sc, jt + 1);
+          pv(sc, jt + 1, al);
+        }
+      }
+    } else {
+      // software pipeline: the score MFMAs of tile j+1 are interleaved with the mask / bias / max VALU work of tile j (two
+      // score accumulators ping-pong), whose exponentials the compiler already weaves into the P.V chain
+      f32x16 sa, sb;
+      if (it >= 1) load_k(kfb, 1);
+      scores(sa, kfa);
+      auto step = [&](f32x16& cur, f32x16& nxt, const f32x4 (&kfn)[8], f32x4 (&kfl)[8], int jt) {
+        if (jt + 2 <= it) load_k(kfl, jt + 2);
+        // scores of tile jt + 1 (32 MFMAs into `nxt`) with the mask / bias / running-max pass over tile jt's scores (`cur`)
+        // written between them: the VALU work issues in the shadow of the dependent MFMA chain
+        float cm = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nxt[r] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(kfn[kc][s], qf[kc][s], nxt, 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int r = kc * 2 + u;
+            const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            float v = cur[r] + slope * (float)j;
+            v = ((j <= i) && (j < n)) ? v : -1e30f;
+            cur[r] = v;
+            cm = fmaxf(cm, v);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);                // nothing of the exp / P.V phase is hoisted into the chain above
+        cm = fmaxf(cm, __shfl_xor(cm, 32));
+        const float mn = fmaxf(m, cm);
+        const float al = __expf(m - mn);
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = cur[r] > -1e29f ? __expf(cur[r] - mn) : 0.f;
+          cur[r] = e;
+          sum += e;
+        }
+        sum += __shfl_xor(sum, 32);
+        l = l * al + sum;
+        m = mn;
+        pv(cur, jt, al);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+#pragma unroll 1
+      for (int jt = 0; jt <= it; jt += 2) {
+        if (jt + 1 <= it) step(sa, sb, kfb, kfa, jt);
+        else { const float al = softmax(sa, jt); pv(sa, jt, al); }
+        if (jt + 1 <= it) {
+          if (jt + 2 <= it) step(sb, sa, kfa, kfb, jt + 1);
+          else { const float al = softmax(sb, jt + 1); pv(sb, jt + 1, al); }
+        }
       }
     }
     if (i < T) {
@@ -1130,10 +1195,13 @@ hipError_t launch_attention(const AttnArgs& a, int B, hipStream_t st) {
   if ((a.ring_rot && n_tiles <= 8) || (n_tiles > 2 && n_tiles <= 8 && !gen1 && !gen2)) {
     static bool attr4 = false;
     if (!attr4) {
-      (void)hipFuncSetAttribute((const void*)attention_long2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute((const void*)attention_long2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute((const void*)attention_long2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
       attr4 = true;
     }
-    hipLaunchKernelGGL(attention_long2_kernel, dim3(B * 2 * 4), dim3(256), (size_t)n_tiles * 32 * 64 * sizeof(float), st, a);
+    static const bool nopipe = getenv("VAPX_ATTN_NOPIPE") != nullptr;   // A/B: without the score / softmax software pipeline
+    if (nopipe) hipLaunchKernelGGL(attention_long2_kernel<false>, dim3(B * 2 * 4), dim3(256), (size_t)n_tiles * 32 * 64 * sizeof(float), st, a);
+    else hipLaunchKernelGGL(attention_long2_kernel<true>, dim3(B * 2 * 4), dim3(256), (size_t)n_tiles * 32 * 64 * sizeof(float), st, a);
     return hipGetLastError();
   }
   if (n_tiles <= 2) hipLaunchKernelGGL(attention_mfma_kernel<2>, dim3(B * 2 * 4), dim3(64 * nw), lds, st, a);
