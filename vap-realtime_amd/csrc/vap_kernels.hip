@@ -697,7 +697,6 @@ __global__ __launch_bounds__(512) void attention_long_kernel(AttnArgs a) {
 //      each takes query tiles w and 7 - w (9 causal key tiles per wave: balanced).  Optional ring addressing lets layer 0
 //      read the per-stream Q|K|V rings in place (no chronological gather for long windows either).
 // ------------------------------------------------------------------------------------------------
-template <bool PIPE>
 __global__ __launch_bounds__(256, 2) void attention_long2_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float Vs[];   // [n_tiles * 32][64]
   const int T = a.T;
@@ -800,73 +799,18 @@ __global__ __launch_bounds__(256, 2) void attention_long2_kernel(AttnArgs a) {
         o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32], p[r], o1, 0, 0, 0);
       }
     };
-    if constexpr (!PIPE) {
-      f32x16 sc;
+    f32x16 sc;
 #pragma unroll 1
-      for (int jt = 0; jt <= it; jt += 2) {             // K fragments ping-pong one tile ahead of their use
-        if (jt + 1 <= it) load_k(kfb, jt + 1);
-        scores(sc, kfa);
-        float al = softmax(sc, jt);
-        pv(sc, jt, al);
-        if (jt + 1 <= it) {
-          if (jt + 2 <= it) load_k(kfa, jt + 2);
-          scores(sc, kfb);
-          al = softmax(sc, jt + 1);
-          pv(sc, jt + 1, al);
-        }
-      }
-    } else {
-      // software pipeline: the score MFMAs of tile j+1 are interleaved with the mask / bias / max VALU work of tile j (two
-      // score accumulators ping-pong), whose exponentials the compiler already weaves into the P.V chain
-      f32x16 sa, sb;
-      if (it >= 1) load_k(kfb, 1);
-      scores(sa, kfa);
-      auto step = [&](f32x16& cur, f32x16& nxt, const f32x4 (&kfn)[8], f32x4 (&kfl)[8], int jt) {
-        if (jt + 2 <= it) load_k(kfl, jt + 2);
-        // scores of tile jt + 1 (32 MFMAs into `nxt`) with the mask / bias / running-max pass over tile jt's scores (`cur`)
-        // written between them: the VALU work issues in the shadow of the dependent MFMA chain
-        float cm = -1e30f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) nxt[r] = 0.f;
-#pragma unroll
-        for (int kc = 0; kc < 8; ++kc) {
-#pragma unroll
-          for (int s = 0; s < 4; ++s) nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(kfn[kc][s], qf[kc][s], nxt, 0, 0, 0);
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int r = kc * 2 + u;
-            const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            float v = cur[r] + slope * (float)j;
-            v = ((j <= i) && (j < n)) ? v : -1e30f;
-            cur[r] = v;
-            cm = fmaxf(cm, v);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);                // nothing of the exp / P.V phase is hoisted into the chain above
-        cm = fmaxf(cm, __shfl_xor(cm, 32));
-        const float mn = fmaxf(m, cm);
-        const float al = __expf(m - mn);
-        float sum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float e = cur[r] > -1e29f ? __expf(cur[r] - mn) : 0.f;
-          cur[r] = e;
-          sum += e;
-        }
-        sum += __shfl_xor(sum, 32);
-        l = l * al + sum;
-        m = mn;
-        pv(cur, jt, al);
-        __builtin_amdgcn_sched_barrier(0);
-      };
-#pragma unroll 1
-      for (int jt = 0; jt <= it; jt += 2) {
-        if (jt + 1 <= it) step(sa, sb, kfb, kfa, jt);
-        else { const float al = softmax(sa, jt); pv(sa, jt, al); }
-        if (jt + 1 <= it) {
-          if (jt + 2 <= it) step(sb, sa, kfa, kfb, jt + 1);
-          else { const float al = softmax(sb, jt + 1); pv(sb, jt + 1, al); }
-        }
+    for (int jt = 0; jt <= it; jt += 2) {             // K fragments ping-pong one tile ahead of their use
+      if (jt + 1 <= it) load_k(kfb, jt + 1);
+      scores(sc, kfa);
+      float al = softmax(sc, jt);
+      pv(sc, jt, al);
+      if (jt + 1 <= it) {
+        if (jt + 2 <= it) load_k(kfa, jt + 2);
+        scores(sc, kfb);
+        al = softmax(sc, jt + 1);
+        pv(sc, jt + 1, al);
       }
     }
     if (i < T) {
@@ -1195,13 +1139,10 @@ hipError_t launch_attention(const AttnArgs& a, int B, hipStream_t st) {
   if ((a.ring_rot && n_tiles <= 8) || (n_tiles > 2 && n_tiles <= 8 && !gen1 && !gen2)) {
     static bool attr4 = false;
     if (!attr4) {
-      (void)hipFuncSetAttribute((const void*)attention_long2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      (void)hipFuncSetAttribute((const void*)attention_long2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute((const void*)attention_long2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
       attr4 = true;
     }
-    static const bool nopipe = getenv("VAPX_ATTN_NOPIPE") != nullptr;   // A/B: without the score / softmax software pipeline
-    if (nopipe) hipLaunchKernelGGL(attention_long2_kernel<false>, dim3(B * 2 * 4), dim3(256), (size_t)n_tiles * 32 * 64 * sizeof(float), st, a);
-    else hipLaunchKernelGGL(attention_long2_kernel<true>, dim3(B * 2 * 4), dim3(256), (size_t)n_tiles * 32 * 64 * sizeof(float), st, a);
+    hipLaunchKernelGGL(attention_long2_kernel, dim3(B * 2 * 4), dim3(256), (size_t)n_tiles * 32 * 64 * sizeof(float), st, a);
     return hipGetLastError();
   }
   if (n_tiles <= 2) hipLaunchKernelGGL(attention_mfma_kernel<2>, dim3(B * 2 * 4), dim3(64 * nw), lds, st, a);
