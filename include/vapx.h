@@ -73,8 +73,6 @@ extern "C" {
                                          the embedding / Q|K|V rings in place (short and long windows alike) */
 #define VAPX_FLAG_SPLIT_F16 512        /* opt-in: the FFN block's contractions as fp32-accurate 3-term split products on the f16
                                          matrix cores (x = hi + lo; hi.hi + lo.hi + hi.lo, fp32 accumulate); default: fp32 MFMA */
-#define VAPX_FLAG_ATTN_BLOCK_V1 2048  /* short windows (T <= 64): the first-generation attention block (one 4-wave workgroup per window) instead of
-                                         the persistent 8-wave one; kept for A/B parity tests */
 #define VAPX_FLAG_UNFUSED_PROJ 1024    /* long windows (T > 64): attention output projections (+ residual + LN, + cross-attention query
                                          projection) as separate GEMM launches instead of riding in the fused blocks; kept for A/B tests */
 #define VAPX_FLAG_UNFUSED_LAST_ROW 256 /* last layer's newest-row path as ten launches (gathers, M = 2B GEMMs, single-query

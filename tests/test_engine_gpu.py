@@ -539,26 +539,3 @@ def test_published_bc_and_nod_settings_against_the_oracle(mode, hz, ctx):
     assert worst <= TOL
     eng.close()
 
-
-@pytest.mark.parametrize("S", [3, 300])
-def test_attention_block_generations_agree_bit_for_bit(S):
-    """The persistent 8-wave attention block (default) performs the same arithmetic in the same order as the first generation
-    (VAPX_FLAG_ATTN_BLOCK_V1): identical outputs while the window fills (second query tile empty, then partly used), when it is
-    full and when it slides; S = 300 makes every persistent workgroup walk over several windows with the V prefetch."""
-    from vap_realtime_amd import engine, synth, weights as W
-    cpc, vap = W.synthetic_weights(9, 20, "vap")
-    blob = W.pack_blob(cpc, vap)
-    F_ = 56 if S == 3 else 8
-    audio = synth.noise_batch(S, 800 * F_, seed=21) * np.linspace(0.3, 2.0, S, dtype=np.float32)[:, None, None]
-    v2 = engine.Engine(blob, 20, 2.5, max_streams=S)
-    v1 = engine.Engine(blob, 20, 2.5, max_streams=S, attn_block_v1=True)
-    if S == 300:                      # start from staggered window fills: streams 0..299 have seen 0..59 frames already
-        for eng in (v1, v2):
-            for k in range(60):
-                n = S - 5 * k
-                if n > 0:
-                    eng.step(audio[:n, :, :800] * (1.0 + 0.01 * k))
-    for f in range(F_):
-        a = audio[:, :, f * 800:(f + 1) * 800]
-        np.testing.assert_array_equal(v2.step(a), v1.step(a), err_msg=f"frame {f}")
-    v1.close(); v2.close()

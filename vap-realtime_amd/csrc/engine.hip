@@ -207,12 +207,6 @@ hipError_t gemm(vapx_engine* h, const GemmArgs& g, int epi, hipStream_t st) {
   return launch_gemm_f32(g, epi, 0, st);
 }
 
-// short-window attention block: persistent 8-wave generation by default, generation 1 for the split-precision path and A/B tests
-hipError_t attn_block(vapx_engine* h, const AttnBlockArgs& ab, int B, hipStream_t st) {
-  if (ab.split || (h->cfg.flags & VAPX_FLAG_ATTN_BLOCK_V1)) return launch_attn_block(ab, B, st);
-  return launch_attn_block2(ab, B, st);
-}
-
 GemmArgs gemm_args(const float* A, RowMap am, const float* W, int M, int N, int K, float* C, RowMap cm) {
   GemmArgs g;
   memset(&g, 0, sizeof g);
@@ -326,12 +320,12 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
       }
       if (l == 0) { ab.ln_g = Lw.ln_ffn_g; ab.ln_b = Lw.ln_ffn_b; }
       else { ab.ln_g = Lw.ln_src_g; ab.ln_b = Lw.ln_src_b; ab.wqxf = asplit ? Lw.wqxh : Lw.wqxf; ab.qx = sc.qx; ab.xn = nullptr; }
-      { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, attn_block(h, ab, B, st)); }
+      { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attn_block(ab, B, st)); }
       if (l > 0) {
         ab.q = sc.qx; ab.k = sc.kvx; ab.v = sc.kvx + 256; ab.ldq = 256; ab.ldkv = 512; ab.swap_kv = 1;
         ab.wprojf = asplit ? Lw.wprojxh : Lw.wprojxf; ab.resid = sc.xmid; ab.ln_g = Lw.ln_ffn_g; ab.ln_b = Lw.ln_ffn_b;
         ab.wqxf = nullptr; ab.qx = nullptr; ab.xn = nullptr; ab.ring_rot = nullptr; ab.ids = nullptr;
-        { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, attn_block(h, ab, B, st)); }
+        { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attn_block(ab, B, st)); }
       }
     } else if (!(h->cfg.flags & (VAPX_FLAG_UNFUSED_PROJ | VAPX_FLAG_SPLIT_F16))) {
       // long window: plain attention kernels; every projection rides in a fused flat-row block (no [rows x 256] GEMM launches)

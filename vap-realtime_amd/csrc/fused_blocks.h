@@ -83,7 +83,6 @@ struct LastBlockArgs {
 bool conv_tail_supported(int P1, int ncpc);
 hipError_t launch_last_block(const LastBlockArgs& a, hipStream_t st);
 hipError_t launch_conv_tail(const ConvTailArgs& a, int B, hipStream_t st);
-hipError_t launch_attn_block(const AttnBlockArgs& a, int B, hipStream_t st);   // T <= 64 only (generation 1: one 4-wave workgroup per window)
-hipError_t launch_attn_block2(const AttnBlockArgs& a, int B, hipStream_t st);  // T <= 64, fp32 path: persistent 8-wave workgroups (attn_block2.hip)
+hipError_t launch_attn_block(const AttnBlockArgs& a, int B, hipStream_t st);   // T <= 64 only
 hipError_t launch_ffn_block(const FfnArgs& a, hipStream_t st);
 hipError_t launch_ffn_block_f16x3(const FfnArgs& a, hipStream_t st);   // w0f/w3f/wqkvf/wkvxf point to the *h (f16 hi/lo) copies
