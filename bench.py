@@ -339,6 +339,8 @@ def paced_latency(cpc, vap, hz, ctx_sec, local_rank, seconds, target_ms=10.0, ma
         out["sustained_streams"] = 0
         return out
     G, Ssub = best
+    import gc
+    gc.disable()                                       # a collector pause inside the 50 ms schedule would be charged to the engine
     for attempt in range(2):
         for s in range(G * Ssub):                     # every trial starts from clean streams (queued, applied by the next step)
             eng.reset_stream(s)
@@ -377,6 +379,7 @@ def paced_latency(cpc, vap, hz, ctx_sec, local_rank, seconds, target_ms=10.0, ma
     else:
         out["sustained_streams"] = 0
     out.setdefault("sustained_streams", 0)
+    gc.enable()
     eng.close()
     return out
 
