@@ -829,7 +829,7 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
   h->id_stamp.assign(S, 0u);
   if (const char* ev = getenv("VAPX_FFN_TILE")) h->ffn_tile_rows = atoi(ev);
   if (const char* ev = getenv("VAPX_GROUP0_STREAMS")) h->group0_streams = atoi(ev);
-  if (getenv("VAPX_FORCE_LONG")) { h->force_long = true; h->cfg.flags |= VAPX_FLAG_MATERIALIZE_X0; }
+  if (getenv("VAPX_FORCE_LONG")) h->force_long = true;
   if (const char* ev = getenv("VAPX_FFN_TRACE")) {
     h->ffn_trace_path = ev;
     CR(dalloc(&h->ffn_trace, (size_t)16384 * 32));

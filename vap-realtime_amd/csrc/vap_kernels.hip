@@ -697,15 +697,19 @@ __global__ __launch_bounds__(512) void attention_long_kernel(AttnArgs a) {
 //      each takes query tiles w and 7 - w (9 causal key tiles per wave: balanced).  Optional ring addressing lets layer 0
 //      read the per-stream Q|K|V rings in place (no chronological gather for long windows either).
 // ------------------------------------------------------------------------------------------------
+// SHORT (T <= 64, two tiles): one workgroup per (stream, channel), wave = head, each wave walks its head's two query tiles
+// (its V tile is wave-private in LDS) — the same 64 KB of LDS and two workgroups per CU.
+template <bool SHORT>
 __global__ __launch_bounds__(256, 2) void attention_long2_kernel(AttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float Vs[];   // [n_tiles * 32][64]
+  extern __shared__ __attribute__((aligned(16))) float Vs_all[];   // [n_tiles * 32][64]  (SHORT: x 4 heads)
   const int T = a.T;
   const int n_tiles = (T + 31) >> 5;                 // <= 8
-  const int h = blockIdx.x & 3, bc = blockIdx.x >> 2, b = bc >> 1;
-  const int n = a.bn[b];
-  const int kvbc = a.swap_kv ? (bc ^ 1) : bc;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = SHORT ? w : (int)(blockIdx.x & 3), bc = SHORT ? (int)blockIdx.x : (int)(blockIdx.x >> 2), b = bc >> 1;
+  float* Vs = SHORT ? Vs_all + w * n_tiles * 32 * 64 : Vs_all;
+  const int n = a.bn[b];
+  const int kvbc = a.swap_kv ? (bc ^ 1) : bc;
   const int l31 = lane & 31, hi = lane >> 5;
   const bool ringed = a.ring_rot != nullptr;
   const int rot = ringed ? a.ring_rot[b] : 0;
@@ -715,7 +719,7 @@ __global__ __launch_bounds__(256, 2) void attention_long2_kernel(AttnArgs a) {
   const float* kp = a.k + slab_kv * T * a.ldkv + h * 64;
   const float* vp = a.v + slab_kv * T * a.ldkv + h * 64;
   const int nt_valid = (n + 31) >> 5;
-  for (int idx = tid; idx < nt_valid * 32 * 16; idx += 256) {
+  for (int idx = SHORT ? lane : tid; idx < nt_valid * 32 * 16; idx += SHORT ? 64 : 256) {
     const int j = idx >> 4, q = (idx & 15) * 4;
     f32x4 vv = {0.f, 0.f, 0.f, 0.f};
     if (j < n) vv = *(const f32x4*)(vp + (long)prow(j) * a.ldkv + q);
@@ -731,7 +735,7 @@ __global__ __launch_bounds__(256, 2) void attention_long2_kernel(AttnArgs a) {
     for (int kc = 0; kc < 8; ++kc) kf[kc] = *(const f32x4*)(kr + kc * 8);
   };
   for (int pass = 0; pass < 2; ++pass) {
-    const int it = pass == 0 ? w : 7 - w;
+    const int it = SHORT ? pass : (pass == 0 ? w : 7 - w);
     if (it >= n_tiles) continue;
     const int i = it * 32 + l31;
     float* op = a.out + ((long)bc * T + i) * 256 + h * 64;
@@ -1136,13 +1140,17 @@ hipError_t launch_attention(const AttnArgs& a, int B, hipStream_t st) {
   }
   static const bool gen1 = getenv("VAPX_ATTN_GEN1") != nullptr;   // A/B: the first-generation 4-wave kernel
   static const bool gen2 = getenv("VAPX_ATTN_GEN2") != nullptr;   // A/B: the 8-wave, K+V-in-LDS kernel
-  if ((a.ring_rot && n_tiles <= 8) || (n_tiles > 2 && n_tiles <= 8 && !gen1 && !gen2)) {
+  if (n_tiles <= 8 && !gen1 && !gen2) {
     static bool attr4 = false;
     if (!attr4) {
-      (void)hipFuncSetAttribute((const void*)attention_long2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute((const void*)attention_long2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute((const void*)attention_long2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
       attr4 = true;
     }
-    hipLaunchKernelGGL(attention_long2_kernel, dim3(B * 2 * 4), dim3(256), (size_t)n_tiles * 32 * 64 * sizeof(float), st, a);
+    if (n_tiles <= 2)   // short windows: workgroup = (stream, channel), wave = head
+      hipLaunchKernelGGL(attention_long2_kernel<true>, dim3(B * 2), dim3(256), (size_t)4 * n_tiles * 32 * 64 * sizeof(float), st, a);
+    else
+      hipLaunchKernelGGL(attention_long2_kernel<false>, dim3(B * 2 * 4), dim3(256), (size_t)n_tiles * 32 * 64 * sizeof(float), st, a);
     return hipGetLastError();
   }
   if (n_tiles <= 2) hipLaunchKernelGGL(attention_mfma_kernel<2>, dim3(B * 2 * 4), dim3(64 * nw), lds, st, a);
