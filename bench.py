@@ -409,6 +409,8 @@ def main():
                     help="opt-in: GEMM-shaped contractions as fp32-accurate 3-term f16 split products (VAPX_FLAG_SPLIT_F16)")
     ap.add_argument("--defer-join", action="store_true", help="with --groups > 1: let overlap groups free-run across ticks")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="plumbing check on a 1-GPU box: every rank uses device 0 (combine with --backend gloo; RCCL cannot put two ranks on one device)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="multi-rank plumbing check without a GPU: spawn, rendezvous, shard the streams, barrier, print the ranks")
     args = ap.parse_args()
@@ -440,6 +442,8 @@ def main():
         return
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = dist_util.init(args.backend, torch.device("cuda", local_rank))
     ctx = (rank, local_rank, world, dist)
