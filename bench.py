@@ -285,6 +285,10 @@ def run_workload(name, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=0, split
         "executed_frac_of_fp32_mfma_peak": value * exec_gflop / 1e3 / (FP32_MFMA_PEAK_TF * world),
         "roofline": roof,
         "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1])},
+        # every kernel class against the same roof (algorithmic FLOPs of the class per step / its time in the profiled pass;
+        # attention classes on the dense T x T count): shows which kernel is furthest below the fp32-MFMA peak
+        "kernel_tflops": {k: round(2.0 * macs.get(k, 0) * S / (v * 1e-3) / 1e12, 1)
+                          for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]) if v > 0 and macs.get(k, 0) > 0},
     }
     if dense_gflop and nm == 1:
         rec["dense_gflop_per_stream_frame"] = dense_gflop
