@@ -310,3 +310,58 @@ def test_library_twin_vap_class_with_microphone_sources(tmp_path):
         np.testing.assert_allclose(r["p_future"], c.z["p_future"][f][0], rtol=0, atol=TOL)
         np.testing.assert_allclose(r["vad"], c.z["vad"][f][0], rtol=0, atol=TOL)
     vap._stop_worker = True
+
+
+def test_serve_program_end_to_end():
+    """``python -m vap_realtime_amd.serve`` — the twin of ``python vap_main.py --vap_model ... --port_num_in ... --gpu`` (vap_main.py:461-530)
+    for many dialogues: started as a subprocess with the reference's argument names, fed the golden audio over TCP, answers compared
+    with the golden of the imported reference; SIGTERM stops it."""
+    import os
+    import re
+    import signal
+    import subprocess
+    import sys
+    from vap_realtime_amd import wire
+    c = Case("multi3")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.Popen([sys.executable, "-u", "-m", "vap_realtime_amd.serve", "--synthetic-weights", str(c.seed), "--streams", "4",
+                             "--port_num_in", "0", "--port_num_out", "0", "--vap_process_rate", str(c.frame_hz),
+                             "--context_len_sec", str(c.ctx_sec), "--gpu", "--stats_sec", "0"],
+                            cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        line = ""
+        t0 = time.time()
+        while "input :" not in line and time.time() - t0 < 180:
+            line = proc.stdout.readline()
+            assert line or proc.poll() is None, "serve exited early"
+        pin, pout = (int(x) for x in re.search(r"input :(\d+), output :(\d+)", line).groups())
+        S = len(c.streams)
+        ins = [socket.create_connection(("127.0.0.1", pin)) for _ in range(S)]
+        time.sleep(0.3)
+        outs = [socket.create_connection(("127.0.0.1", pout)) for _ in range(S)]
+        time.sleep(0.3)
+        for f in range(8):
+            new = c.new_samples(f).astype(np.float64)
+            for s in range(S):
+                ins[s].sendall(wire.encode_input(new[s, 0], new[s, 1]))
+            for s in range(S):
+                outs[s].settimeout(30)
+                hdr = b""
+                while len(hdr) < 4:
+                    hdr += outs[s].recv(4 - len(hdr))
+                ln = struct.unpack("<I", hdr)[0]
+                payload = b""
+                while len(payload) < ln:
+                    payload += outs[s].recv(ln - len(payload))
+                r = wire.decode_result(payload)
+                np.testing.assert_allclose(r["p_now"], c.z["p_now"][f][s], rtol=0, atol=TOL)
+                np.testing.assert_allclose(r["vad"], c.z["vad"][f][s], rtol=0, atol=TOL)
+        for s in ins + outs:
+            s.close()
+    finally:
+        proc.send_signal(signal.SIGTERM)
+        try:
+            proc.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+    assert proc.returncode == 0
