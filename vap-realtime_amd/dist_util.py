@@ -25,8 +25,10 @@ def init(backend: str, device=None):
         # RCCL for CUDA tensors (the barrier / max-over-ranks of the bench), gloo for CPU tensors (shard bookkeeping); if RCCL
         # cannot come up in this environment the control plane still works over gloo — there is no collective on the data path
         try:
+            import datetime
             kw = {"device_id": device} if device is not None else {}
-            dist.init_process_group("cpu:gloo,cuda:nccl", rank=rank, world_size=world, **kw)
+            # a finite timeout: a collective that cannot complete fails the run instead of hanging it
+            dist.init_process_group("cpu:gloo,cuda:nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600), **kw)
         except Exception as e:                                    # noqa: BLE001
             import sys
             print(f"[dist_util] RCCL init failed ({e}); falling back to gloo for the bench's barrier", file=sys.stderr)
