@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--rx-threads", type=int, default=4)
     ap.add_argument("--tx-threads", type=int, default=4)
     ap.add_argument("--client-threads", type=int, default=8)
+    ap.add_argument("--repeat", type=int, default=1, help="run the load generator this many times against the SAME server (slot reuse, resets at scale)")
     ap.add_argument("--python", action="store_true", help="serve with the Python front-end instead of the native one")
     ap.add_argument("--fake", action="store_true", help="native front-end over a trivial step function (plumbing only, no GPU)")
     args = ap.parse_args()
@@ -69,6 +70,11 @@ def main():
             kind = "native front-end (vapx_ingest_*) + engine"
     cmd = [loadgen, "--port-in", str(srv.port_in), "--port-out", str(srv.port_out), "--streams", str(S), "--hz", str(args.hz),
            "--seconds", str(args.seconds), "--warm", str(args.warm), "--packet-ms", str(args.packet_ms), "--threads", str(args.client_threads)]
+    for rep in range(args.repeat - 1):              # earlier rounds: only their summary line is kept
+        first = json.loads(subprocess.run(cmd, stdout=subprocess.PIPE).stdout.decode().strip().splitlines()[-1])
+        print(json.dumps({"round": rep, "frames_answered": first["frames_answered"], "frames_sent": first["frames_sent"],
+                          "lat_p99_ms": first["lat_p99_ms"]}), file=sys.stderr)
+        time.sleep(1.0)
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE)
     base = {}
     if hasattr(srv, "stats"):                       # server-side latency window = the load generator's measured window
