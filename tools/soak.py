@@ -3,6 +3,7 @@
 for many ticks with random resets; the first two must stay bit-identical while both batch sizes select the same kernel
 variants (<= 512 streams; beyond that tile heuristics differ and only the tolerance applies), the third within tolerance,
 nothing may go non-finite.  Usage: tools/soak.py [streams] [ticks]"""
+import os
 import sys
 
 import numpy as np
@@ -29,13 +30,13 @@ st = torch.cuda.current_stream().cuda_stream
 worst = 0.0
 for t in range(TICKS):
     x = frames[t % NF]
-    if t % 37 == 5:
+    if t % 37 == 5 and not os.environ.get("SOAK_NO_RESET"):
         torch.cuda.synchronize()
         for sid in rng.integers(0, S, 3):
             for e in (a, b, c):
                 e.reset_stream(int(sid))
     a.step_device(S, x.data_ptr(), 800, oa.data_ptr(), stream=st)
-    b.step_device(S, x.data_ptr(), 800, ob.data_ptr(), stream=st, defer_join=True)
+    b.step_device(S, x.data_ptr(), 800, ob.data_ptr(), stream=st, defer_join=not os.environ.get("SOAK_NO_DEFER"))
     c.step_device(S, x.data_ptr(), 800, oc.data_ptr(), stream=st)
     if t % 25 == 24 or t == TICKS - 1:
         b.join(st)

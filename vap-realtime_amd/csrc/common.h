@@ -60,6 +60,11 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return copysignf(r, x);
 }
 
+// value of lane `l` (wave-uniform index) in every lane: v_readlane_b32, no LDS
+__device__ __forceinline__ float lane_bcast(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
 // 64-lane butterfly all-reduce (max; the sum is below, built on the DPP half_sum)
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

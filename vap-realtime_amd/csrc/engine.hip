@@ -91,6 +91,7 @@ struct vapx_engine {
   int n_groups = 1;
   int ffn_tile_rows = 0;   // tuning knob (env VAPX_FFN_TILE): 32 or 64 rows per FFN-block workgroup
   int group0_streams = 0;    // experiment knob (env VAPX_GROUP0_STREAMS): size of the first of two overlap groups
+  int split_mask = 15;       // diagnostic knob (env VAPX_SPLIT_MASK): which kernel families of a VAPX_FLAG_SPLIT_F16 engine run split (1 GEMM, 2 attn_block, 4 FFN block, 8 unfused conv tail)
   bool force_long = false;   // experiment knob (env VAPX_FORCE_LONG): short windows through the long-window kernel chain
   unsigned long long* ffn_trace = nullptr;   // env VAPX_FFN_TRACE=<file>: phase stamps of the layer-0 FFN block's workgroups
   size_t ffn_trace_wgs = 0;
@@ -199,7 +200,7 @@ struct ProfScope {
 
 hipError_t gemm(vapx_engine* h, const GemmArgs& g, int epi, hipStream_t st) {
   ProfScope ps(h, epi, st);
-  if (h->cfg.flags & VAPX_FLAG_SPLIT_F16) {
+  if ((h->cfg.flags & VAPX_FLAG_SPLIT_F16) && (h->split_mask & 1)) {
     GemmArgs gs = g;
     gs.split = 1;
     return launch_gemm_f32(gs, epi, 0, st);
@@ -234,7 +235,8 @@ int run_encoder(vapx_engine* h, const Scratch& sc, const StateView& sv, int B, c
   };
   // one stream per workgroup pays 27 % row padding: worth it only while the three GEMMs cannot fill the chip
   // (on the split-precision path the three GEMMs are 2x cheaper and beat the fp32 fused tail even at 256 streams)
-  const bool fused_tail = conv_tail_supported(P[1], h->ncpc) && !(h->cfg.flags & (VAPX_FLAG_UNFUSED_CONV | VAPX_FLAG_SPLIT_F16)) && B <= 512;
+  const bool fused_tail = conv_tail_supported(P[1], h->ncpc) && !(h->cfg.flags & VAPX_FLAG_UNFUSED_CONV) &&
+                          !((h->cfg.flags & VAPX_FLAG_SPLIT_F16) && (h->split_mask & 8)) && B <= 512;
   char nm[32];
   for (int i = 0; i < (fused_tail ? 1 : 3); ++i) {
     const ConvSpec& c = cs[i];
@@ -311,7 +313,7 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
       AttnBlockArgs ab;
       memset(&ab, 0, sizeof ab);
       ab.q = sc.qkv; ab.k = sc.qkv + 256; ab.v = sc.qkv + 512; ab.ldq = 768; ab.ldkv = 768; ab.swap_kv = 0;
-      const bool asplit = (h->cfg.flags & VAPX_FLAG_SPLIT_F16) != 0;
+      const bool asplit = (h->cfg.flags & VAPX_FLAG_SPLIT_F16) != 0 && (h->split_mask & 2);
       ab.split = asplit ? 1 : 0;
       ab.bn = sc.bn; ab.T = T; ab.wprojf = asplit ? Lw.wprojh : Lw.wprojf; ab.resid = xin; ab.xmid = sc.xmid; ab.xn = nullptr;
       if (l == 0 && rv && rv->ring) {   // Q|K|V and the residual straight from the per-stream rings
@@ -370,7 +372,7 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
       }
     }
     // feed-forward (+ next layer's projections)
-    const bool split = (h->cfg.flags & VAPX_FLAG_SPLIT_F16) != 0;   // fp32-accurate products on the f16 matrix cores
+    const bool split = (h->cfg.flags & VAPX_FLAG_SPLIT_F16) != 0 && (h->split_mask & 4);   // fp32-accurate products on the f16 matrix cores
     FfnArgs fa;
     memset(&fa, 0, sizeof fa);
     fa.xmid = sc.xmid; fa.lnf_g = Lw.ln_ffn_g; fa.lnf_b = Lw.ln_ffn_b; fa.xout = xout; fa.M = M;
@@ -830,6 +832,7 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
   if (const char* ev = getenv("VAPX_FFN_TILE")) h->ffn_tile_rows = atoi(ev);
   if (const char* ev = getenv("VAPX_GROUP0_STREAMS")) h->group0_streams = atoi(ev);
   if (getenv("VAPX_FORCE_LONG")) h->force_long = true;
+  if (const char* e = getenv("VAPX_SPLIT_MASK")) h->split_mask = atoi(e);
   if (const char* ev = getenv("VAPX_FFN_TRACE")) {
     h->ffn_trace_path = ev;
     CR(dalloc(&h->ffn_trace, (size_t)16384 * 32));

@@ -870,13 +870,10 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
 // one workgroup per (stream, channel), one wave per head.  Phase 1: lane = key j computes the
 // score; softmax across lanes; phase 2: lane = feature d accumulates sum_j p_j V[j][d].
 __global__ __launch_bounds__(256) void attention_last_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) float sq[4][64];
-  __shared__ float sp[4][64];
   const int bc = blockIdx.x, b = bc >> 1, h = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = a.bn[b], T = a.T;
   const int kvbc = a.swap_kv ? (bc ^ 1) : bc;
-  sq[h][lane] = a.q[(long)bc * a.ldq + h * 64 + lane] * 0.0625f;
-  __syncthreads();
+  const float qm = a.q[(long)bc * a.ldq + h * 64 + lane] * 0.0625f;   // element `lane` of this head's query; broadcast from registers
   const float slope = exp2f(-2.0f * (float)(h + 1));
   const float* kp = a.k + (long)kvbc * T * a.ldkv + h * 64;
   const float* vp = a.v + (long)kvbc * T * a.ldkv + h * 64;
@@ -888,7 +885,8 @@ __global__ __launch_bounds__(256) void attention_last_kernel(AttnArgs a) {
       const f32x4* kr = (const f32x4*)(kp + (long)j * a.ldkv);
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int c = 0; c < 16; ++c) acc += kr[c] * *(const f32x4*)&sq[h][c * 4];
+      for (int c = 0; c < 16; ++c)
+        acc += kr[c] * f32x4{lane_bcast(qm, c * 4), lane_bcast(qm, c * 4 + 1), lane_bcast(qm, c * 4 + 2), lane_bcast(qm, c * 4 + 3)};
       sc = (acc[0] + acc[1]) + (acc[2] + acc[3]) + slope * (float)j;
     }
     const float mn = fmaxf(mx, wave_max(sc));
@@ -897,12 +895,8 @@ __global__ __launch_bounds__(256) void attention_last_kernel(AttnArgs a) {
     l = l * corr + wave_sum(pj);
     o *= corr;
     mx = mn;
-    sp[h][lane] = pj;
-    __builtin_amdgcn_s_waitcnt(0);   // sp is private to this wave; LDS write -> read by other lanes
-    __builtin_amdgcn_wave_barrier();
     const int jn = (n - j0) < 64 ? (n - j0) : 64;
-    for (int jj = 0; jj < jn; ++jj) o += sp[h][jj] * vp[(long)(j0 + jj) * a.ldkv + lane];
-    __builtin_amdgcn_wave_barrier();
+    for (int jj = 0; jj < jn; ++jj) o += lane_bcast(pj, jj) * vp[(long)(j0 + jj) * a.ldkv + lane];   // p_j from registers (no LDS)
   }
   a.out[(long)bc * 256 + h * 64 + lane] = o / l;
 }
@@ -917,8 +911,13 @@ __global__ __launch_bounds__(256) void attention_last_kernel(AttnArgs a) {
 //    one LDS exchange.
 // ------------------------------------------------------------------------------------------------
 
+// Cross-wave exchange of N per-wave values through LDS.  No thread reads LDS with a wave-uniform address: on this MI355X pool a
+// wave-uniform ds_read_b128 returns wrong data when ANOTHER wave on the CU runs K=16 f16 / bf16 MFMAs (another engine with
+// VAPX_FLAG_SPLIT_F16, another process; reproducer: tools/mfma_victim + tools/mfma_aggr, DESIGN.md "co-running f16 MFMA").
+// Every lane fetches one distinct word and the values are broadcast from registers (v_readlane).  4 N <= 64.
 template <int N>
-__device__ __forceinline__ void block_sum(float (&v)[N], float* red /* [4][N] */, int wave, int lane) {
+__device__ __forceinline__ void block_sum(float (&v)[N], float* red /* [64] */, int wave, int lane) {
+  static_assert(4 * N <= 64, "one word per lane");
 #pragma unroll
   for (int i = 0; i < N; ++i) v[i] = wave_sum(v[i]);
   __syncthreads();
@@ -926,11 +925,13 @@ __device__ __forceinline__ void block_sum(float (&v)[N], float* red /* [4][N] */
 #pragma unroll
     for (int i = 0; i < N; ++i) red[wave * N + i] = v[i];
   __syncthreads();
+  const float mine = red[lane];
 #pragma unroll
-  for (int i = 0; i < N; ++i) v[i] = red[i] + red[N + i] + red[2 * N + i] + red[3 * N + i];
+  for (int i = 0; i < N; ++i) v[i] = lane_bcast(mine, i) + lane_bcast(mine, N + i) + lane_bcast(mine, 2 * N + i) + lane_bcast(mine, 3 * N + i);
 }
 template <int N>
 __device__ __forceinline__ void block_max(float (&v)[N], float* red, int wave, int lane) {
+  static_assert(4 * N <= 64, "one word per lane");
 #pragma unroll
   for (int i = 0; i < N; ++i) v[i] = wave_max(v[i]);
   __syncthreads();
@@ -938,32 +939,34 @@ __device__ __forceinline__ void block_max(float (&v)[N], float* red, int wave, i
 #pragma unroll
     for (int i = 0; i < N; ++i) red[wave * N + i] = v[i];
   __syncthreads();
+  const float mine = red[lane];
 #pragma unroll
-  for (int i = 0; i < N; ++i) v[i] = fmaxf(fmaxf(red[i], red[N + i]), fmaxf(red[2 * N + i], red[3 * N + i]));
+  for (int i = 0; i < N; ++i)
+    v[i] = fmaxf(fmaxf(lane_bcast(mine, i), lane_bcast(mine, N + i)), fmaxf(lane_bcast(mine, 2 * N + i), lane_bcast(mine, 3 * N + i)));
 }
 
 // y[s][j] = sum_k WT[k][j] * x[s][k] for the HB streams of the block: the k range is split over the 4
 // waves (64 k each), each lane accumulates 4 adjacent outputs with 16-byte weight loads (a 1 KiB
 // coalesced row per wave instruction), partials are combined through LDS.  Thread j returns y[.][j].
-template <int XS /* floats between consecutive streams in x */, int HB>
-__device__ __forceinline__ void block_matvec(const float* __restrict__ WT, const float* x, float* psum /* [4][HB][256] */,
+// xm[s] = x[s][j]: thread j = 64 w + lane holds exactly element `lane` of its wave's k slice, so the
+// activations are broadcast from registers (v_readlane) and never staged in LDS.
+template <int HB>
+__device__ __forceinline__ void block_matvec(const float* __restrict__ WT, const float (&xm)[HB], float* psum /* [4][HB][256] */,
                                              float (&y)[HB], int j) {
   const int lane = j & 63, w = j >> 6;
   f32x4 part[HB];
 #pragma unroll
   for (int s = 0; s < HB; ++s) part[s] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float* wp = WT + (long)(w * 64) * 256 + lane * 4;
-#pragma unroll 2
+#pragma unroll
   for (int kk = 0; kk < 64; kk += 4) {
     f32x4 wv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) wv[u] = *(const f32x4*)(wp + (long)(kk + u) * 256);
 #pragma unroll
-    for (int s = 0; s < HB; ++s) {
-      f32x4 xv = *(const f32x4*)(x + s * XS + w * 64 + kk);
+    for (int s = 0; s < HB; ++s)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) part[s] += wv[u] * xv[u];
-    }
+      for (int u = 0; u < 4; ++u) part[s] += wv[u] * lane_bcast(xm[s], kk + u);
   }
   __syncthreads();   // psum may still be read from a previous call
 #pragma unroll
@@ -976,27 +979,24 @@ __device__ __forceinline__ void block_matvec(const float* __restrict__ WT, const
 
 template <int HB>
 __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
-  __shared__ __attribute__((aligned(16))) float xs[HB][2][256];  // newest rows of the two towers
-  __shared__ __attribute__((aligned(16))) float hs[HB][256];
   __shared__ __attribute__((aligned(16))) float psum[4 * HB * 256];
-  __shared__ float red[4 * 2 * HB];
+  __shared__ float red[64];
   const int j = threadIdx.x, lane = j & 63, wave = j >> 6;
   const int b0 = blockIdx.x * HB;
   int nb[HB];
+  float xa[HB], xb[HB];   // newest rows of the two towers, element j
 #pragma unroll
   for (int s = 0; s < HB; ++s) {
     int b = b0 + s;
     b = b < a.B ? b : a.B - 1;
     nb[s] = a.bn[b];
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-      xs[s][c][j] = a.x_last_only ? a.x[((long)b * 2 + c) * 256 + j] : a.x[(((long)b * 2 + c) * a.T + nb[s] - 1) * 256 + j];
+    xa[s] = a.x_last_only ? a.x[((long)b * 2) * 256 + j] : a.x[(((long)b * 2) * a.T + nb[s] - 1) * 256 + j];
+    xb[s] = a.x_last_only ? a.x[((long)b * 2 + 1) * 256 + j] : a.x[(((long)b * 2 + 1) * a.T + nb[s] - 1) * 256 + j];
   }
-  __syncthreads();
   // combinator projections
   float ha[HB], hb[HB];
-  block_matvec<512, HB>(a.waT, &xs[0][0][0], psum, ha, j);
-  block_matvec<512, HB>(a.wbT, &xs[0][1][0], psum, hb, j);
+  block_matvec<HB>(a.waT, xa, psum, ha, j);
+  block_matvec<HB>(a.wbT, xb, psum, hb, j);
   // shared LayerNorm on both, exact GELU, sum
   float v[2 * HB];
 #pragma unroll
@@ -1013,16 +1013,16 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
   }
   block_sum<2 * HB>(v, red, wave, lane);
   const float cg = a.cg[j], cb = a.cb[j];
+  float hs[HB];   // combinator output, element j
 #pragma unroll
   for (int s = 0; s < HB; ++s) {
     float ya = (ha[s] - mean[2 * s]) * rsqrtf(v[2 * s] * (1.0f / 256.0f) + 1e-5f) * cg + cb;
     float yb = (hb[s] - mean[2 * s + 1]) * rsqrtf(v[2 * s + 1] * (1.0f / 256.0f) + 1e-5f) * cg + cb;
-    hs[s][j] = gelu_erf(ya) + gelu_erf(yb);
+    hs[s] = gelu_erf(ya) + gelu_erf(yb);
   }
-  __syncthreads();
   // vap_head logits
   float lg[HB];
-  block_matvec<256, HB>(a.hwT, &hs[0][0], psum, lg, j);
+  block_matvec<HB>(a.hwT, hs, psum, lg, j);
   const float hbias = a.hb[j];
 #pragma unroll
   for (int s = 0; s < HB; ++s) lg[s] += hbias;
@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
     for (int r = 0; r < 4; ++r) {
       const float wr = a.aw[r * 256 + j];
 #pragma unroll
-      for (int s = 0; s < HB; ++s) ax[r][s] = wr * hs[s][j];
+      for (int s = 0; s < HB; ++s) ax[r][s] = wr * hs[s];
       block_sum<HB>(ax[r], red, wave, lane);
     }
   }
