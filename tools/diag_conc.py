@@ -58,7 +58,7 @@ kw = {"none": None, "fp32": {}, "fp32other": {}, "split": {"split_f16": True}, "
 agg = engine.Engine(blob, HZ, CTX, max_streams=S, mode=EMODE, **kw) if kw is not None else None
 child = None
 if aggr.startswith("mfma"):      # tools/mfma_aggr <f16|f32|bf16> in another process
-    child = subprocess.Popen([__file__.rsplit("/", 1)[0] + "/mfma_aggr", aggr[4:], "60"], stdout=subprocess.PIPE, text=True)
+    child = subprocess.Popen([__file__.rsplit("/", 1)[0] + "/mfma_aggr", aggr[4:], "600"], stdout=subprocess.PIPE, text=True)
     child.stdout.readline()
     time.sleep(0.5)
 elif aggr.startswith("proc"):
