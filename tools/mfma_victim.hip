@@ -38,7 +38,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // mode 3: packed-fp32 VALU FMA chains (v_pk_fma_f32) fed from global + LDS like a mat-vec, plus cross-lane DPP reductions
 // FEAT bits: 1 weights from global memory, 2 activations from LDS, 4 cross-lane reduction at the end
 // PAT (how the LDS activations are read): 0 wave-uniform 16-byte reads, 1 wave-uniform 4-byte reads (strided), 2 one distinct word
-// per lane + v_readlane broadcast, 3 per-lane distinct 16-byte reads
+// per lane + v_readlane broadcast, 3 per-lane distinct 16-byte reads, 4 wave-uniform 8-byte reads
 template <int FEAT, int PAT = 0>
 __global__ __launch_bounds__(256) void valu_work(const float* __restrict__ w, float* out, int iters) {
   __shared__ __attribute__((aligned(16))) float xs[1024];
@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void valu_work(const float* __restrict__ w, fl
                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), 17)),
                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), 40)),
                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), 61))};
-      } else xv = *(const f32x4*)(xs + ((it * 4 + (tid & 63) * 4) & 1020));
+      } else if (PAT == 3) xv = *(const f32x4*)(xs + ((it * 4 + (tid & 63) * 4) & 1020));
+      else { const f32x2 lo = *(const f32x2*)(xs + ((it * 2) & 1022)), hi2 = *(const f32x2*)(xs + ((it * 2 + 512) & 1022)); xv = f32x4{lo[0], lo[1], hi2[0], hi2[1]}; }   // PAT 4: wave-uniform 8-byte reads
     }
     else xv = f32x4{0.01f, -0.02f, 0.03f, 0.015f} * (1.0f + (it & 15) * 0.001f);
     for (int u = 0; u < 4; ++u) { acc0 += wv0 * xv[u]; acc1 += wv1 * xv[3 - u]; }
@@ -92,7 +93,8 @@ int main(int argc, char** argv) {
     else if (mode == 7) hipLaunchKernelGGL(valu_work<0>, dim3(wgs), dim3(256), 0, nullptr, w, out, 4096);
     else if (mode == 8) hipLaunchKernelGGL((valu_work<2, 1>), dim3(wgs), dim3(256), 0, nullptr, w, out, 4096);
     else if (mode == 9) hipLaunchKernelGGL((valu_work<2, 2>), dim3(wgs), dim3(256), 0, nullptr, w, out, 4096);
-    else hipLaunchKernelGGL((valu_work<2, 3>), dim3(wgs), dim3(256), 0, nullptr, w, out, 4096);
+    else if (mode == 10) hipLaunchKernelGGL((valu_work<2, 3>), dim3(wgs), dim3(256), 0, nullptr, w, out, 4096);
+    else hipLaunchKernelGGL((valu_work<2, 4>), dim3(wgs), dim3(256), 0, nullptr, w, out, 4096);
     (void)hipMemcpy(l == 0 ? ref.data() : got.data(), out, n * 4, hipMemcpyDeviceToHost);
     if (l > 0) {
       long d = 0;
