@@ -308,7 +308,8 @@ def paced_latency(cpc, vap, hz, ctx_sec, local_rank, seconds, target_ms=10.0, ma
     sub-batches phase-staggered over the frame period (50 ms at 20 Hz) on a wall-clock schedule for `seconds`;
     latency of a sub-tick = its scheduled audio-ready time -> results on the host (pinned H2D + kernels + D2H + sync,
     including any wait behind a late predecessor).  A short calibration picks the largest G x Ssub whose sub-tick service
-    time keeps the GPU under `max_util`; if the paced run misses p99 <= target it is repeated one group smaller."""
+    time keeps the GPU under `max_util`; if the paced run misses p99 <= target or the utilisation bound it is repeated with 64 fewer
+    streams per sub-batch (up to twice), then one group smaller."""
     from vap_realtime_amd import engine, weights as W
     period = 1.0 / hz
     hop = 16000 // hz
@@ -316,7 +317,8 @@ def paced_latency(cpc, vap, hz, ctx_sec, local_rank, seconds, target_ms=10.0, ma
     blob = W.pack_blob(cpc, vap)
     Ssub_opts = (1024, 768, 512)
     Gmax = 12
-    eng = engine.Engine(blob, hz, ctx_sec, max_streams=Gmax * max(Ssub_opts), max_batch=max(Ssub_opts), device_id=local_rank)
+    eng = engine.Engine(blob, hz, ctx_sec, max_streams=Gmax * max(Ssub_opts), max_batch=max(Ssub_opts), device_id=local_rank,
+                        groups=2)   # two intra-tick overlap groups: -1.4 % sub-tick time at 1024 streams (joined inside every step)
     NF = 8
     base = synth_audio(list(range(64)), max(Ssub_opts), hop, NF)          # [NF, Ssub, 2, hop]
     pin_in = [engine.pinned_empty((max(Ssub_opts), 2, hop)) for _ in range(NF)]
@@ -351,7 +353,7 @@ def paced_latency(cpc, vap, hz, ctx_sec, local_rank, seconds, target_ms=10.0, ma
     G, Ssub = best
     import gc
     gc.disable()                                       # a collector pause inside the 50 ms schedule would be charged to the engine
-    for attempt in range(2):
+    for attempt in range(4):
         for s in range(G * Ssub):                     # every trial starts from clean streams (queued, applied by the next step)
             eng.reset_stream(s)
         idsets = [np.arange(g * Ssub, (g + 1) * Ssub, dtype=np.int32) for g in range(G)]
@@ -379,11 +381,15 @@ def paced_latency(cpc, vap, hz, ctx_sec, local_rank, seconds, target_ms=10.0, ma
                "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)), "max_ms": float(lat.max()),
                "gpu_busy_fraction": busy / wall, "late_fraction": float((lat > target_ms).mean())}
         out["runs"].append(run)
-        if run["p99_ms"] <= target_ms and run["gpu_busy_fraction"] <= max_util + 0.02:
+        if run["p99_ms"] <= target_ms and run["gpu_busy_fraction"] <= max_util:
             out["sustained_streams"] = G * Ssub
             out.update({k: run[k] for k in ("groups", "sub_tick_streams", "p50_ms", "p99_ms", "max_ms", "gpu_busy_fraction")})
             break
-        G -= 1
+        # too busy or too late: shed 64 streams per sub-batch (same schedule) and measure again; after three such steps drop a group
+        if attempt < 2 and Ssub > 640:
+            Ssub -= 64
+        else:
+            G -= 1
         if G < 1:
             break
     else:
