@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
@@ -42,6 +43,17 @@ namespace {
 constexpr int NBUF = 5;   // frame buffers per stream: filling + waiting + in flight + two of slack for a client that bursts after a stall
 constexpr int PAIR_BYTES = 16;                 // one sample of both channels: f64 ch1, f64 ch2 (util.py:52-62)
 enum BufState : int { B_FREE = 0, B_FILLING = 1, B_READY = 2, B_INFLIGHT = 3 };
+
+// Timed condition wait.  Under ThreadSanitizer the wait goes through system_clock (pthread_cond_timedwait): gcc-11's libtsan does
+// not intercept pthread_cond_clockwait, loses the unlock inside it and then reports every access under that mutex as a race.
+template <class Rep, class Period>
+inline void cv_wait_for(std::condition_variable& cv, std::unique_lock<std::mutex>& lk, std::chrono::duration<Rep, Period> d) {
+#if defined(__SANITIZE_THREAD__)
+  cv.wait_until(lk, std::chrono::system_clock::now() + d);
+#else
+  cv.wait_for(lk, d);
+#endif
+}
 
 double mono_now() {
   timespec ts;
@@ -119,13 +131,13 @@ struct Hist {   // log2-spaced latency histogram, 8 sub-buckets per octave from 
 
 struct Slot {
   int fd_in = -1;
-  uint32_t gen = 0;                       // bumped per connection: queued frames of a dead connection are dropped
+  std::atomic<uint32_t> gen{0};           // bumped per connection: queued frames of a dead connection are dropped (read by the tick thread)
   std::atomic<int> state[NBUF];
   double t_ready[NBUF] = {};
   int wbuf = -1, fill = 0;                // rx thread only
   uint8_t partial[PAIR_BYTES]; int npartial = 0;
   std::vector<uint8_t> backlog;           // bytes received while no buffer was free
-  bool paused = false;
+  std::atomic<bool> paused{false};        // written by the slot's rx / accept thread, read by whoever frees a buffer
   std::mutex lmu;                         // guards listeners
   std::vector<int> listeners;
   Slot() { for (auto& s : state) s = B_FREE; }
@@ -256,8 +268,8 @@ void release_buf(vapx_ingest* g, int slot, int buf) {
   bool need = false;
   {
     std::lock_guard<std::mutex> lk(g->resume_mu[r]);
-    // `paused` is owned by the rx thread; a stale read only costs a spurious wake-up
-    if (g->slots[slot].paused) { g->resume[r].push_back(slot); need = true; }
+    // a stale read only costs a spurious wake-up
+    if (g->slots[slot].paused.load(std::memory_order_acquire)) { g->resume[r].push_back(slot); need = true; }
   }
   if (need) kick(g->wake[r]);
 }
@@ -272,7 +284,7 @@ void drop_input(vapx_ingest* g, int r, int slot) {
   {
     std::lock_guard<std::mutex> lk(g->slots_mu);
     s.fd_in = -1;
-    ++s.gen;                                // frames of this connection still queued are dropped by the tick thread
+    s.gen.fetch_add(1);                     // frames of this connection still queued are dropped by the tick thread
   }
   g->in_conns.fetch_sub(1);
 }
@@ -340,7 +352,7 @@ size_t feed(vapx_ingest* g, int slot, const uint8_t* p, size_t n) {
       s.wbuf = -1; s.fill = 0;
       {
         std::lock_guard<std::mutex> lk(g->ready_mu);
-        g->ready.push_back({slot, b, s.gen, t});
+        g->ready.push_back({slot, b, s.gen.load(std::memory_order_relaxed), t});
       }
       g->ready_cv.notify_one();
     }
@@ -582,10 +594,10 @@ void tick_main(vapx_ingest* g) {
     {
       std::unique_lock<std::mutex> lk(g->ready_mu);
       if (g->ready.empty() && g->resets.empty()) {
-        if (pending.empty()) g->ready_cv.wait_for(lk, std::chrono::milliseconds(20));
+        if (pending.empty()) cv_wait_for(g->ready_cv, lk, std::chrono::milliseconds(20));
         else {
           const double left = first_ready + max_wait - mono_now();
-          if (left > 0) g->ready_cv.wait_for(lk, std::chrono::microseconds((long)(left * 1e6) + 1));
+          if (left > 0) cv_wait_for(g->ready_cv, lk, std::chrono::microseconds((long)(left * 1e6) + 1));
         }
       }
       fresh.swap(g->ready);
@@ -594,7 +606,7 @@ void tick_main(vapx_ingest* g) {
     for (auto& rs : resets)
       if (g->reset) g->reset(g->user, rs.second ? -(rs.first + 1) : rs.first);   // negative = carry only
     for (auto& rd : fresh) {
-      if (rd.gen != g->slots[rd.slot].gen) { release_buf(g, rd.slot, rd.buf); continue; }   // connection already gone
+      if (rd.gen != g->slots[rd.slot].gen.load(std::memory_order_acquire)) { release_buf(g, rd.slot, rd.buf); continue; }   // connection already gone
       if (pending.empty()) first_ready = rd.t;
       pending.push_back(rd);
     }
@@ -608,7 +620,7 @@ void tick_main(vapx_ingest* g) {
     // the oldest frame is already older than that and ticks run back to back)
     if (now < earliest_next && (int)pending.size() < g->max_batch && now - first_ready < max_wait) {
       std::unique_lock<std::mutex> lk(g->ready_mu);
-      if (g->ready.empty()) g->ready_cv.wait_for(lk, std::chrono::microseconds((long)((earliest_next - now) * 1e6) + 1));
+      if (g->ready.empty()) cv_wait_for(g->ready_cv, lk, std::chrono::microseconds((long)((earliest_next - now) * 1e6) + 1));
       continue;
     }
 
@@ -624,7 +636,7 @@ void tick_main(vapx_ingest* g) {
     while (!pending.empty()) {
       Ready rd = pending.front();
       pending.pop_front();
-      if (rd.gen != g->slots[rd.slot].gen) { release_buf(g, rd.slot, rd.buf); continue; }
+      if (rd.gen != g->slots[rd.slot].gen.load(std::memory_order_acquire)) { release_buf(g, rd.slot, rd.buf); continue; }
       if (in_batch[rd.slot] || (int)job.rows.size() >= g->max_batch) { later.push_back(rd); continue; }
       in_batch[rd.slot] = 1;
       g->slots[rd.slot].state[rd.buf].store(B_INFLIGHT);
