@@ -1,0 +1,42 @@
+"""Nothing the engine consumes is stale: with VAPX_POISON_SCRATCH every scratch buffer is refilled with NaN bit patterns before each
+step and the context rings start as NaNs, so a kernel that reads a row, a padding lane or a window slot which no kernel of the same
+tick (or no earlier frame) wrote turns the outputs non-finite.  The goldens must still be met."""
+import os
+
+import numpy as np
+import pytest
+
+from golden_util import Case
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.mark.parametrize("name,keys,kw", [
+    ("multi3", ("p_now", "p_future", "vad", "logits"), {}),
+    ("vap50", ("p_now", "p_future", "vad", "logits"), {}),                       # long-window chain, window fills and slides
+    ("vap50", ("p_now", "p_future", "vad", "logits"), {"unfused_proj": True}),   # GEMM-chain variant
+    ("nod20", ("e",), {}),                                                         # full last layer + all-rows combinator
+    ("multi3", ("p_now", "p_future", "vad", "logits"), {"split_f16": True}),
+    ("multi3", ("p_now", "p_future", "vad", "logits"), {"unfused_last_row": True, "unfused_conv": True, "materialize_x0": True}),
+])
+def test_goldens_with_poisoned_scratch(name, keys, kw):
+    from vap_realtime_amd import engine, weights as W
+    c = Case(name)
+    os.environ["VAPX_POISON_SCRATCH"] = "1"
+    try:
+        eng = engine.Engine(W.pack_blob(c.cpc_sd, c.vap_sd, c.mode), c.frame_hz, c.ctx_sec, max_streams=len(c.streams) + 2, mode=c.mode, **kw)
+    finally:
+        del os.environ["VAPX_POISON_SCRATCH"]
+    ids = np.arange(len(c.streams), dtype=np.int32)[::-1].copy() + 1            # not the identity mapping, slot 0 stays unused
+    order = ids - 1
+    worst = 0.0
+    for f in range(c.n_frames):
+        raw = eng.step(np.ascontiguousarray(c.new_samples(f)[order]), ids)
+        assert np.isfinite(raw).all(), f"{name} frame {f}: non-finite outputs with poisoned scratch"
+        o = engine.split_outputs(raw)
+        for k in keys:
+            want = c.z[k][f][order]
+            worst = max(worst, float(np.abs(o[k].reshape(want.shape) - want).max()))
+    eng.close()
+    assert worst <= TOL, (name, kw, worst)

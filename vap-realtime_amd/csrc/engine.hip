@@ -91,6 +91,9 @@ struct vapx_engine {
   int n_groups = 1;
   int ffn_tile_rows = 0;   // tuning knob (env VAPX_FFN_TILE): 32 or 64 rows per FFN-block workgroup
   int group0_streams = 0;    // experiment knob (env VAPX_GROUP0_STREAMS): size of the first of two overlap groups
+  // debug knob (env VAPX_POISON_SCRATCH): every scratch buffer is refilled with NaN bit patterns before each step and the rings start as
+  // NaNs, so a kernel that consumes anything it (or an earlier kernel of the same tick) did not write shows up as a non-finite output
+  std::vector<std::pair<void*, size_t>> poison;
   int split_mask = 15;       // diagnostic knob (env VAPX_SPLIT_MASK): which kernel families of a VAPX_FLAG_SPLIT_F16 engine run split (1 GEMM, 2 attn_block, 4 FFN block, 8 unfused conv tail)
   bool force_long = false;   // experiment knob (env VAPX_FORCE_LONG): short windows through the long-window kernel chain
   unsigned long long* ffn_trace = nullptr;   // env VAPX_FFN_TRACE=<file>: phase stamps of the layer-0 FFN block's workgroups
@@ -829,6 +832,17 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
   CR(hipHostMalloc((void**)&h->ids_pinned, B * sizeof(int), hipHostMallocDefault));
   CR(hipHostMalloc((void**)&h->audio_pinned, B * 2 * h->L * sizeof(float), hipHostMallocDefault));
   h->id_stamp.assign(S, 0u);
+  if (getenv("VAPX_POISON_SCRATCH")) {
+    CR(hipMemset(h->ring, 0xFF, S * 2 * T * 256 * sizeof(float)));          // rows beyond frames_seen are never read: prove it
+    CR(hipMemset(h->ring_qkv, 0xFF, S * 2 * T * 768 * sizeof(float)));
+    auto add = [&](float* q, size_t n) { h->poison.push_back({q, n * sizeof(float)}); };
+    add(h->sc.z, B * 2 * h->ncpc * 256); add(h->sc.lstm_out, B * 2 * h->ncpc * 256); add(h->sc.gx, B * 2 * h->ncpc * 1024); add(h->sc.e, B * 2 * 256);
+    for (int i = 0; i < 5; ++i) add(h->sc.xl[i], rows * 256);
+    add(h->sc.xn, rows * 256); add(h->sc.xmid, rows * 256); add(h->sc.att, rows * 256); add(h->sc.qkv, rows * 768); add(h->sc.qx, rows * 256);
+    add(h->sc.kvx, rows * 512);
+    for (int i = 0; i < 6; ++i) add(h->sc.last[i], B * 2 * 256);
+    add(h->sc.en, B * 2 * 256); add(h->sc.qkv_new, B * 2 * 768); add(h->sc.lffn, B * 2 * 768); add(h->out_dev, B * VAPX_OUT_STRIDE);
+  }
   if (const char* ev = getenv("VAPX_FFN_TILE")) h->ffn_tile_rows = atoi(ev);
   if (const char* ev = getenv("VAPX_GROUP0_STREAMS")) h->group0_streams = atoi(ev);
   if (getenv("VAPX_FORCE_LONG")) h->force_long = true;
@@ -888,6 +902,11 @@ int vapx_step(vapx_handle h, int32_t n, const int32_t* stream_ids, const float* 
   if (h->deferred_pending && (!defer_join || n != h->last_B || G != h->last_G || !h->pending_resets.empty())) {
     rc = join_deferred(h, st);
     if (rc) return rc;
+  }
+  if (!h->poison.empty()) {
+    rc = join_deferred(h, st);
+    if (rc) return rc;
+    for (auto& pb : h->poison) HIPCHK(h, hipMemsetAsync(pb.first, 0xFF, pb.second, st));
   }
   if (!lead) { rc = flush_resets(h, st); if (rc) return rc; }
   const int* ids = nullptr;
@@ -1009,7 +1028,14 @@ int vapx_attach_trunk(vapx_handle f, vapx_handle lead) {
   // a follower never runs the encoder: release its encoder scratch and LSTM / carry state
   float** drop[] = {&f->sc.h0, &f->sc.h1, &f->sc.h2, &f->sc.h3, &f->sc.z, &f->sc.gx, &f->sc.lstm_out, &f->audio_dev,
                     &f->h_state, &f->c_state, &f->carry};
-  for (float** p : drop) { if (*p) (void)hipFree(*p); *p = nullptr; }
+  for (float** p : drop) {
+    if (*p) {
+      f->poison.erase(std::remove_if(f->poison.begin(), f->poison.end(), [&](const std::pair<void*, size_t>& pb) { return pb.first == (void*)*p; }),
+                      f->poison.end());
+      (void)hipFree(*p);
+    }
+    *p = nullptr;
+  }
   f->trunk = lead;
   lead->followers.push_back(f);
   return VAPX_OK;

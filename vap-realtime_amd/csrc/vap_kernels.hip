@@ -1086,6 +1086,8 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
       out[11] = vd[2 * s] + a.vb[0];          // va_classifier outputs before the sigmoid (VapGPT.forward returns these)
       out[12] = vd[2 * s + 1] + a.vb[0];
       out[10] = (float)nb[s];
+      out[14] = 0.f; out[15] = 0.f;            // reserved slots: the whole row is defined, whatever the buffer held before
+      if (a.mode == 0) { out[6] = 0.f; out[7] = 0.f; out[8] = 0.f; out[9] = 0.f; }
       if (a.mode != 0) {
         int nr = a.mode == 1 ? 3 : 4;
         float z[4], zm = -1e30f, zs = 0.f;
