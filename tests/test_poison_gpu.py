@@ -40,3 +40,37 @@ def test_goldens_with_poisoned_scratch(name, keys, kw):
             worst = max(worst, float(np.abs(o[k].reshape(want.shape) - want).max()))
     eng.close()
     assert worst <= TOL, (name, kw, worst)
+
+
+def test_no_out_of_bounds_writes_around_any_engine_buffer():
+    """VAPX_GUARD_ZONES: 4 KiB canary zones on both sides of every device allocation of the engine; after full-window runs of the
+    short-window, long-window and nod paths at a batch that is not a multiple of any tile size, no canary byte has changed."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, ".")
+from vap_realtime_amd import engine, synth, weights as W
+total = 0
+for hz, ctx, mode, S in ((20, 2.5, "vap", 77), (50, 5.0, "vap", 21), (20, 2.5, "nod", 33), (10, 5.0, "bc", 19), (20, 2.5, "vap", 1101)):
+    cpc, vap = W.synthetic_weights(3, hz, mode=mode)
+    for kw in ({}, {"groups": 2}, {"split_f16": True}, {"unfused_last_row": True, "unfused_conv": True, "materialize_x0": True}):
+        if S > 1000 and kw:
+            continue
+        eng = engine.Engine(W.pack_blob(cpc, vap, mode), hz, ctx, max_streams=S, mode=mode, **kw)
+        hop = 16000 // hz
+        audio = synth.dialogue_batch(list(range(S)), hop * 4)
+        for t in range(int(ctx * hz) + 3):
+            out = eng.step(np.ascontiguousarray(audio[:, :, (t % 4) * hop:(t % 4 + 1) * hop]))
+        assert np.isfinite(out).all()
+        v = eng.peek("guard_violations", (1,))[0]
+        assert v >= 0, "guard zones not enabled"
+        total += int(v)
+        assert v == 0, (hz, mode, S, kw, v)
+        eng.close()
+print("guard zones intact:", total)
+'''
+    env = dict(os.environ, VAPX_GUARD_ZONES="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "guard zones intact: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -151,11 +152,57 @@ int fail(vapx_engine* h, int code, const char* fmt, ...) {
     if (_e != hipSuccess) return fail(h, VAPX_E_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
   } while (0)
 
+// debug knob (env VAPX_GUARD_ZONES): every device allocation of the engine gets a 4 KiB canary zone on both sides; vapx_peek("guard_violations")
+// counts the canary bytes that changed, i.e. out-of-bounds writes just past (or before) a buffer
+constexpr size_t kGuardBytes = 4096;
+bool guard_enabled() { static const bool on = getenv("VAPX_GUARD_ZONES") != nullptr; return on; }
+struct GuardRec { char* base; size_t bytes; };
+std::mutex g_guard_mu;
+std::vector<GuardRec> g_guards;
+
 template <typename T>
 hipError_t dalloc(T** p, size_t n, bool zero = true) {
-  hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+  const size_t bytes = n * sizeof(T);
+  if (!guard_enabled()) {
+    hipError_t e = hipMalloc((void**)p, bytes);
+    if (e != hipSuccess) return e;
+    return zero ? hipMemset(*p, 0, bytes) : hipSuccess;
+  }
+  char* base = nullptr;
+  hipError_t e = hipMalloc((void**)&base, bytes + 2 * kGuardBytes);
   if (e != hipSuccess) return e;
-  return zero ? hipMemset(*p, 0, n * sizeof(T)) : hipSuccess;
+  if ((e = hipMemset(base, 0xA5, kGuardBytes)) != hipSuccess) return e;
+  if ((e = hipMemset(base + kGuardBytes + bytes, 0xA5, kGuardBytes)) != hipSuccess) return e;
+  if (zero && bytes && (e = hipMemset(base + kGuardBytes, 0, bytes)) != hipSuccess) return e;
+  *p = (T*)(base + kGuardBytes);
+  std::lock_guard<std::mutex> lk(g_guard_mu);
+  g_guards.push_back({base, bytes});
+  return hipSuccess;
+}
+void dfree(void* p) {
+  if (!p) return;
+  if (guard_enabled()) {
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    for (size_t i = 0; i < g_guards.size(); ++i)
+      if (g_guards[i].base + kGuardBytes == (char*)p) {
+        (void)hipFree(g_guards[i].base);
+        g_guards.erase(g_guards.begin() + (long)i);
+        return;
+      }
+  }
+  (void)hipFree(p);
+}
+// canary bytes overwritten around ANY live allocation of the process's engines (device must be idle)
+long guard_violations() {
+  std::lock_guard<std::mutex> lk(g_guard_mu);
+  std::vector<unsigned char> host(kGuardBytes);
+  long bad = 0;
+  for (const GuardRec& r : g_guards)
+    for (int side = 0; side < 2; ++side) {
+      if (hipMemcpy(host.data(), side ? r.base + kGuardBytes + r.bytes : r.base, kGuardBytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+      for (unsigned char c : host) bad += c != 0xA5;
+    }
+  return bad;
 }
 
 // true when p is page-locked host memory known to HIP (hipHostMalloc / hipHostRegister), i.e. a real async copy source / target
@@ -714,17 +761,15 @@ void vapx_destroy(vapx_handle h) {
     if (!host.empty() && hipMemcpy(host.data(), h->ffn_trace, host.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
       if (FILE* f = fopen(h->ffn_trace_path.c_str(), "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
     }
-    (void)hipFree(h->ffn_trace);
+    dfree(h->ffn_trace);
   }
   float* fp[] = {h->w, h->ring, h->ring_qkv, h->h_state, h->c_state, h->carry, h->audio_dev, h->out_dev, h->sc.h0, h->sc.h1, h->sc.h2, h->sc.h3,
                  h->sc.z, h->sc.lstm_out, h->sc.e, h->sc.xl[0], h->sc.xl[1], h->sc.xl[2], h->sc.xl[3], h->sc.xl[4], h->sc.xn, h->sc.xmid, h->sc.att,
                  h->sc.qkv, h->sc.qx, h->sc.kvx, h->sc.ffn, h->sc.gx, h->sc.last[0], h->sc.last[1], h->sc.last[2],
                  h->sc.last[3], h->sc.last[4], h->sc.last[5], h->sc.en, h->sc.qkv_new, h->sc.lffn};
-  for (float* p : fp)
-    if (p) (void)hipFree(p);
+  for (float* p : fp) dfree(p);
   int* ip[] = {h->frames_seen, h->ids_dev, h->sc.bn, h->sc.bhead, h->sc.rot};
-  for (int* p : ip)
-    if (p) (void)hipFree(p);
+  for (int* p : ip) dfree(p);
   if (h->out_pinned) (void)hipHostFree(h->out_pinned);
   if (h->ids_pinned) (void)hipHostFree(h->ids_pinned);
   if (h->audio_pinned) (void)hipHostFree(h->audio_pinned);
@@ -1032,7 +1077,7 @@ int vapx_attach_trunk(vapx_handle f, vapx_handle lead) {
     if (*p) {
       f->poison.erase(std::remove_if(f->poison.begin(), f->poison.end(), [&](const std::pair<void*, size_t>& pb) { return pb.first == (void*)*p; }),
                       f->poison.end());
-      (void)hipFree(*p);
+      dfree(*p);
     }
     *p = nullptr;
   }
@@ -1204,6 +1249,10 @@ int64_t vapx_peek(vapx_handle h, const char* name, float* dst, size_t max_floats
   const int* P = h->P;
   const float* src = nullptr;
   size_t n = 0;
+  if (!strcmp(name, "guard_violations")) {   // debug: see VAPX_GUARD_ZONES
+    dst[0] = guard_enabled() ? (float)guard_violations() : -1.f;
+    return 1;
+  }
   if (!strcmp(name, "h0")) { src = h->sc.h0; n = B * 2 * (P[0] + 4) * 256; }
   else if (!strcmp(name, "h1")) { src = h->sc.h1; n = B * 2 * (P[1] + 2) * 256; }
   else if (!strcmp(name, "h2") || !strcmp(name, "h3")) {
