@@ -49,7 +49,7 @@ def dialogue(stream_id: int, n_samples: int, seed_base: int = 1000) -> np.ndarra
         gate = np.repeat(state[c], seg)[:n_samples].astype(np.float64)
         # 10 ms raised-cosine smoothing of the on/off gate
         k = np.hanning(321); k /= k.sum()
-        gate = np.convolve(gate, k, mode="same")
+        gate = np.convolve(gate, k, mode="full")[160:160 + n_samples]   # == mode "same", also for clips shorter than the kernel
         noise = 1e-3 * rng.standard_normal(n_samples)
         out[c] = (gate * voiced + noise).astype(np.float32)
     return out
