@@ -214,7 +214,9 @@ int vapx_aggregate(int64_t rows, const float* probs, int32_t from_bin, int32_t t
 /* Copy an internal scratch buffer of the LAST vapx_step to the host (per-layer parity tests).
  * name: "h0".."h3","z","lstm_out","e","x0","o","stereo0".."stereo2"; returns the number of
  * floats written (<= max_floats) or a negative error.  "h2"/"h3" need VAPX_FLAG_UNFUSED_CONV and
- * "stereo2" needs VAPX_FLAG_FULL_LAST_LAYER (the default path never materialises them). */
+ * "stereo2" needs VAPX_FLAG_FULL_LAST_LAYER (the default path never materialises them).
+ * Debug: "guard_violations" writes one float, the number of canary bytes overwritten around the process's engine allocations (-1 unless
+ * the library was started with VAPX_GUARD_ZONES=1; INTEGRATION.md "Debug and experiment knobs"). */
 int64_t vapx_peek(vapx_handle h, const char* name, float* dst, size_t max_floats);
 
 /* Standalone fp32-MFMA GEMM used by every dense contraction of the path (kernel unit tests):
