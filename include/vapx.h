@@ -275,7 +275,7 @@ typedef struct vapx_ingest_config {
   int32_t bind_any;         /* 0 = 127.0.0.1 like the reference, 1 = 0.0.0.0 */
   double gain;              /* audio_gain, 1.0 = off */
   int32_t target_util_pct;  /* pacing: the next tick starts no earlier than (previous tick's start + its duration * 100 / pct), so the
-                               engine stays at most pct % busy and batches grow instead of the queue (0 = 75; 100 = back-to-back) */
+                               engine stays at most pct % busy and batches grow instead of the queue (0 = 90; 100 = back-to-back) */
   int32_t reserved;
 } vapx_ingest_config;
 

@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--max-wait-ms", type=float, default=2.0)
     ap.add_argument("--min-batch", type=int, default=0)
     ap.add_argument("--max-batch", type=int, default=0)
-    ap.add_argument("--target-util", type=float, default=0.75)
+    ap.add_argument("--target-util", type=float, default=0.9)
     ap.add_argument("--rx-threads", type=int, default=4)
     ap.add_argument("--tx-threads", type=int, default=4)
     ap.add_argument("--client-threads", type=int, default=8)

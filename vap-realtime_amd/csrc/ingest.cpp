@@ -586,7 +586,7 @@ void tick_main(vapx_ingest* g) {
   double first_ready = 0.0;
   int jsel = 0;
   const double max_wait = (g->cfg.max_wait_us > 0 ? g->cfg.max_wait_us : 2000) * 1e-6;
-  const double util = (g->cfg.target_util_pct > 0 ? std::min(g->cfg.target_util_pct, 100) : 75) * 0.01;
+  const double util = (g->cfg.target_util_pct > 0 ? std::min(g->cfg.target_util_pct, 100) : 90) * 0.01;   // 90: measured best at the edge (6144 streams: client p99 12.6 ms vs 19.0 at 75, 16.0 unpaced)
   double earliest_next = 0.0;              // pacing: previous tick's start + its duration / util
   while (!g->stop.load()) {
     std::vector<Ready> fresh;

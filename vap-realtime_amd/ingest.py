@@ -42,7 +42,7 @@ _RESET_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32)
 class NativeServer:
     def __init__(self, eng: "_engine.Engine", port_in: int = 50007, port_out: int = 50008, gain: float = 1.0, max_wait_s: float = 0.002,
                  min_batch: int = 0, reset_on_connect: bool = True, broadcast: Optional[bool] = None, rx_threads: int = 0,
-                 tx_threads: int = 0, bind_any: bool = False, target_util: float = 0.75):
+                 tx_threads: int = 0, bind_any: bool = False, target_util: float = 0.9):
         self.lib = _engine.load_library()
         self._keep = [eng]
         cfg = self._cfg(port_in, port_out, gain, max_wait_s, min_batch, reset_on_connect, broadcast, rx_threads, tx_threads, bind_any, target_util)
@@ -54,7 +54,7 @@ class NativeServer:
         self._ports()
 
     @staticmethod
-    def _cfg(port_in, port_out, gain, max_wait_s, min_batch, reset_on_connect, broadcast, rx_threads, tx_threads, bind_any, target_util=0.75):
+    def _cfg(port_in, port_out, gain, max_wait_s, min_batch, reset_on_connect, broadcast, rx_threads, tx_threads, bind_any, target_util=0.9):
         return _IngestConfig(C.sizeof(_IngestConfig), port_in, port_out, rx_threads, tx_threads, int(max_wait_s * 1e6), min_batch,
                              1 if reset_on_connect else 0, -1 if broadcast is None else int(bool(broadcast)), int(bool(bind_any)), gain,
                              int(round(target_util * 100)), 0)
