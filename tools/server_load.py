@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--rx-threads", type=int, default=4)
     ap.add_argument("--tx-threads", type=int, default=4)
     ap.add_argument("--client-threads", type=int, default=8)
+    ap.add_argument("--groups", type=int, default=2, help="intra-tick overlap groups of the engine (what vap_realtime_amd.serve uses: 2)")
     ap.add_argument("--repeat", type=int, default=1, help="run the load generator this many times against the SAME server (slot reuse, resets at scale)")
     ap.add_argument("--python", action="store_true", help="serve with the Python front-end instead of the native one")
     ap.add_argument("--fake", action="store_true", help="native front-end over a trivial step function (plumbing only, no GPU)")
@@ -64,7 +65,7 @@ def main():
             srv = ManyStreamServer(vap, port_in=0, port_out=0, max_wait_s=args.max_wait_ms * 1e-3).start()
             kind = "Python front-end (server.ManyStreamServer)"
         else:
-            eng = engine.Engine(W.pack_blob(cpc, vap_sd), args.hz, args.ctx_sec, max_streams=S, max_batch=args.max_batch or None)
+            eng = engine.Engine(W.pack_blob(cpc, vap_sd), args.hz, args.ctx_sec, max_streams=S, max_batch=args.max_batch or None, groups=args.groups)
             srv = ingest.NativeServer(eng, port_in=0, port_out=0, max_wait_s=args.max_wait_ms * 1e-3, min_batch=args.min_batch,
                                       rx_threads=args.rx_threads, tx_threads=args.tx_threads, target_util=args.target_util)
             kind = "native front-end (vapx_ingest_*) + engine"
