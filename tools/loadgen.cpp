@@ -101,6 +101,8 @@ int main(int argc, char** argv) {
 
   std::atomic<bool> stop{false};
   std::atomic<long> frames_sent{0}, frames_answered{0}, late{0}, slipped{0};
+  std::atomic<long> max_send_lag_us{0}, max_recv_gap_us{0}, max_send_call_us{0};   // the load generator's own stalls (so they are not blamed on the server)
+  auto amax = [](std::atomic<long>& a, long v) { long m = a.load(); while (v > m && !a.compare_exchange_weak(m, v)) {} };
   std::mutex lat_mu;
   std::vector<float> lats;
   lats.reserve((size_t)(S * hz * seconds * 1.1));
@@ -121,6 +123,7 @@ int main(int argc, char** argv) {
       q.pop();
       if (e.t >= t_end) continue;
       double n = now_s();
+      if (n > e.t) amax(max_send_lag_us, (long)((n - e.t) * 1e6));
       if (n - e.t > 0.5 * period / packets_per_frame + 2e-3) { e.t = n; slipped.fetch_add(1); }   // fell behind: re-base — a microphone cannot burst either
       while (n < e.t) {
         if (e.t - n > 2e-4) usleep((useconds_t)((e.t - n) * 5e5));
@@ -132,11 +135,13 @@ int main(int argc, char** argv) {
         std::lock_guard<std::mutex> lk(st[e.s].mu);
         st[e.s].sent.push_back(now_s());
       }
+      const double t_call = now_s();
       while (left) {
         ssize_t w = send(st[e.s].fd_in, p, left, MSG_NOSIGNAL);
         if (w <= 0) { if (errno == EINTR) continue; stop.store(true); break; }
         p += w; left -= (size_t)w;
       }
+      amax(max_send_call_us, (long)((now_s() - t_call) * 1e6));
       if (++e.pk == packets_per_frame) {
         e.pk = 0;
         ++e.frame;
@@ -158,8 +163,10 @@ int main(int argc, char** argv) {
     }
     std::vector<uint8_t> buf(1 << 18);
     epoll_event evs[128];
+    double t_busy = 0.0;
     while (!stop.load()) {
       int n = epoll_wait(ep, evs, 128, 50);
+      if (n > 0 && t_busy > 0.0) amax(max_recv_gap_us, (long)((now_s() - t_busy) * 1e6));
       for (int k = 0; k < n; ++k) {
         Stream& s = st[evs[k].data.u32];
         ssize_t r = recv(s.fd_out, buf.data(), buf.size(), MSG_DONTWAIT);
@@ -188,6 +195,7 @@ int main(int argc, char** argv) {
         }
         if (off) s.rbuf.erase(s.rbuf.begin(), s.rbuf.begin() + off);
       }
+      t_busy = n > 0 ? now_s() : 0.0;
     }
     close(ep);
   };
@@ -206,9 +214,10 @@ int main(int argc, char** argv) {
   for (auto& s : st) unanswered += (long)s.sent.size();
   printf("{\"streams\": %d, \"frame_hz\": %d, \"packet_ms\": %d, \"seconds_measured\": %.1f, \"frames_sent\": %ld, \"frames_answered\": %ld, "
          "\"unanswered_at_end\": %ld, \"latency_samples\": %zu, \"lat_p50_ms\": %.3f, \"lat_p99_ms\": %.3f, \"lat_p999_ms\": %.3f, \"lat_max_ms\": %.3f, "
-         "\"late_over_%.0fms\": %ld, \"schedule_slips\": %ld, \"stream_frames_per_s\": %.1f}\n",
+         "\"late_over_%.0fms\": %ld, \"schedule_slips\": %ld, \"client_max_send_lag_ms\": %.2f, \"client_max_send_call_ms\": %.2f, \"client_max_recv_pass_ms\": %.2f, \"stream_frames_per_s\": %.1f}\n",
          S, hz, packet_ms, seconds, frames_sent.load(), frames_answered.load(), unanswered, lats.size(), pct(0.50), pct(0.99), pct(0.999),
-         lats.empty() ? 0.0 : (double)lats.back(), late_ms, late.load(), slipped.load(), lats.size() / seconds);
+         lats.empty() ? 0.0 : (double)lats.back(), late_ms, late.load(), slipped.load(), max_send_lag_us.load() * 1e-3, max_send_call_us.load() * 1e-3,
+         max_recv_gap_us.load() * 1e-3, lats.size() / seconds);
   for (auto& s : st) { close(s.fd_in); close(s.fd_out); }
   return 0;
 }

@@ -202,6 +202,9 @@ struct vapx_ingest {
   std::atomic<int64_t> frames_done{0}, ticks{0}, rx_bytes{0}, tx_bytes{0}, in_conns{0}, out_conns{0}, dropped{0}, numeric_resets{0},
       overruns{0}, batch_sum{0};
   std::atomic<int64_t> step_us{0};
+  // stall diagnostics (printed at close when VAPX_INGEST_DEBUG is set): longest single pass of an rx thread over its ready sockets, longest gap
+  // between two passes that both had work, longest step, longest send of one tick's rows
+  std::atomic<int64_t> dbg_rx_pass_us{0}, dbg_rx_gap_us{0}, dbg_step_us{0}, dbg_tx_us{0};
   Hist lat;
   std::string err;
   bool pinned_blocks = true;               // staging came from vapx_host_alloc (false: plain calloc, no HIP device)
@@ -482,11 +485,19 @@ void accept_main(vapx_ingest* g) {
   }
 }
 
+inline void atomic_max(std::atomic<int64_t>& a, int64_t v) {
+  int64_t m = a.load(std::memory_order_relaxed);
+  while (v > m && !a.compare_exchange_weak(m, v, std::memory_order_relaxed)) {}
+}
+
 void rx_main(vapx_ingest* g, int r) {
   std::vector<uint8_t> scratch(256 * 1024);
   epoll_event evs[256];
+  double t_last_busy = 0.0;
   while (!g->stop.load()) {
     int n = epoll_wait(g->ep[r], evs, 256, 100);
+    const double t_in = mono_now();
+    if (n > 0 && t_last_busy > 0.0) atomic_max(g->dbg_rx_gap_us, (int64_t)((t_in - t_last_busy) * 1e6));
     for (int i = 0; i < n; ++i) {
       const uint64_t tag = evs[i].data.u64, kind = tag & ~0xffffffffull;
       if (kind == K_WAKE) {
@@ -501,6 +512,10 @@ void rx_main(vapx_ingest* g, int r) {
         for (int slot : todo) do_resume(g, r, slot);
       } else on_data(g, r, (int)(tag & 0xffffffffu), scratch.data(), scratch.size());
     }
+    if (n > 0) {
+      t_last_busy = mono_now();
+      atomic_max(g->dbg_rx_pass_us, (int64_t)((t_last_busy - t_in) * 1e6));
+    } else t_last_busy = 0.0;
   }
 }
 
@@ -657,6 +672,7 @@ void tick_main(vapx_ingest* g) {
     const double t1 = mono_now();
     earliest_next = t0 + (t1 - t0) / util;
     g->step_us.fetch_add((int64_t)((t1 - t0) * 1e6));
+    atomic_max(g->dbg_step_us, (int64_t)((t1 - t0) * 1e6));
     g->ticks.fetch_add(1);
     g->batch_sum.fetch_add(n);
     if (rc != 0 && rc != VAPX_E_NUMERIC) {   // the step itself failed: nothing to send; free the frames and keep serving
@@ -832,6 +848,9 @@ void vapx_ingest_close(vapx_ingest_handle g) {
   if (g->tick_thread.joinable()) g->tick_thread.join();
   g->job_cv.notify_all();
   for (auto& t : g->tx_threads) if (t.joinable()) t.join();
+  if (getenv("VAPX_INGEST_DEBUG"))
+    fprintf(stderr, "[vapx ingest] longest rx pass %.2f ms, longest gap between busy rx passes %.2f ms, longest step %.2f ms, latency max %.2f ms\n",
+            g->dbg_rx_pass_us.load() * 1e-3, g->dbg_rx_gap_us.load() * 1e-3, g->dbg_step_us.load() * 1e-3, (double)g->lat.max_us.load() * 1e-3);
   if (g->slots) {
     for (int i = 0; i < g->S; ++i) {
       if (g->slots[i].fd_in >= 0) close(g->slots[i].fd_in);
