@@ -203,8 +203,8 @@ struct vapx_ingest {
       overruns{0}, batch_sum{0};
   std::atomic<int64_t> step_us{0};
   // stall diagnostics (printed at close when VAPX_INGEST_DEBUG is set): longest single pass of an rx thread over its ready sockets, longest gap
-  // between two passes that both had work, longest step, longest send of one tick's rows
-  std::atomic<int64_t> dbg_rx_pass_us{0}, dbg_rx_gap_us{0}, dbg_step_us{0}, dbg_tx_us{0};
+  // between two passes that both had work, longest step
+  std::atomic<int64_t> dbg_rx_pass_us{0}, dbg_rx_gap_us{0}, dbg_step_us{0};
   Hist lat;
   std::string err;
   bool pinned_blocks = true;               // staging came from vapx_host_alloc (false: plain calloc, no HIP device)
