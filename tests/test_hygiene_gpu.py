@@ -102,3 +102,29 @@ def test_create_destroy_does_not_leak_device_memory():
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 32 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 40 create/destroy cycles"
+
+
+def test_out_of_memory_at_create_is_an_error_code_and_leaks_nothing():
+    """4 M stream slots need 400 GB of context rings: vapx_create must come back with VAPX_E_NOMEM (-4 family, not a crash) after releasing
+    whatever it had already allocated, and a normal engine must still work afterwards."""
+    import torch
+    from vap_realtime_amd import engine, synth, weights as W
+    cpc, vap = W.synthetic_weights(3, 20)
+    blob = W.pack_blob(cpc, vap)
+    for _ in range(2):                       # warm the runtime (code objects, its own pools) with a normal create + a failed one
+        engine.Engine(blob, 20, 2.5, max_streams=8).close()
+        with pytest.raises(engine.VapxError):
+            engine.Engine(blob, 20, 2.5, max_streams=4_000_000, max_batch=64)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(3):
+        with pytest.raises(engine.VapxError) as ei:
+            engine.Engine(blob, 20, 2.5, max_streams=4_000_000, max_batch=64)
+        assert "memory" in str(ei.value).lower(), str(ei.value)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, f"{(free0 - free1) >> 20} MiB lost after three failed creates"
+    eng = engine.Engine(blob, 20, 2.5, max_streams=8)
+    out = eng.step(synth.dialogue_batch(list(range(8)), 800))
+    assert np.isfinite(out).all()
+    eng.close()

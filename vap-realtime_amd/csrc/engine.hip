@@ -629,6 +629,7 @@ int flush_resets(vapx_engine* h, hipStream_t st) {
 
 // quiesce the device and apply queued resets (state import / export, peeks)
 int quiesce(vapx_engine* h) {
+  (void)hipGetLastError();   // a stale error of an earlier, unrelated HIP call (this library's or anyone's) is not this call's
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   HIPCHK(h, hipDeviceSynchronize());
   vapx_engine* lead = h->trunk ? h->trunk : h;
@@ -818,6 +819,7 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
     hipError_t _e = (expr);                                                                        \
     if (_e != hipSuccess) {                                                                        \
       int rc = fail(nullptr, _e == hipErrorOutOfMemory ? VAPX_E_NOMEM : VAPX_E_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+      (void)hipGetLastError();   /* do not leave the error for the next launch check to find */     \
       vapx_destroy(h);                                                                             \
       return rc;                                                                                   \
     }                                                                                              \
@@ -932,6 +934,7 @@ int vapx_step(vapx_handle h, int32_t n, const int32_t* stream_ids, const float* 
   }
   if (!stream_ids && n > h->cfg.max_streams) return fail(h, VAPX_E_RANGE, "n exceeds max_streams");
   hipStream_t st = (hipStream_t)hip_stream;
+  (void)hipGetLastError();   // a stale error of an earlier, unrelated HIP call (this library's or anyone's) is not this call's
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   // split the batch into groups on separate HIP streams: streams are independent, and a second
   // group's kernels fill the prologue / epilogue / tail bubbles of the first group's kernels
@@ -1045,6 +1048,7 @@ void vapx_host_free(void* p) {
 
 int vapx_join(vapx_handle h, void* hip_stream) {
   if (!h) return VAPX_E_INVAL;
+  (void)hipGetLastError();   // a stale error of an earlier, unrelated HIP call (this library's or anyone's) is not this call's
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   for (int g = 0; g < h->last_G && h->last_G > 1; ++g) HIPCHK(h, hipStreamWaitEvent((hipStream_t)hip_stream, h->gdone[g], 0));
   return VAPX_OK;   // deferred_pending stays set: only `hip_stream` waited, a later step on another stream still has to
@@ -1187,6 +1191,7 @@ int vapx_encode_audio(vapx_handle h, int32_t n, const int32_t* stream_ids, const
   if (n < 1 || n > h->cfg.max_batch) return fail(h, VAPX_E_RANGE, "n=%d outside [1,%d]", n, h->cfg.max_batch);
   if (!frames || !e) return fail(h, VAPX_E_INVAL, "null frames/e");
   hipStream_t st = (hipStream_t)hip_stream;
+  (void)hipGetLastError();   // a stale error of an earlier, unrelated HIP call (this library's or anyone's) is not this call's
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   const int* ids = nullptr;
   int rc = join_deferred(h, st);
@@ -1213,6 +1218,7 @@ int vapx_transformer(vapx_handle h, int32_t n, int32_t rows, const float* x, flo
   if (stage == 1 && (x12 || comb)) return fail(h, VAPX_E_INVAL, "stage 1 produces only o");
   if (stage == 2 && o) return fail(h, VAPX_E_INVAL, "stage 2 does not produce o");
   hipStream_t st = (hipStream_t)hip_stream;
+  (void)hipGetLastError();   // a stale error of an earlier, unrelated HIP call (this library's or anyone's) is not this call's
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   const int T = h->T;
   const int l_begin = stage == 2 ? 1 : 0, l_end = stage == 1 ? 1 : 4;
@@ -1291,6 +1297,7 @@ int vapx_profile_enable(vapx_handle h, uint32_t class_mask) {
 
 int vapx_profile_read(vapx_handle h, double* total_ms, int64_t* launches, int32_t n_classes) {
   if (!h || !total_ms || !launches) return VAPX_E_INVAL;
+  (void)hipGetLastError();   // a stale error of an earlier, unrelated HIP call (this library's or anyone's) is not this call's
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   HIPCHK(h, hipDeviceSynchronize());
   for (int i = 0; i < n_classes; ++i) { total_ms[i] = 0.0; launches[i] = 0; }
@@ -1307,6 +1314,7 @@ int vapx_profile_read(vapx_handle h, double* total_ms, int64_t* launches, int32_
 int vapx_vap_head(vapx_handle h, int64_t rows, const float* x, float* logits, void* hip_stream) {
   if (!h || !x || !logits || rows < 1) return VAPX_E_INVAL;
   if (h->cfg.mode != VAPX_MODE_VAP) return fail(h, VAPX_E_INVAL, "this weight set has no vap_head (bc / nod variant)");
+  (void)hipGetLastError();   // a stale error of an earlier, unrelated HIP call (this library's or anyone's) is not this call's
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   GemmArgs g = gemm_args(x, contiguous_rows(256), h->W("head.w"), (int)rows, 256, 256, logits, contiguous_rows(256));
   g.bias = h->W("head.b");
@@ -1316,6 +1324,7 @@ int vapx_vap_head(vapx_handle h, int64_t rows, const float* x, float* logits, vo
 
 int vapx_va_classifier(vapx_handle h, int64_t rows, const float* x, float* y, void* hip_stream) {
   if (!h || !x || !y || rows < 1) return VAPX_E_INVAL;
+  (void)hipGetLastError();   // a stale error of an earlier, unrelated HIP call (this library's or anyone's) is not this call's
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)hip_stream, x, h->W("vad.w"), h->W("vad.b"), y, (long)rows);
   HIPCHK(h, hipGetLastError());
@@ -1324,18 +1333,21 @@ int vapx_va_classifier(vapx_handle h, int64_t rows, const float* x, float* y, vo
 
 int vapx_softmax256(int64_t rows, const float* x, float* y, void* hip_stream) {
   if (!x || !y || rows < 1) return VAPX_E_INVAL;
+  (void)hipGetLastError();
   hipLaunchKernelGGL(softmax256_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)hip_stream, x, y, (long)rows);
   return hipGetLastError() == hipSuccess ? VAPX_OK : VAPX_E_HIP;
 }
 
 int vapx_aggregate(int64_t rows, const float* probs, int32_t from_bin, int32_t to_bin, float* out, void* hip_stream) {
   if (!probs || !out || rows < 1 || from_bin < 0 || to_bin > 3 || from_bin > to_bin) return VAPX_E_INVAL;
+  (void)hipGetLastError();
   hipLaunchKernelGGL(aggregate_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)hip_stream, probs, out, (long)rows, from_bin, to_bin);
   return hipGetLastError() == hipSuccess ? VAPX_OK : VAPX_E_HIP;
 }
 
 int vapx_gemm(void* hip_stream, int32_t M, int32_t N, int32_t K, const float* A, const float* W, float* C, int32_t epi,
               const float* bias, const float* gamma, const float* beta, const float* resid, float* C2, int32_t tile_rows) {
+  (void)hipGetLastError();
   GemmArgs g = gemm_args(A, contiguous_rows(K), W, M, N, K, C, contiguous_rows(N));
   g.bias = bias; g.gamma = gamma; g.beta = beta; g.resid = resid; g.C2 = C2;
   hipError_t e = launch_gemm_f32(g, epi, tile_rows, (hipStream_t)hip_stream);
