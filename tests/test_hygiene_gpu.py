@@ -128,3 +128,43 @@ def test_out_of_memory_at_create_is_an_error_code_and_leaks_nothing():
     out = eng.step(synth.dialogue_batch(list(range(8)), 800))
     assert np.isfinite(out).all()
     eng.close()
+
+
+def test_engines_stepped_from_concurrent_host_threads():
+    """One handle per thread is the contract (vapx.h): four threads, each creating, stepping and destroying its own engine at the same
+    time (ctypes drops the GIL inside every call), must produce what the same four engines produce one after the other."""
+    import threading
+    from vap_realtime_amd import engine, synth, weights as W
+    hz_of = (20, 50, 10, 20)
+    blobs, audios = [], []
+    for k, hz in enumerate(hz_of):
+        cpc, vap = W.synthetic_weights(40 + k, hz)
+        blobs.append(W.pack_blob(cpc, vap))
+        audios.append(synth.dialogue_batch(list(range(48)), (16000 // hz) * 6))
+
+    def run(k, sink):
+        hz = hz_of[k]
+        hop = 16000 // hz
+        eng = engine.Engine(blobs[k], hz, 2.5, max_streams=48, groups=(k % 2) * 2)
+        outs = [eng.step(np.ascontiguousarray(audios[k][:, :, (t % 6) * hop:(t % 6 + 1) * hop])).copy() for t in range(40)]
+        eng.close()
+        sink[k] = np.stack(outs)
+
+    solo, conc = {}, {}
+    for k in range(4):
+        run(k, solo)
+    errors = []
+
+    def guarded(k):
+        try:
+            run(k, conc)
+        except Exception as e:          # noqa: BLE001 - reported below
+            errors.append((k, repr(e)))
+    threads = [threading.Thread(target=guarded, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(4):
+        assert np.array_equal(solo[k], conc[k]), f"engine {k} differs when stepped next to three other threads"
