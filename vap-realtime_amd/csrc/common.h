@@ -1,6 +1,7 @@
 // Shared device helpers for libvapx (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdint.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -59,6 +60,24 @@ __device__ __forceinline__ float fast_tanh(float x) {
   float r = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
   return copysignf(r, x);
 }
+
+// Host side: runs `f` once per (call site, HIP device) — used to raise a kernel's dynamic-LDS limit before its first launch on that device.
+// Guarded by a mutex so that a second host thread cannot launch before the first one has finished setting the attribute, and per device
+// because the attribute lives with the device's copy of the function (an engine may be created on every GPU of a process).
+struct PerDeviceOnce {
+  std::mutex mu;
+  unsigned long long done = 0;
+  template <class F>
+  void run(F&& f) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    std::lock_guard<std::mutex> lk(mu);
+    if (done & bit) return;
+    f();
+    done |= bit;
+  }
+};
 
 // value of lane `l` (wave-uniform index) in every lane: v_readlane_b32, no LDS
 __device__ __forceinline__ float lane_bcast(float v, int l) {

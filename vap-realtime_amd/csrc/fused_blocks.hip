@@ -887,11 +887,10 @@ bool conv_tail_supported(int P1, int ncpc) {
 
 hipError_t launch_conv_tail(const ConvTailArgs& a, int B, hipStream_t st) {
   if (!conv_tail_supported(a.P1, a.ncpc)) return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  attr_set.run([] {
     (void)hipFuncSetAttribute((const void*)conv_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  });
   const size_t lds = ((size_t)((a.P1 + 2) + 2 * (a.P1 / 2 + 2)) * LDH + 128) * sizeof(float);
   hipLaunchKernelGGL(conv_tail_kernel, dim3(B), dim3(256), lds, st, a);
   return hipGetLastError();
@@ -906,21 +905,19 @@ hipError_t launch_attn_block(const AttnBlockArgs& a, int B, hipStream_t st) {
 
 hipError_t launch_ffn_block(const FfnArgs& a, hipStream_t st) {
   if (a.M <= 0) return hipSuccess;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  attr_set.run([] {
     (void)hipFuncSetAttribute((const void*)ffn_block_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ffn_block_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  });
   const int mt = (a.tile_rows == 64 && a.mode == 0) ? 2 : 1;
   const size_t lds = (size_t)(2 * 32 * mt * LDH + 4 * 32 * mt) * sizeof(float);
   if (a.mode == 1 || a.mode == 2) {
-    static bool attr2 = false;
-    if (!attr2) {
+    static PerDeviceOnce attr2;
+    attr2.run([] {
       (void)hipFuncSetAttribute((const void*)ffn_block_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute((const void*)ffn_block_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr2 = true;
-    }
+    });
     if (!a.att || !a.wprojf || !a.resid || !a.xmid_out) return hipErrorInvalidValue;
     if (a.mode == 1) hipLaunchKernelGGL((ffn_block_kernel<1, 1>), dim3((a.M + 31) / 32), dim3(256), lds, st, a);
     else hipLaunchKernelGGL((ffn_block_kernel<1, 2>), dim3((a.M + 31) / 32), dim3(256), lds, st, a);

@@ -1134,21 +1134,19 @@ hipError_t launch_attention(const AttnArgs& a, int B, hipStream_t st) {
   const int n_tiles = (a.T + 31) / 32;
   const int nw = n_tiles < 4 ? n_tiles : 4;
   const size_t lds = (size_t)n_tiles * 32 * KV_LD * 2 * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  attr_set.run([] {
     (void)hipFuncSetAttribute((const void*)attention_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)attention_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  });
   static const bool gen1 = getenv("VAPX_ATTN_GEN1") != nullptr;   // A/B: the first-generation 4-wave kernel
   static const bool gen2 = getenv("VAPX_ATTN_GEN2") != nullptr;   // A/B: the 8-wave, K+V-in-LDS kernel
   if (n_tiles <= 8 && !gen1 && !gen2) {
-    static bool attr4 = false;
-    if (!attr4) {
+    static PerDeviceOnce attr4;
+    attr4.run([] {
       (void)hipFuncSetAttribute((const void*)attention_long2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
       (void)hipFuncSetAttribute((const void*)attention_long2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      attr4 = true;
-    }
+    });
     if (n_tiles <= 2)   // short windows: workgroup = (stream, channel), wave = head
       hipLaunchKernelGGL(attention_long2_kernel<true>, dim3(B * 2), dim3(256), (size_t)4 * n_tiles * 32 * 64 * sizeof(float), st, a);
     else
@@ -1157,11 +1155,10 @@ hipError_t launch_attention(const AttnArgs& a, int B, hipStream_t st) {
   }
   if (n_tiles <= 2) hipLaunchKernelGGL(attention_mfma_kernel<2>, dim3(B * 2 * 4), dim3(64 * nw), lds, st, a);
   else if (n_tiles <= 8 && !gen1) {
-    static bool attr3 = false;
-    if (!attr3) {
+    static PerDeviceOnce attr3;
+    attr3.run([] {
       (void)hipFuncSetAttribute((const void*)attention_long_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr3 = true;
-    }
+    });
     hipLaunchKernelGGL(attention_long_kernel, dim3(B * 2 * 4), dim3(512), lds, st, a);
   } else if (n_tiles <= 8) hipLaunchKernelGGL(attention_mfma_kernel<8>, dim3(B * 2 * 4), dim3(64 * nw), lds, st, a);
   else return hipErrorInvalidValue;
