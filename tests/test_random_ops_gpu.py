@@ -28,7 +28,7 @@ class Dialogue:
             self.st = self.o.new_state(1)
 
 
-@pytest.mark.parametrize("seed,hz,ctx,groups", [(1, 20, 2.5, 0), (2, 20, 1.0, 2), (3, 50, 1.3, 0), (4, 10, 2.5, 2)])
+@pytest.mark.parametrize("seed,hz,ctx,groups", [(1, 20, 2.5, 0), (2, 20, 1.0, 2), (3, 50, 1.3, 2)])
 def test_random_program_against_per_stream_oracles(seed, hz, ctx, groups):
     import torch
     from oracle.vap_oracle import VapOracle
@@ -37,7 +37,7 @@ def test_random_program_against_per_stream_oracles(seed, hz, ctx, groups):
     cpc, vap = W.synthetic_weights(30 + seed, hz, "vap")
     oracle = VapOracle(cpc, vap, hz, ctx)
     hop = 16000 // hz
-    S, slots, ticks = 5, 9, int(ctx * hz) + 14           # 5 dialogues living in 9 engine slots
+    S, slots, ticks = 4, 8, int(ctx * hz) + 10           # 4 dialogues living in 8 engine slots
     audio = synth.dialogue_batch([70 + i for i in range(S)], hop * ticks)
     eng = engine.Engine(W.pack_blob(cpc, vap), hz, ctx, max_streams=slots, max_batch=slots, groups=groups)
     dia = [Dialogue(oracle, hop) for _ in range(S)]
