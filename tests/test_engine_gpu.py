@@ -539,3 +539,43 @@ def test_published_bc_and_nod_settings_against_the_oracle(mode, hz, ctx):
     assert worst <= TOL
     eng.close()
 
+
+
+@pytest.mark.parametrize("kind", ["silence", "tiny", "full_scale_square", "loud", "dc_offset", "one_channel_dead"])
+def test_degenerate_audio_against_the_oracle(kind):
+    """Inputs a live microphone path really produces — digital silence, a muted channel, clipping, a DC offset, samples far outside [-1, 1],
+    values near the fp32 denormal range — against the oracle: ChannelNorm divides by a channel spread that silence makes tiny, so this is
+    where a fused kernel's arithmetic order would show."""
+    from oracle.vap_oracle import ServerFramer, VapOracle
+    from vap_realtime_amd import engine, synth, weights as W
+    cpc, vap = W.synthetic_weights(23, 20, "vap")
+    o = VapOracle(cpc, vap, 20, 2.5)
+    S, F_ = 2, 26
+    base = synth.dialogue_batch([50, 51], 800 * F_)
+    t = np.arange(800 * F_)
+    if kind == "silence":
+        audio = np.zeros_like(base)
+    elif kind == "tiny":
+        audio = base * 1e-30
+    elif kind == "full_scale_square":
+        audio = np.broadcast_to(np.where((t // 40) % 2 == 0, 1.0, -1.0).astype(np.float32), base.shape).copy()
+    elif kind == "loud":
+        audio = base * 3e3
+    elif kind == "dc_offset":
+        audio = base + 0.75
+    else:
+        audio = base.copy(); audio[:, 1] = 0.0
+    st, fr = o.new_state(S), ServerFramer(S, 800)
+    eng = engine.Engine(W.pack_blob(cpc, vap), 20, 2.5, max_streams=S)
+    worst = 0.0
+    for f in range(F_):
+        new = np.ascontiguousarray(audio[:, :, f * 800:(f + 1) * 800])
+        want = o.step(fr.frame(new), st)
+        got = engine.split_outputs(eng.step(new))
+        assert np.isfinite(got["logits"]).all(), f"{kind} frame {f}: non-finite logits"
+        for k in ("p_now", "p_future", "vad"):
+            worst = max(worst, float(np.abs(got[k] - want[k]).max()))
+        worst_l = float(np.abs(got["logits"] - want["logits"]).max())
+        assert worst_l <= 5 * TOL, f"{kind} frame {f}: logits off by {worst_l:.3e}"
+    eng.close()
+    assert worst <= TOL, (kind, worst)
