@@ -550,8 +550,8 @@ def test_degenerate_audio_against_the_oracle(kind):
     from vap_realtime_amd import engine, synth, weights as W
     cpc, vap = W.synthetic_weights(23, 20, "vap")
     o = VapOracle(cpc, vap, 20, 2.5)
-    S, F_ = 2, 26
-    base = synth.dialogue_batch([50, 51], 800 * F_)
+    S, F_ = 3, 56
+    base = synth.dialogue_batch([50, 51, 52], 800 * F_)
     t = np.arange(800 * F_)
     if kind == "silence":
         audio = np.zeros_like(base)

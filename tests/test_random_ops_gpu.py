@@ -28,18 +28,33 @@ class Dialogue:
             self.st = self.o.new_state(1)
 
 
-@pytest.mark.parametrize("seed,hz,ctx,groups", [(1, 20, 2.5, 0), (2, 20, 1.0, 2), (3, 50, 1.3, 2)])
-def test_random_program_against_per_stream_oracles(seed, hz, ctx, groups):
+def _compare(mode, got, i, want):
+    """max |hip - oracle| over the outputs the `mode` program publishes, for batch slot i of `got` and the 1-stream oracle result."""
+    pairs = [(got["vad"][i], want["vad"][0])]
+    if mode == "vap":
+        pairs += [(got[k][i], want[k][0]) for k in ("p_now", "p_future", "logits")]
+    elif mode == "bc":
+        pairs += [(got["aux"][i, 1], want["p_bc_react"][0]), (got["aux"][i, 2], want["p_bc_emo"][0])]
+    else:
+        pairs += [(got["aux"][i, 1], want["p_nod_short"][0]), (got["aux"][i, 2], want["p_nod_long"][0]), (got["aux"][i, 3], want["p_nod_long_p"][0])]
+        n = want["p_bc"].shape[1]                       # p_bc of every window row (the reference's batch-index quirk)
+        pairs.append((got["logits"][i, :n], want["p_bc"][0]))
+    return max(float(np.abs(np.asarray(a, np.float64).reshape(-1) - np.asarray(b, np.float64).reshape(-1)).max()) for a, b in pairs)
+
+
+@pytest.mark.parametrize("seed,hz,ctx,groups,mode", [(1, 20, 2.5, 0, "vap"), (2, 20, 1.0, 2, "vap"), (3, 50, 1.3, 2, "vap"), (4, 10, 2.5, 2, "vap"),
+                                                     (5, 20, 2.5, 0, "nod"), (6, 10, 5.0, 2, "bc"), (7, 5, 10.0, 0, "vap"), (8, 50, 5.0, 0, "vap")])
+def test_random_program_against_per_stream_oracles(seed, hz, ctx, groups, mode):
     import torch
     from oracle.vap_oracle import VapOracle
     from vap_realtime_amd import engine, synth, weights as W
     rng = np.random.default_rng(seed)
-    cpc, vap = W.synthetic_weights(30 + seed, hz, "vap")
-    oracle = VapOracle(cpc, vap, hz, ctx)
+    cpc, vap = W.synthetic_weights(30 + seed, hz, mode)
+    oracle = VapOracle(cpc, vap, hz, ctx, mode=mode)
     hop = 16000 // hz
-    S, slots, ticks = 4, 8, int(ctx * hz) + 10           # 4 dialogues living in 8 engine slots
+    S, slots, ticks = 5, 9, int(ctx * hz) + 14          # 5 dialogues living in 9 engine slots
     audio = synth.dialogue_batch([70 + i for i in range(S)], hop * ticks)
-    eng = engine.Engine(W.pack_blob(cpc, vap), hz, ctx, max_streams=slots, max_batch=slots, groups=groups)
+    eng = engine.Engine(W.pack_blob(cpc, vap, mode), hz, ctx, max_streams=slots, max_batch=slots, groups=groups, mode=mode)
     dia = [Dialogue(oracle, hop) for _ in range(S)]
     slot_of = list(rng.permutation(slots)[:S])            # dialogue k lives in engine slot slot_of[k]
     pos = [0] * S                                         # next audio frame of each dialogue
@@ -79,10 +94,9 @@ def test_random_program_against_per_stream_oracles(seed, hz, ctx, groups):
         for i, k in enumerate(order):
             want = dia[k].step(audio[k, :, pos[k] * hop:(pos[k] + 1) * hop])
             pos[k] += 1
-            for key in ("p_now", "p_future", "vad", "logits"):
-                d = float(np.abs(np.asarray(got[key][i]).reshape(-1) - np.asarray(want[key][0]).reshape(-1)).max())
-                worst = max(worst, d)
-                assert d <= TOL, f"tick {t} dialogue {k} (slot {slot_of[k]}) {key}: |hip - oracle| = {d:.3e}; ops so far {n_ops}"
+            d = _compare(mode, got, i, want)
+            worst = max(worst, d)
+            assert d <= TOL, f"tick {t} dialogue {k} (slot {slot_of[k]}): |hip - oracle| = {d:.3e}; ops so far {n_ops}"
             steps += 1
     eng.close()
     print(f"seed {seed}: {steps} stream-steps, ops {n_ops}, worst |hip - oracle| = {worst:.2e}")
