@@ -1,6 +1,12 @@
 // Diagnostic only: a deterministic fp32-MFMA workload checked bit-for-bit against its own first launch.  Run it next to
 // tools/mfma_aggr (another process) to see whether co-running matrix-core work of another data type disturbs it.
-// usage: mfma_victim <launches> [mode: 0 registers only, 1 operands streamed from global memory, 2 via LDS]
+// usage: mfma_victim <launches> <mode>
+//   fp32 MFMA victims:  0 operands from registers, 1 from global memory, 2 A operand from LDS (per-lane rows, stride 260)
+//   VALU FMA victims:   3 global + LDS + cross-lane reduction, 4 global + LDS, 5 global only, 7 registers only,
+//                       6 activations by WAVE-UNIFORM 16-byte LDS reads   <- wrong data next to `mfma_aggr f16` / `bf16`
+//                       11 the same by wave-uniform 8-byte reads          <- wrong data too
+//                       8 wave-uniform 4-byte reads, 9 one word per lane + v_readlane, 10 per-lane distinct 16-byte reads
+// prints how many launches differ bit-wise from the first one (alone: always 0).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
