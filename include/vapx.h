@@ -45,8 +45,9 @@ extern "C" {
                                 probabilities (a poisoned LSTM / ring state, Inf audio, or |activation| >= 65504 on the
                                 split-precision path).  PER STREAM, not per call: the out block is complete, every other row is
                                 valid, the offending rows carry VAPX_OUT_STATUS = 1 and vapx_bad_slots() lists them; reset those
-                                streams and keep serving the rest.  NaN audio SAMPLES do not trigger it: the ReLU after the first
-                                ChannelNorm is fmaxf(y, 0), which maps NaN to 0 (torch.relu would propagate it). */
+                                streams and keep serving the rest.  A NaN / Inf audio SAMPLE triggers it exactly as it poisons the
+                                reference: ChannelNorm and torch.relu propagate it (encoder_components.py:64-66,103), the LSTM state
+                                keeps it for good (tests/golden/poison20.npz records the unmodified reference doing so). */
 
 /* model variants: which heads are evaluated (vap_main.py:290-307, vap_bc_main.py:272-277,
  * vap_nod_main.py:273-279) */

@@ -26,8 +26,11 @@ def run_oracle(case, collect_frames=()):
     return outs, cols
 
 
-@pytest.mark.parametrize("name", ["vap20", "vap10", "offline20", "multi3", "vap50"])
+@pytest.mark.parametrize("name", ["vap20", "vap10", "offline20", "multi3", "vap50", "degenerate20", "poison20", "vap20_10s"])
 def test_oracle_matches_reference_outputs(name):
+    """degenerate20: silence / near-denormal / clipping / 3e3 x / DC offset / dead channel — where ChannelNorm divides by ~0
+    (encoder_components.py:64-66); poison20: one NaN and one Inf SAMPLE — the reference's outputs turn NaN for good (equal_nan
+    comparison: same positions); vap20_10s: T = 200, the longest published window (README.md:381)."""
     c = Case(name)
     z = c.z
     es = int(z["meta.e_stride"]) if "meta.e_stride" in z.files else 1
@@ -60,8 +63,9 @@ def test_oracle_bc_heads():
         np.testing.assert_allclose(out["p_bc_emo"], c.z["p_bc_emo"][f].reshape(-1), rtol=0, atol=TOL_P)
 
 
-def test_oracle_nod_heads():
-    c = Case("nod20")
+@pytest.mark.parametrize("name", ["nod20", "nod20_10s"])
+def test_oracle_nod_heads(name):
+    c = Case(name)
     outs, _ = run_oracle(c)
     for f, out in enumerate(outs):
         for k in ("p_nod_short", "p_nod_long", "p_nod_long_p"):
@@ -94,3 +98,17 @@ def test_batched_oracle_equals_independent_runs():
     outs, _ = run_oracle(c)
     # different streams must actually differ (guards against a broadcast bug)
     assert np.abs(outs[-1]["logits"][0] - outs[-1]["logits"][1]).max() > 1e-2
+
+
+def test_poison_golden_records_what_the_reference_does_with_a_nan_sample():
+    """Pins the FACT the HIP path has to reproduce (tests/test_engine_gpu.py::test_poisoned_sample_behaves_like_the_reference):
+    from the frame holding the NaN / Inf sample on, p_now / p_future / logits and the VAD of the poisoned channel are NaN for
+    good; the other channel's VAD (ar_channel output of channel 2 only, vap_main.py:292-293) and the clean stream stay finite."""
+    c = Case("poison20")
+    z = c.z
+    assert c.kinds == ["clean", "nan_sample", "inf_sample"]
+    for s in (1, 2):
+        assert np.isfinite(z["logits"][:3, s]).all() and np.isnan(z["logits"][3:, s]).all()
+        assert np.isnan(z["p_now"][3:, s]).all() and np.isnan(z["p_future"][3:, s]).all()
+        assert np.isnan(z["vad"][3:, s, 0]).all() and np.isfinite(z["vad"][:, s, 1]).all()
+    assert np.isfinite(z["logits"][:, 0]).all() and np.isfinite(z["vad"][:, 0]).all()

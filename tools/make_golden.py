@@ -40,6 +40,17 @@ CASES = {
     "trunk_vap20": dict(mode="vap", frame_hz=20, ctx=2.5, streams=[6, 7], n_frames=54, framing="server", seed=7, cpc_seed=6, inter=[], e_stride=6),
     "trunk_bc20": dict(mode="bc", frame_hz=20, ctx=2.5, streams=[6, 7], n_frames=54, framing="server", seed=8, cpc_seed=6, inter=[], e_stride=6),
     "trunk_nod20": dict(mode="nod", frame_hz=20, ctx=2.5, streams=[6, 7], n_frames=54, framing="server", seed=9, cpc_seed=6, inter=[], e_stride=6),
+    # degenerate microphone input (synth.degenerate): one independent reference run per kind, on the dialogue of stream 50 + k.
+    # This is where ChannelNorm divides by ~0 (encoder_components.py:64-66): pins the oracle AND the HIP path on exactly those inputs.
+    "degenerate20": dict(mode="vap", frame_hz=20, ctx=2.5, streams=[50, 51, 52, 53, 54, 55], n_frames=56, framing="server", seed=23,
+                         inter=[], e_stride=8, kinds=["silence", "tiny", "full_scale_square", "loud", "dc_offset", "one_channel_dead"]),
+    # one NaN / Inf SAMPLE (frame 3): what the unmodified reference does with it (torch.relu and ChannelNorm propagate it, the LSTM
+    # state keeps it for good) next to a clean run of the same model
+    "poison20": dict(mode="vap", frame_hz=20, ctx=2.5, streams=[60, 61, 62], n_frames=10, framing="server", seed=24,
+                     inter=[], e_stride=1, kinds=["clean", "nan_sample", "inf_sample"]),
+    # T = 200: the longest published window (20 Hz x 10 s, README.md:381 vap-nod_state_dict_erica_20hz_10000msec) for vap and nod
+    "vap20_10s": dict(mode="vap", frame_hz=20, ctx=10.0, streams=[70], n_frames=204, framing="server", seed=25, inter=[0, 202], e_stride=17),
+    "nod20_10s": dict(mode="nod", frame_hz=20, ctx=10.0, streams=[71], n_frames=203, framing="server", seed=26, inter=[], e_stride=29),
 }
 ROW_SUBSET_AT = 8  # intermediates with more rows than this keep rows [0, n//3, n-1] only
 
@@ -75,6 +86,8 @@ def run_case(name: str) -> None:
     F_, S = cfg["n_frames"], len(cfg["streams"])
     n_samp = hop * F_ + 320
     audio = synth.dialogue_batch(cfg["streams"], n_samp)            # [S,2,n]
+    if "kinds" in cfg:
+        audio = np.stack([synth.degenerate(audio[i], k) for i, k in enumerate(cfg["kinds"])])
 
     res = {k: [] for k in ("p_now", "p_future", "vad", "logits", "e")}
     aux = {}
@@ -167,7 +180,10 @@ def run_case(name: str) -> None:
     out["meta.seed"] = np.array(cfg["seed"])
     out["meta.cpc_seed"] = np.array(cfg.get("cpc_seed", cfg["seed"]))
     out["meta.weights_fp"] = W.weights_fingerprint(cpc_sd, vap_sd)
-    out["meta.audio_fp"] = np.array([audio.astype(np.float64).sum(), np.abs(audio.astype(np.float64)).sum()])
+    fin = np.where(np.isfinite(audio), audio, 0.0).astype(np.float64)          # (poison20 holds one NaN and one Inf sample)
+    out["meta.audio_fp"] = np.array([fin.sum(), np.abs(fin).sum()])
+    if "kinds" in cfg:
+        out["meta.kinds"] = np.array(cfg["kinds"])
     path = os.path.join(REPO, "tests", "golden", f"{name}.npz")
     np.savez_compressed(path, **out)
     print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KB); "

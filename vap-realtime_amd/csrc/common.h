@@ -51,6 +51,9 @@ __device__ __forceinline__ float gelu_fast(float x) {
   const float e = 1.0f - p * t * __expf(-z * z);     // erf(|x| / sqrt 2)
   return 0.5f * x * (1.0f + copysignf(e, x));
 }
+// ReLU as torch.relu computes it (encoder_components.py:103): a NaN stays a NaN (fmaxf(NaN, 0) would return 0 and hide a poisoned
+// sample that the reference carries into the LSTM state for good; tests/golden/poison20.npz pins that behaviour).
+__device__ __forceinline__ float relu_nanprop(float x) { return x < 0.f ? 0.f : x; }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 // branch-free gate non-linearities for the LSTM recurrence (40 evaluations per lane per step): v_exp +
 // v_rcp (1 ulp) instead of libm's branchy tanhf and IEEE division.  Absolute error ~1e-7.

@@ -788,8 +788,8 @@ __global__ __launch_bounds__(256, 1) void conv_tail_kernel(const ConvTailArgs g)
       int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
       float var = (red[lr] + red[32 + lr] + red[64 + lr] + red[96 + lr]) * (1.0f / 255.0f);
       float rstd = rsqrtf(var + 1e-5f);
-      acc[0][r] = fmaxf((acc[0][r] - mean[r]) * rstd * g0 + b0, 0.f);
-      acc[1][r] = fmaxf((acc[1][r] - mean[r]) * rstd * g1 + b1, 0.f);
+      acc[0][r] = relu_nanprop((acc[0][r] - mean[r]) * rstd * g0 + b0);
+      acc[1][r] = relu_nanprop((acc[1][r] - mean[r]) * rstd * g1 + b1);
     }
   };
   auto zero = [](f32x16(&acc)[2]) {

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256, (WM == 4 ? 2 : 2)) void gemm_f32_kernel(const 
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns) {
           float y = (acc[ns][r] - mean[r]) * rstd * gam[ns] + bet[ns];
-          if constexpr (EPI == EPI_CN_RELU) y = fmaxf(y, 0.f);
+          if constexpr (EPI == EPI_CN_RELU) y = relu_nanprop(y);
           if constexpr (EPI == EPI_BIAS_LN_GELU) y = gelu_erf(y);
           op[ns * 32] = y;
         }

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(Conv0Args a) {
     float ss = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]);
     float rstd = rsqrtf(ss * (1.0f / 255.0f) + 1e-5f);
     f32x4 y = d * rstd * gam + bet;
-    y[0] = fmaxf(y[0], 0.f); y[1] = fmaxf(y[1], 0.f); y[2] = fmaxf(y[2], 0.f); y[3] = fmaxf(y[3], 0.f);
+    y[0] = relu_nanprop(y[0]); y[1] = relu_nanprop(y[1]); y[2] = relu_nanprop(y[2]); y[3] = relu_nanprop(y[3]);
     *(f32x4*)(outb + (long)p * 256 + ch) = y;
   }
 }

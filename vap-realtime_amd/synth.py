@@ -65,3 +65,38 @@ def noise_batch(n_streams: int, n_samples: int, seed: int = 7, scale: float = 0.
     streams would dominate set-up time; same shape/dtype as ``dialogue_batch``."""
     rng = np.random.default_rng(seed)
     return (scale * rng.standard_normal((n_streams, 2, n_samples), dtype=np.float32)).astype(np.float32)
+
+
+# Inputs a live microphone path really produces, as transforms of a seeded dialogue (the degenerate-audio goldens of
+# tools/make_golden.py and their parity tests share this one definition).  "nan_sample" / "inf_sample" poison ONE sample of
+# channel 0 (index 3 * 800 + 17: frame 3 at 20 Hz): the reference propagates it into the LSTM state for good.
+DEGENERATE_KINDS = ("silence", "tiny", "full_scale_square", "loud", "dc_offset", "one_channel_dead")
+POISON_KINDS = ("clean", "nan_sample", "inf_sample")
+POISON_INDEX = 3 * 800 + 17
+
+
+def degenerate(base: np.ndarray, kind: str) -> np.ndarray:
+    """base float32 [2, n] -> float32 [2, n] of the given kind."""
+    n = base.shape[-1]
+    t = np.arange(n)
+    if kind == "clean":
+        return base.copy()
+    if kind == "silence":
+        return np.zeros_like(base)
+    if kind == "tiny":
+        return (base * np.float32(1e-30)).astype(np.float32)
+    if kind == "full_scale_square":
+        return np.broadcast_to(np.where((t // 40) % 2 == 0, 1.0, -1.0).astype(np.float32), base.shape).copy()
+    if kind == "loud":
+        return (base * np.float32(3e3)).astype(np.float32)
+    if kind == "dc_offset":
+        return (base + np.float32(0.75)).astype(np.float32)
+    if kind == "one_channel_dead":
+        out = base.copy()
+        out[1] = 0.0
+        return out
+    if kind in ("nan_sample", "inf_sample"):
+        out = base.copy()
+        out[0, POISON_INDEX] = np.nan if kind == "nan_sample" else np.inf
+        return out
+    raise ValueError(kind)
