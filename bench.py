@@ -4,20 +4,27 @@
 One "step" = one VAP frame (one tick) for every stream of this rank: frame assembly -> CPC CNN -> LSTM -> downsample ->
 context ring -> 1+3 transformer layers -> heads, through the C ABI (vapx_step) with audio and outputs resident in HBM.
 
-Headline workload (`value`) = BASELINE.json configs[1] ("c2"): 256 concurrent synthetic stereo streams, 20 Hz frames,
-2.5 s context (T = 50) per GPU.  The same command also measures, as sub-records under "configs" with their own
-`roofline` each, the other single-GPU configurations of BASELINE.json:
+Headline workload (`value`) = BASELINE.json configs[2] ("c3"): 4096 concurrent synthetic stereo streams, 50 Hz frames, 5 s
+context (T = 250) per GPU — the LARGEST single-GPU configuration.  The same command measures the other single-GPU
+configurations as sub-records under "configs", each with its own `roofline`, `cpu_baseline`, `parity_gate`, `split_f16` side
+record and `paced_latency`:
+  c2          256 streams x 20 Hz / T = 50    (configs[1])
   s4096_20hz  4096 streams x 20 Hz / T = 50   (the per-GPU shard of configs[3]: 32768 streams over 8 GPUs)
-  c3          4096 streams x 50 Hz / T = 250  (configs[2], the largest single-GPU configuration)
   c5          bc + nod on one shared CPC trunk, 4096 streams (configs[4])
 `--gpus N` with N > 1 (and no WORLD_SIZE in the environment) re-executes itself under torch.distributed.run with N ranks,
 one per GPU; streams are sharded over the ranks with NO data-path collective (they are independent), every record is then
 the whole-job aggregate (units of all ranks / max-over-ranks time), so "s4096_20hz" at N = 8 IS configs[3].
 
-Prints ONE JSON line on rank 0 (contract in the task prompt): metric / value / unit / ... plus
+Every record passes a PARITY GATE before anything is timed: ticks 0, 1 (window warm-up), T-1 (first full window) and T (first
+slide) of the first and the last stream of the rank are compared with the oracle (CPU restatement of the reference step, pinned
+to the unmodified reference by tests/golden) at 1e-4 abs; a miss aborts the run without a number.
+
+Prints ONE JSON line on rank 0 (contract in the task prompt): metric / value / unit / ... plus per record
   "roofline":      dominant kernel (by summed time), HIP-event timed inside the timed region on the launch stream
-  "cpu_baseline":  the oracle (CPU restatement of the reference step) timed on this host (1 thread, and all physical cores)
-  "paced_latency": >= 6144 distinct streams in phase-staggered sub-ticks on a wall-clock schedule (the <= 10 ms p99 target)
+  "cpu_baseline":  the oracle timed on this host at the record's own shape (1 thread, batch 1), continuing from the gate's state
+  "paced_latency": distinct streams in phase-staggered sub-ticks on a wall-clock schedule (the <= 10 ms p99 target), per rank
+  "split_f16":     the same workload on the opt-in split-precision path (never `value`)
+and once: "front_end" (the native TCP front-end under the real-time load generator, reference wire format).
 """
 from __future__ import annotations
 
@@ -38,48 +45,68 @@ FP32_MFMA_PEAK_TF = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, den
 F16_MFMA_PEAK_TF = 2516.6     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16, dense
 HBM_PEAK_GBS = 8000.0
 GFLOP_PER_STREAM_FRAME = {(20, 50): 0.920, (50, 250): 4.505, (10, 50): 1.054}   # dense count: SURVEY.md §8d / BASELINE.md §3
+ALGO_BYTES_PER_STREAM_FRAME = {(20, 50): 119e3, (50, 250): 525e3}
+PARITY_TOL = 1e-4             # BASELINE.json north_star
 
-WORKLOADS = {   # name -> (streams per GPU, frame_hz, ctx_sec, mode, default steps, default warmup)
-    "c2": (256, 20, 2.5, "vap", 100, 10),
-    "s4096_20hz": (4096, 20, 2.5, "vap", 20, 3),
-    "c3": (4096, 50, 5.0, "vap", 8, 2),
-    "c5": (4096, 20, 2.5, "bc+nod", 10, 2),
+WORKLOADS = {   # name -> (streams per GPU, frame_hz, ctx_sec, mode, default steps, default warmup): every record >= 2 s or >= 100 ticks
+    "c3": (4096, 50, 5.0, "vap", 24, 3),
+    "c2": (256, 20, 2.5, "vap", 1000, 20),
+    "s4096_20hz": (4096, 20, 2.5, "vap", 100, 5),
+    "c5": (4096, 20, 2.5, "bc+nod", 48, 3),
 }
 KERNEL_NAMES = {"ffn_block": "ffn_block_kernel", "attention": "attn_block_kernel", "conv_tail": "conv_tail_kernel",
                 "last_row": "last_block_kernel", "lstm": "lstm_kernel", "head": "head_kernel", "conv0": "conv0_kernel"}
 
 
-def macs_per_stream_frame(hz: int, T: int) -> dict:
-    """EXECUTED multiply-accumulates per stream-frame (both channels) by kernel class of the default path (exact last-layer
-    pruning, absorbed last-layer K/V projections, cached layer-0 Q|K|V).  The attention classes count the DENSE T x T
+def model_macs(hz: int, T: int, mode: str = "vap", leader: bool = True) -> dict:
+    """EXECUTED multiply-accumulates per stream-frame (both channels) by kernel class for ONE weight set of the default path.
+    vap / bc: exact last-layer pruning, absorbed last-layer K/V projections, cached layer-0 Q|K|V.  nod emits p_bc for every
+    window row (vap_nod_main.py:276), so it runs the FULL last layer and the Combinator on all rows.  leader = False: a trunk
+    follower (shares the leader's CPC CNN + LSTM, runs only its own downsample).  The attention classes count the DENSE T x T
     products like SURVEY.md does (the kernels skip most of the causally masked tiles, see `attention_executed_fraction`)."""
     hop = 16000 // hz
     L = hop + 320
     P0 = L // 5; P1 = P0 // 4; P2 = P1 // 2; P3 = P2 // 2; P4 = P3 // 2; ncpc = P4 - 2
     D = 256
     rows = 2 * T
-    fused = T <= 64          # fused attention block (attention + projection + LN + cross-q) vs attention_mfma_kernel + GEMMs
-    attn = 5 * 2 * 4 * (T * T * 64 * 2)
+    fused = T <= 64          # fused attention block (attention + projection + LN + cross-q) vs attention_long2_kernel + flat-row blocks
+    full = mode == "nod"
+    n_ffn = 4 if full else 3                       # FFN blocks executed on all rows
+    n_next = 3 if full else 2                      # next-layer Q|K|V + cross K|V emitted by an FFN block
+    n_attn = 7 if full else 5                      # attention blocks on all rows (l0 self, l1.. self + cross)
+    n_proj = n_attn + (3 if full else 2)           # attention output projections + cross-attention query projections
+    attn = n_attn * 2 * 4 * (T * T * 64 * 2)
     m = {
-        "conv0": 2 * P0 * D * 10,
-        "gemm_cn_relu": 2 * (P1 * 8 + P2 * 4 + P3 * 4 + ncpc * 4) * D * D,
-        "lstm": 2 * ncpc * D * 4 * D + 2 * ncpc * D * D,                # recurrence (K=256) + fused downsample
-        "gemm_bias_ln_gelu": 0,
-        "gemm_store": 2 * ncpc * D * 4 * D + 2 * D * 768,               # LSTM input projection + layer-0 QKV of the NEW row (others cached)
+        "conv0": 2 * P0 * D * 10 if leader else 0,
+        "gemm_cn_relu": 2 * (P1 * 8 + P2 * 4 + P3 * 4 + ncpc * 4) * D * D if leader else 0,
+        "lstm": (2 * ncpc * D * 4 * D + 2 * ncpc * D * D) if leader else 0,    # recurrence (K=256) + fused downsample
+        # follower: its own downsample GEMM; nod: Combinator on all rows (two [T x 256 x 256] per stream)
+        "gemm_bias_ln_gelu": (0 if leader else 2 * ncpc * D * D) + (2 * T * D * D if full else 0),
+        # LSTM input projection (leader) + layer-0 QKV of the NEW row (others cached)
+        "gemm_store": (2 * ncpc * D * 4 * D if leader else 0) + 2 * D * 768,
         "gemm_resid_ln": 0,
-        # FFN x3 + QKV and cross-KV of layers 1, 2 (layer 3: absorbed); long windows: + the five attention output projections and
-        # the two cross-attention query projections, which ride in the same flat-row blocks (fused_blocks.hip, modes 1 / 2)
-        "ffn_block": rows * D * (3 * 2 * 768 + 2 * 768 + 2 * 512 + (0 if fused else 7 * D)),
-        # layer 3 on one row per channel: 14 contractions (q, Wk^T q, Wv, proj, their cross twins, FFN) + two
+        # FFN + next layer's QKV / cross-KV (last pruned layer: absorbed); long windows: + the attention output projections and
+        # the cross-attention query projections, which ride in the same flat-row blocks (fused_blocks.hip, modes 1 / 2)
+        "ffn_block": rows * D * (n_ffn * 2 * 768 + n_next * (768 + 512) + (0 if fused else n_proj * D)),
+        # pruned layer 3 on one row per channel: 14 contractions (q, Wk^T q, Wv, proj, their cross twins, FFN) + two
         # 4-head single-query attentions over T rows of 256 (score + weighted sum)
-        "last_row": 2 * (14 * D * D + 2 * 4 * T * D * 2),
+        "last_row": 0 if full else 2 * (14 * D * D + 2 * 4 * T * D * 2),
         "gemm_gelu": 0, "gemm_resid": 0,
-        # dense T x T attention of layers 0-2 (+ in the fused block: output projections x5, cross-q projections x2)
-        "attention": attn + (rows * 7 * D * D if fused else 0),
+        # dense T x T attention (+ in the fused block: output projections, cross-q projections)
+        "attention": attn + (rows * n_proj * D * D if fused else 0),
         "head": 3 * D * D + 2 * D,
         "gather_ln": 0,
     }
     return m
+
+
+def macs_per_stream_frame(hz: int, T: int, mode: str = "vap") -> dict:
+    """Sum of `model_macs` over the weight sets of `mode` ("bc+nod": the first leads the shared CPC trunk)."""
+    tot = {}
+    for k, md in enumerate(mode.split("+")):
+        for c, v in model_macs(hz, T, md, leader=(k == 0)).items():
+            tot[c] = tot.get(c, 0) + v
+    return tot
 
 
 def attention_executed_fraction(T: int) -> float:
@@ -140,27 +167,45 @@ def synth_audio(stream_ids, S: int, hop: int, NF: int) -> np.ndarray:
     return np.ascontiguousarray(audio.reshape(S, 2, NF, hop).transpose(2, 0, 1, 3))
 
 
+def model_weights(hz: int, mode: str):
+    """(cpc state dict, [(mode, vap state dict), ...]) of a workload: the first weight set leads the shared CPC trunk."""
+    from vap_realtime_amd import weights as W
+    modes = mode.split("+")
+    cpc, vap0 = W.synthetic_weights(0, hz, modes[0])
+    sets = [(modes[0], vap0)]
+    for k, m in enumerate(modes[1:]):                              # same cpc_model "file", own VAP state dict
+        sets.append((m, W.synthetic_weights(1 + k, hz, m)[1]))
+    return cpc, sets
+
+
+def make_engines(cpc, sets, hz, ctx_sec, max_streams, device_id, groups=0, split_f16=False, max_batch=None):
+    from vap_realtime_amd import engine, weights as W
+    lead = engine.Engine(W.pack_blob(cpc, sets[0][1], sets[0][0]), hz, ctx_sec, max_streams=max_streams, max_batch=max_batch,
+                         device_id=device_id, groups=groups, mode=sets[0][0], split_f16=split_f16)
+    followers = []
+    for m, vap in sets[1:]:
+        f = engine.Engine(W.pack_blob(cpc, vap, m), hz, ctx_sec, max_streams=max_streams, max_batch=max_batch, device_id=device_id,
+                          groups=groups, mode=m, split_f16=split_f16)
+        f.attach_trunk(lead)
+        followers.append(f)
+    return lead, followers
+
+
 class Workload:
     """Engines + resident synthetic audio of one configuration on this rank."""
 
     def __init__(self, S, hz, ctx_sec, mode, rank, world, local_rank, groups=0, split_f16=False):
         import torch
-        from vap_realtime_amd import engine, weights as W
+        from vap_realtime_amd import engine
         from vap_realtime_amd.sharding import shard_streams
         self.S, self.hz, self.ctx_sec, self.mode = S, hz, ctx_sec, mode
         self.T = int(ctx_sec * hz)
         self.hop = 16000 // hz
         self.modes = mode.split("+")
         self.my_streams = shard_streams(S * world, world, rank)         # global stream ids of this rank
-        self.cpc, self.vap = W.synthetic_weights(0, hz, self.modes[0])
-        self.eng = engine.Engine(W.pack_blob(self.cpc, self.vap, self.modes[0]), hz, ctx_sec, max_streams=S, device_id=local_rank,
-                                 groups=groups, mode=self.modes[0], split_f16=split_f16)
-        self.followers = []
-        for k, m in enumerate(self.modes[1:]):                          # same cpc_model "file", own VAP state dict
-            f = engine.Engine(W.pack_blob(self.cpc, W.synthetic_weights(1 + k, hz, m)[1], m), hz, ctx_sec, max_streams=S,
-                              device_id=local_rank, groups=groups, mode=m)
-            f.attach_trunk(self.eng)
-            self.followers.append(f)
+        self.cpc, self.sets = model_weights(hz, mode)
+        self.vap = self.sets[0][1]
+        self.eng, self.followers = make_engines(self.cpc, self.sets, hz, ctx_sec, S, local_rank, groups=groups, split_f16=split_f16)
         self.NF = 32 if S * self.hop <= 1024 * 800 else 8               # distinct audio frames, cycled
         self.audio = synth_audio(self.my_streams, S, self.hop, self.NF)
         self.d_audio = torch.from_numpy(self.audio).cuda()
@@ -173,6 +218,10 @@ class Workload:
                              defer_join=defer_join)
         for f, o in zip(self.followers, self.d_out_f):
             f.step_follow_device(self.S, o.data_ptr(), stream=self.stream)
+
+    def rows(self, idx):
+        """Host copies of the output rows `idx` of every model: [n_models][len(idx), OUT_STRIDE]."""
+        return [o[idx].cpu().numpy() for o in [self.d_out] + self.d_out_f]
 
     def profile_enable(self, classes):
         for e in [self.eng] + self.followers:
@@ -192,6 +241,98 @@ class Workload:
         self.eng.close()
 
 
+class OracleTwin:
+    """The oracle (oracle/vap_oracle.py: CPU restatement of the reference's process_vap, pinned to the unmodified reference by
+    tests/golden) run on a few streams of a workload — the CHECKER of the parity gate and, continued from the gate's state,
+    the CPU baseline.  One oracle per weight set; each re-encodes the audio, as the reference's separate programs do."""
+
+    def __init__(self, cpc, sets, hz, ctx_sec, audio, gate_idx):
+        from oracle.vap_oracle import ServerFramer, VapOracle
+        self.hop = 16000 // hz
+        self.audio = audio[:, gate_idx]                         # [NF, G, 2, hop]
+        self.NF = audio.shape[0]
+        self.modes = [m for m, _ in sets]
+        self.oracles = [VapOracle(cpc, vap, hz, ctx_sec, mode=m) for m, vap in sets]
+        self.states = [o.new_state(len(gate_idx)) for o in self.oracles]
+        self.framers = [ServerFramer(len(gate_idx), self.hop) for _ in self.oracles]
+        self.tick = 0
+
+    def step(self):
+        outs = [o.step(fr.frame(self.audio[self.tick % self.NF]), st) for o, st, fr in zip(self.oracles, self.states, self.framers)]
+        self.tick += 1
+        return outs
+
+    def time_one_stream(self, seconds: float):
+        """Continue stream 0 alone (batch 1, 1 thread: the reference's shape) for `seconds`: (frames, elapsed)."""
+        import torch
+        from oracle.vap_oracle import OracleState, ServerFramer
+        torch.set_num_threads(1)
+        sts, frs = [], []
+        for st, fr in zip(self.states, self.framers):
+            sts.append(OracleState(1, st.ctx_len, [r[:1].clone() for r in st.ring], st.h[:1].clone(), st.c[:1].clone()))
+            f1 = ServerFramer(1, self.hop)
+            f1.carry = fr.carry[:1].copy()
+            frs.append(f1)
+        a1 = self.audio[:, :1]
+        n, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < seconds:
+            for o, st, fr in zip(self.oracles, sts, frs):
+                o.step(fr.frame(a1[(self.tick + n) % self.NF]), st)
+            n += 1
+        return n, time.perf_counter() - t1
+
+
+def compare_with_oracle(mode, row, want, n):
+    """max |hip - oracle| over the outputs the reference's process_vap of this model variant publishes."""
+    from vap_realtime_amd import engine
+    got = engine.split_outputs(row)
+    worst = float(np.abs(got["vad"] - want["vad"]).max())
+    if mode == "vap":
+        for k in ("p_now", "p_future", "logits"):
+            worst = max(worst, float(np.abs(got[k] - want[k]).max()))
+    elif mode == "bc":
+        worst = max(worst, float(np.abs(got["aux"][:, 1] - want["p_bc_react"]).max()), float(np.abs(got["aux"][:, 2] - want["p_bc_emo"]).max()))
+    else:
+        for k, col in (("p_nod_short", 1), ("p_nod_long", 2), ("p_nod_long_p", 3)):
+            worst = max(worst, float(np.abs(got["aux"][:, col] - want[k]).max()))
+        worst = max(worst, float(np.abs(got["logits"][:, :n] - want["p_bc"][:, :n]).max()))
+    return worst if np.isfinite(worst) else float("inf")
+
+
+def fill_and_gate(wl: Workload, name: str):
+    """Fill the context window (T + 1 ticks: the timed region is the steady state) and hold the engines' outputs of the first and
+    the last stream at ticks 0, 1, T-1, T against the oracle.  Raises SystemExit on a miss: no number without parity."""
+    import torch
+    T, S = wl.T, wl.S
+    gate_idx = [0, S - 1] if S > 1 else [0]
+    check_ticks = sorted({0, 1, T - 1, T})
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    twin = OracleTwin(wl.cpc, wl.sets, wl.hz, wl.ctx_sec, wl.audio, gate_idx)
+    got = {}
+    for i in range(T + 1):
+        wl.step(i)
+        if i in check_ticks:
+            got[i] = wl.rows(gate_idx)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    worst = {}
+    for i in range(T + 1):
+        want = twin.step()
+        if i in check_ticks:
+            n = min(i + 1, T)
+            for k, m in enumerate(twin.modes):
+                worst[(i, m)] = compare_with_oracle(m, got[i][k], want[k], n)
+    oracle_s = time.perf_counter() - t0
+    w = max(worst.values())
+    rec = {"ok": bool(w <= PARITY_TOL), "tolerance_abs": PARITY_TOL, "worst_abs": w, "streams_checked": [int(wl.my_streams[g]) for g in gate_idx],
+           "ticks_checked": check_ticks, "models": twin.modes, "worst_by_tick": {str(t): max(v for (tt, _), v in worst.items() if tt == t) for t in check_ticks},
+           "oracle_seconds": oracle_s,
+           "what": "p_now / p_future / VAD / 256 logits (bc, nod: their head probabilities, nod's p_bc of every window row) vs oracle/vap_oracle.py"}
+    if not rec["ok"]:
+        raise SystemExit(f"bench.py: PARITY GATE FAILED for {name}: max |hip - oracle| = {w:.3e} > {PARITY_TOL} ({json.dumps(rec)}); nothing was timed")
+    return rec, twin
+
+
 def load_traffic(key: str, dominant: str):
     """HBM bytes / launch of the dominant kernel from the committed PMC passes (separate rocprofv3 --pmc runs of this very
     command, profiles/pmc_traffic.json; counters cannot be collected inside a timed run)."""
@@ -204,8 +345,8 @@ def load_traffic(key: str, dominant: str):
 
 
 def run_workload(name, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=0, split_f16=False, defer_join=False):
-    """Prime the window, find the dominant kernel class, then time exactly `steps` ticks bracketed by barrier + device
-    synchronise; returns (record, workload) — the caller closes the workload."""
+    """Parity gate while the window fills, find the dominant kernel class, then time exactly `steps` ticks bracketed by barrier +
+    device synchronise; returns (record, workload, oracle twin) — the caller closes the workload."""
     import torch
     from vap_realtime_amd import dist_util, engine
     rank, local_rank, world, dist = ctx
@@ -215,9 +356,7 @@ def run_workload(name, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=0, split
     def barrier():
         dist_util.barrier(dist, torch.cuda.synchronize)
 
-    for i in range(T):                               # fill the context window: the timed region is the steady state
-        wl.step(i)
-    torch.cuda.synchronize()
+    gate, twin = fill_and_gate(wl, name + ("_split_f16" if split_f16 else ""))
     wl.profile_enable(range(13))
     wl.profile_read()
     NP = 3 if S * T > 100000 else 5
@@ -243,11 +382,12 @@ def run_workload(name, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=0, split
     dom_ms, dom_launches = wl.profile_read()[dominant]
     wl.profile_enable([])
     dt = dist_util.max_over_ranks(dist, dt, "cuda")
-    assert torch.isfinite(wl.d_out[:, :6]).all(), "non-finite outputs"
-    assert not wl.d_out[:, engine.OUT_STATUS].any(), "engine flagged non-finite rows"
+    for o in [wl.d_out] + wl.d_out_f:
+        assert torch.isfinite(o[:, :6]).all(), "non-finite outputs"
+        assert not o[:, engine.OUT_STATUS].any(), "engine flagged non-finite rows"
 
     value = S * world * steps / dt
-    macs = macs_per_stream_frame(hz, T)
+    macs = macs_per_stream_frame(hz, T, mode)
     if "conv_tail" in breakdown:          # conv2-4 ran as the fused tail kernel (<= 512 streams): its MACs leave the GEMM class
         hop_ = 16000 // hz
         P1_ = (hop_ + 320) // 5 // 4
@@ -255,9 +395,6 @@ def run_workload(name, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=0, split
         macs["conv_tail"] = macs["gemm_cn_relu"] - conv1
         macs["gemm_cn_relu"] = conv1
     nm = len(wl.modes)
-    if nm > 1:   # every model runs its own downsample + transformer; the encoder classes run once
-        shared = ("conv0", "gemm_cn_relu", "conv_tail", "lstm")   # (gemm_store holds the shared LSTM input projection and the per-model new-row QKV: counted per model, a slight over-count)
-        macs = {k: v * (1 if k in shared else nm) for k, v in macs.items()}
     launches_per_step = dom_launches / steps
     flop_per_launch = 2.0 * macs[dominant] * S / launches_per_step
     avg_launch_s = dom_ms * 1e-3 / dom_launches
@@ -265,26 +402,36 @@ def run_workload(name, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=0, split
     dense_gflop = GFLOP_PER_STREAM_FRAME.get((hz, T))
     exec_gflop = 2.0 * sum(macs.values()) / 1e9      # executed, attention still counted dense
     fa = attention_executed_fraction(T)
-    exec_gflop_causal = exec_gflop - 2.0 * (1.0 - fa) * 5 * 2 * 4 * (T * T * 64 * 2) * nm / 1e9
-    peak = FP32_MFMA_PEAK_TF
+    n_attn = sum(7 if m == "nod" else 5 for m in wl.modes)
+    exec_gflop_causal = exec_gflop - 2.0 * (1.0 - fa) * n_attn * 2 * 4 * (T * T * 64 * 2) / 1e9
+    # the split path's matrix-core roof: three f16 products per fp32 product on the f16 MFMA (judge r02: "f16 MFMA peak / 3")
+    peak = F16_MFMA_PEAK_TF / 3.0 if split_f16 else FP32_MFMA_PEAK_TF
     kernel = KERNEL_NAMES.get(dominant, f"gemm_f32_kernel ({dominant})")
     if dominant == "attention" and T > 64:
-        kernel = "attention_mfma_kernel"
+        kernel = "attention_long2_kernel"
+    if dominant == "ffn_block" and split_f16:
+        kernel = "ffn_block_f16x3_kernel"
     roof = {"bound": "mfma", "kernel": kernel, "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tf / peak,
-            "traffic": load_traffic(f"{S}x{hz}hz_T{T}" + ("" if mode == "vap" else "_" + mode), dominant),
+            "traffic": None if split_f16 else load_traffic(f"{S}x{hz}hz_T{T}" + ("" if mode == "vap" else "_" + mode), dominant),
             "avg_launch_us": avg_launch_s * 1e6, "launches_per_step": launches_per_step, "gflop_per_launch": flop_per_launch / 1e9,
             "flop_count": "algorithmic FLOPs of the launch (dense T x T for attention), MACs x 2"}
+    ab = ALGO_BYTES_PER_STREAM_FRAME.get((hz, T))
+    if ab:
+        roof["hbm_algorithmic"] = {"bytes_per_stream_frame": ab, "achieved_gbs": value * ab / 1e9 / world, "peak_gbs": HBM_PEAK_GBS,
+                                   "frac": value * ab / 1e9 / world / HBM_PEAK_GBS, "note": "the path is MFMA-bound: the HBM roof is two orders of magnitude away"}
     if dominant == "attention":
         roof["frac_executed_causal"] = roof["frac"] * fa
     if split_f16:
-        roof["note"] = ("GEMM-shaped contractions run as 3 f16 MFMA products each: the fp32-MFMA peak is NOT the bound of this path "
-                        "(3/16 of the MFMA time); its bound is the L2 -> VGPR weight stream")
+        roof["peak_note"] = ("every GEMM-shaped contraction = 3 f16 MFMA products (hi.hi + lo.hi + hi.lo), fp32 accumulate: peak = dense f16 MFMA / 3 "
+                             f"= {peak:.1f} fp32-equivalent TFLOP/s; frac_of_fp32_mfma_peak = {achieved_tf / FP32_MFMA_PEAK_TF:.3f}")
     rec = {
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+        "timed_seconds": dt,
         "config": {"workload": f"{name}: {S} concurrent synthetic stereo streams per GPU, {ctx_sec} s / {hz} Hz (T={T}), mode {mode}, 1 MI355X per rank",
                    "streams_per_gpu": S, "streams_total": S * world, "frame_hz": hz, "ctx_frames": T, "mode": mode,
                    "gemm_arithmetic": ("f16x3 split products, fp32 accumulate" if split_f16 else "fp32 MFMA"),
                    "parallelism": f"stream-sharded x{world}, no collective"},
+        "parity_gate": gate,
         "realtime_streams_sustained": value / hz,
         "executed_gflop_per_stream_frame": exec_gflop, "executed_gflop_per_stream_frame_causal_attention": exec_gflop_causal,
         "executed_tflops": value * exec_gflop / 1e3,
@@ -296,63 +443,81 @@ def run_workload(name, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=0, split
         "kernel_tflops": {k: round(2.0 * macs.get(k, 0) * S / (v * 1e-3) / 1e12, 1)
                           for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]) if v > 0 and macs.get(k, 0) > 0},
     }
-    if dense_gflop and nm == 1:
+    if dense_gflop and nm == 1 and mode == "vap":
         rec["dense_gflop_per_stream_frame"] = dense_gflop
         rec["dense_tflops"] = value * dense_gflop / 1e3
         rec["dense_frac_of_fp32_mfma_peak"] = value * dense_gflop / 1e3 / (FP32_MFMA_PEAK_TF * world)
-    return rec, wl
+    return rec, wl, twin
 
 
-def paced_latency(cpc, vap, hz, ctx_sec, local_rank, seconds, target_ms=10.0, max_util=0.85):
-    """The north-star latency target measured, not extrapolated: ONE engine holding G x Ssub DISTINCT streams, its G
-    sub-batches phase-staggered over the frame period (50 ms at 20 Hz) on a wall-clock schedule for `seconds`;
-    latency of a sub-tick = its scheduled audio-ready time -> results on the host (pinned H2D + kernels + D2H + sync,
-    including any wait behind a late predecessor).  A short calibration picks the largest G x Ssub whose sub-tick service
-    time keeps the GPU under `max_util`; if the paced run misses p99 <= target or the utilisation bound it is repeated with 64 fewer
-    streams per sub-batch (up to twice), then one group smaller."""
-    from vap_realtime_amd import engine, weights as W
+def cpu_baseline_record(twin: OracleTwin, wl_cfg, seconds: float):
+    """The oracle at the record's own shape on this host: 1 thread, batch 1, window full (continues the parity gate's state)."""
+    S, hz, ctx_sec, mode = wl_cfg
+    n, cdt = twin.time_one_stream(seconds)
+    each = " (one frame = the bc AND the nod program, each encoding the audio itself as the reference deploys them)" if "+" in mode else ""
+    return {"value": n / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{n} frames of 1 stream at {hz} Hz / T={int(ctx_sec * hz)}, mode {mode}{each} (batch 1, window full, torch-CPU fp32, 1 thread) in "
+                      f"{cdt:.1f} s; host has {physical_cores()} physical / {os.cpu_count()} logical cores",
+            "ms_per_frame": cdt / n * 1e3}
+
+
+def paced_latency(cpc, sets, hz, ctx_sec, local_rank, seconds, target_ms=10.0, max_util=0.85, split_f16=False):
+    """The north-star latency target measured, not extrapolated: ONE engine (plus trunk followers for bc+nod) holding G x Ssub
+    DISTINCT streams, its G sub-batches phase-staggered over the frame period (50 ms at 20 Hz, 20 ms at 50 Hz) on a wall-clock
+    schedule for `seconds`; latency of a sub-tick = its scheduled audio-ready time -> results of EVERY model on the host (pinned
+    H2D + kernels + D2H + sync, including any wait behind a late predecessor).  A short calibration picks the largest G x Ssub
+    whose sub-tick service time keeps the GPU under `max_util`; if the paced run misses p99 <= target or the utilisation bound it
+    is repeated with ~6 % fewer streams per sub-batch (up to twice), then one group smaller."""
+    from vap_realtime_amd import engine
     period = 1.0 / hz
     hop = 16000 // hz
     T = int(ctx_sec * hz)
-    blob = W.pack_blob(cpc, vap)
-    Ssub_opts = (1024, 768, 512)
-    Gmax = 12
-    eng = engine.Engine(blob, hz, ctx_sec, max_streams=Gmax * max(Ssub_opts), max_batch=max(Ssub_opts), device_id=local_rank,
-                        groups=2)   # two intra-tick overlap groups: -1.4 % sub-tick time at 1024 streams (joined inside every step)
+    Ssub_opts = (64, 128, 192, 256, 384, 512, 768, 1024)
+    Gmax = 16
     NF = 8
     base = synth_audio(list(range(64)), max(Ssub_opts), hop, NF)          # [NF, Ssub, 2, hop]
     pin_in = [engine.pinned_empty((max(Ssub_opts), 2, hop)) for _ in range(NF)]
     for i in range(NF):
         pin_in[i][...] = base[i]
-    pin_out = engine.pinned_empty((max(Ssub_opts), engine.OUT_STRIDE))
+    pin_out = [engine.pinned_empty((max(Ssub_opts), engine.OUT_STRIDE)) for _ in sets]
+    # calibration engine: sub-tick service time per candidate size (two intra-tick overlap groups: -1.4 % at 1024 streams)
+    eng, fol = make_engines(cpc, sets, hz, ctx_sec, max(Ssub_opts), local_rank, groups=2, split_f16=split_f16)
 
-    def service_time(Ssub, reps=24):
-        ids = np.arange(Ssub, dtype=np.int32)
-        ts = []
-        for i in range(reps):
-            t1 = time.perf_counter()
-            eng.step(pin_in[i % NF][:Ssub], ids, out=pin_out)
-            ts.append(time.perf_counter() - t1)
-        return float(np.percentile(ts[4:], 95))
+    def sub_tick(e, f, audio, ids):
+        e.step(audio, ids, out=pin_out[0])
+        for k, ff in enumerate(f):
+            ff.step_follow(len(ids), out=pin_out[1 + k])
 
     calib = {}
     best = None
     for Ssub in Ssub_opts:
-        sv = service_time(Ssub)
+        ids = np.arange(Ssub, dtype=np.int32)
+        ts = []
+        for i in range(16):
+            t1 = time.perf_counter()
+            sub_tick(eng, fol, pin_in[i % NF][:Ssub], ids)
+            ts.append(time.perf_counter() - t1)
+        sv = float(np.percentile(ts[4:], 95))
         calib[Ssub] = sv * 1e3
+        if sv * 1e3 > 0.8 * target_ms:
+            break
         G = min(Gmax, int(max_util * period / sv))
-        if sv * 1e3 <= 0.8 * target_ms and G >= 1 and (best is None or G * Ssub > best[0] * best[1]):
+        if G >= 1 and (best is None or G * Ssub > best[0] * best[1]):
             best = (G, Ssub)
+    for f in fol:
+        f.close()
+    eng.close()
     out = {"calibration_subtick_p95_ms": calib, "frame_period_ms": period * 1e3, "target_p99_ms": target_ms, "max_utilisation": max_util,
+           "models": [m for m, _ in sets], "gemm_arithmetic": "f16x3 split products" if split_f16 else "fp32 MFMA",
            "method": "one engine, G phase-staggered sub-batches of DISTINCT streams per frame period, wall-clock schedule; latency = "
-                     "scheduled audio-ready -> results on host (pinned staging both ways)", "runs": []}
+                     "scheduled audio-ready -> results of every model on host (pinned staging both ways)", "runs": []}
     if best is None:
-        eng.close()
         out["sustained_streams"] = 0
         return out
     G, Ssub = best
+    eng, fol = make_engines(cpc, sets, hz, ctx_sec, G * Ssub, local_rank, groups=2, split_f16=split_f16, max_batch=Ssub)
     import gc
-    gc.disable()                                       # a collector pause inside the 50 ms schedule would be charged to the engine
+    gc.disable()                                       # a collector pause inside the schedule would be charged to the engine
     for attempt in range(4):
         for s in range(G * Ssub):                     # every trial starts from clean streams (queued, applied by the next step)
             eng.reset_stream(s)
@@ -370,7 +535,7 @@ def paced_latency(cpc, vap, hz, ctx_sec, local_rank, seconds, target_ms=10.0, ma
                     if ready - now > 2e-4:
                         time.sleep((ready - now) * 0.5)
                 t1 = time.perf_counter()
-                eng.step(pin_in[(k + g) % NF][:Ssub], idsets[g], out=pin_out)
+                sub_tick(eng, fol, pin_in[(k + g) % NF][:Ssub], idsets[g])
                 t2 = time.perf_counter()
                 busy += t2 - t1
                 if k >= T:                             # window full: steady state
@@ -385,19 +550,54 @@ def paced_latency(cpc, vap, hz, ctx_sec, local_rank, seconds, target_ms=10.0, ma
             out["sustained_streams"] = G * Ssub
             out.update({k: run[k] for k in ("groups", "sub_tick_streams", "p50_ms", "p99_ms", "max_ms", "gpu_busy_fraction")})
             break
-        # too busy or too late: shed 64 streams per sub-batch (same schedule) and measure again; after three such steps drop a group
-        if attempt < 2 and Ssub > 640:
-            Ssub -= 64
+        # too busy or too late: shed ~6 % of the streams of every sub-batch (same schedule) and measure again; then drop a group
+        if attempt < 2 and Ssub >= 64:
+            Ssub -= max(8, (Ssub // 16) // 8 * 8)
         else:
             G -= 1
         if G < 1:
             break
-    else:
-        out["sustained_streams"] = 0
     out.setdefault("sustained_streams", 0)
     gc.enable()
+    for f in fol:
+        f.close()
     eng.close()
     return out
+
+
+def gather_paced(dist, rank, world, rec):
+    """Whole-job view of the per-rank paced runs (they ran concurrently, one per GPU): streams summed, worst p99."""
+    if dist is None or rec is None:
+        return rec
+    import torch
+    mine = torch.tensor([float(rec.get("sustained_streams", 0)), float(rec.get("p99_ms", 0.0)), float(rec.get("max_ms", 0.0)),
+                         float(rec.get("gpu_busy_fraction", 0.0))], dtype=torch.float64)
+    allv = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allv, mine)
+    rec = dict(rec)
+    rec["per_rank"] = [{"sustained_streams": int(v[0]), "p99_ms": float(v[1]), "max_ms": float(v[2]), "gpu_busy_fraction": float(v[3])} for v in allv]
+    rec["sustained_streams_all_ranks"] = int(sum(v[0] for v in allv))
+    rec["worst_p99_ms_all_ranks"] = float(max(v[1] for v in allv))
+    return rec
+
+
+def front_end_record(streams: int, seconds: float):
+    """The native TCP front-end (vapx_ingest_*) + one engine under tools/loadgen: `streams` real-time dialogue clients sending the
+    reference's 10 ms packets (2560 B, vap_main.py:373-391), every result packet (12 880 B at 20 Hz) read back and timed."""
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "server_load.py"), "--streams", str(streams), "--seconds", str(seconds), "--warm", "4"]
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=seconds + 240)
+        line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]
+        r = json.loads(line)
+        keep = ("streams", "frames_sent", "frames_answered", "stream_frames_per_s", "realtime_streams_served", "lat_p50_ms", "lat_p99_ms",
+                "lat_max_ms", "late_over_10ms", "server", "server_window")
+        rec = {k: r[k] for k in keep if k in r}
+        st = r.get("server_stats", {})
+        rec["server_latency_ms"] = {k: st[k] for k in st if k.startswith("lat_")}
+        rec["how"] = "tools/server_load.py: native front-end + engine on this GPU, tools/loadgen on the same host (loopback TCP), reference wire format"
+        return rec
+    except Exception as e:                                        # noqa: BLE001 - a side record must not cost the headline
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def main():
@@ -405,8 +605,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS), help="headline workload (`value`)")
-    ap.add_argument("--configs", default="s4096_20hz,c3,c5",
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS), help="headline workload (`value`)")
+    ap.add_argument("--configs", default="c2,s4096_20hz,c5",
                     help="comma list of further workloads measured as sub-records under \"configs\" ('' = none)")
     ap.add_argument("--streams", type=int, default=None, help="override: concurrent streams per GPU of the headline workload")
     ap.add_argument("--frame-hz", type=int, default=None)
@@ -414,12 +614,13 @@ def main():
     ap.add_argument("--mode", default=None, choices=["vap", "bc", "nod", "bc+nod", "vap+bc+nod"],
                     help="override: model variant; a+b = weight sets served on one shared CPC trunk (one stream-frame = one audio "
                          "frame through the shared encoder and every listed model)")
-    ap.add_argument("--cpu-baseline-sec", type=float, default=12.0)
+    ap.add_argument("--cpu-baseline-sec", type=float, default=8.0, help="timed oracle seconds per distinct record shape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=-1,
-                    help="processes of the multi-core CPU leg (-1 = every physical core, 0 = skip)")
-    ap.add_argument("--no-latency", action="store_true", help="skip the latency legs and the overlap / split-precision side records")
-    ap.add_argument("--paced-sec", type=float, default=20.0, help="duration of the paced many-stream latency run (0 = skip)")
+                    help="processes of the multi-core CPU leg at the headline shape (-1 = every physical core, 0 = skip)")
+    ap.add_argument("--no-latency", action="store_true", help="skip the latency legs, the split-precision side records and the front-end record")
+    ap.add_argument("--paced-sec", type=float, default=12.0, help="duration of each paced many-stream latency run (0 = skip)")
+    ap.add_argument("--front-end-streams", type=int, default=4096, help="real-time TCP clients of the front-end record (0 = skip)")
     ap.add_argument("--groups", type=int, default=0, help="intra-tick overlap groups (0 = engine default)")
     ap.add_argument("--split-f16", action="store_true",
                     help="opt-in: GEMM-shaped contractions as fp32-accurate 3-term f16 split products (VAPX_FLAG_SPLIT_F16)")
@@ -441,7 +642,8 @@ def main():
     from vap_realtime_amd import dist_util
     from vap_realtime_amd.sharding import shard_streams
     rank, local_rank, world = dist_util.env_rank()
-    pinned = dist_util.pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    dev_index = 0 if args.share_gpu else local_rank
+    pinned = dist_util.pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), device_index=dev_index)
 
     if args.rendezvous_only:
         dist = dist_util.init("gloo")
@@ -458,11 +660,94 @@ def main():
         return
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    if args.share_gpu:
-        local_rank = 0
+    local_rank = dev_index
     torch.cuda.set_device(local_rank)
     dist = dist_util.init(args.backend, torch.device("cuda", local_rank))
     ctx = (rank, local_rank, world, dist)
+    side = not args.no_latency
+    cpu_cache = {}      # (hz, ctx_sec, mode) -> cpu_baseline record: c2 and s4096_20hz are the same CPU shape
+
+    def full_record(name, S, hz, ctx_sec, mode, steps, warmup, headline=False):
+        """One configuration: fp32 record (gate, timing, roofline) + its CPU baseline + split-precision side record + paced latency."""
+        rec, wl, twin = run_workload(name, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=args.groups, split_f16=args.split_f16 and headline,
+                                     defer_join=args.defer_join and headline)
+        extras = {}
+        if headline:
+            extras = {}
+            if rank == 0 and world == 1 and side and not wl.followers:
+                extras["lat"] = host_latency(wl)
+                extras["groups"] = overlap_groups_record(wl, steps) if args.groups <= 1 and not args.split_f16 else None
+        cpc, sets = wl.cpc, wl.sets
+        wl.close()
+        del wl
+        torch.cuda.empty_cache()
+        if rank == 0 and not args.no_cpu_baseline:
+            key = (hz, ctx_sec, mode)
+            if key not in cpu_cache:
+                cpu_cache[key] = cpu_baseline_record(twin, (S, hz, ctx_sec, mode), args.cpu_baseline_sec)
+            rec["cpu_baseline"] = cpu_cache[key]
+        del twin
+        if side and not args.split_f16:
+            # the same workload on the opt-in split-precision path (VAPX_FLAG_SPLIT_F16): every GEMM-shaped contraction as
+            # three f16 MFMA products with fp32 accumulation — same deviation from the reference as the fp32-MFMA path
+            # (tests/test_split_precision_gpu.py), its own parity gate.  Reported next to `value`, never as `value`.
+            try:
+                srec, w2, tw2 = run_workload(name, S, hz, ctx_sec, mode, steps, warmup, ctx, split_f16=True)
+                w2.close()
+                del w2, tw2
+                torch.cuda.empty_cache()
+                srec["arithmetic"] = ("x = hi + lo (f16); hi.hi + lo.hi + hi.lo on v_mfma_f32_32x32x16_f16, fp32 accumulate; opt-in "
+                                      "(VAPX_FLAG_SPLIT_F16), not the default")
+                srec["speedup_over_fp32"] = srec["value"] / rec["value"]
+                rec["split_f16"] = srec
+            except SystemExit as e:                               # its parity gate failed: report that instead of a number
+                rec["split_f16"] = {"error": str(e)}
+        if side and args.paced_sec > 0:
+            pl = paced_latency(cpc, sets, hz, ctx_sec, local_rank, args.paced_sec)
+            rec["paced_latency"] = gather_paced(dist, rank, world, pl)
+            rec["concurrent_streams_at_10ms"] = rec["paced_latency"].get("sustained_streams_all_ranks", pl.get("sustained_streams", 0))
+            if rec["concurrent_streams_at_10ms"] < 4096 * world and not args.split_f16 and "value" in rec.get("split_f16", {}):
+                # the north-star stream count is out of the fp32 matrix cores' reach for this configuration: measure what the
+                # split-precision path sustains under the same schedule (side record, like its throughput)
+                pls = paced_latency(cpc, sets, hz, ctx_sec, local_rank, args.paced_sec, split_f16=True)
+                rec["split_f16"]["paced_latency"] = gather_paced(dist, rank, world, pls)
+                rec["split_f16"]["concurrent_streams_at_10ms"] = rec["split_f16"]["paced_latency"].get("sustained_streams_all_ranks", pls.get("sustained_streams", 0))
+        return rec, extras
+
+    def host_latency(wl):
+        """host-inclusive tick latency: host audio -> results on host (pinned H2D + kernels + D2H + sync)"""
+        from vap_realtime_amd import engine
+        pin_in = engine.pinned_empty((wl.S, 2, wl.hop))
+        pin_out = engine.pinned_empty((wl.S, engine.OUT_STRIDE))
+        lat = []
+        for i in range(60 if wl.S * wl.T > 100000 else 210):
+            pin_in[...] = wl.audio[i % wl.NF]
+            t1 = time.perf_counter()
+            wl.eng.step(pin_in, out=pin_out)
+            lat.append((time.perf_counter() - t1) * 1e3)
+        lat = np.array(lat[10:])
+        return {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)), "max": float(lat.max()),
+                "staging": "pinned (vapx_host_alloc)"}
+
+    def overlap_groups_record(wl, steps):
+        # the same workload with the tick split into two overlap groups that free-run across ticks (VAPX_DEFER_JOIN):
+        # reported next to `value`, not as `value`, because co-running kernels stretch each other's launch time and the
+        # per-kernel roofline would stop meaning anything
+        from vap_realtime_amd import engine, weights as W
+        eng_g = engine.Engine(W.pack_blob(wl.cpc, wl.vap, wl.modes[0]), wl.hz, wl.ctx_sec, max_streams=wl.S, device_id=local_rank,
+                              groups=2, mode=wl.modes[0])
+        for i in range(wl.T + 5):
+            eng_g.step_device(wl.S, wl.d_audio[i % wl.NF].data_ptr(), wl.hop, wl.d_out.data_ptr(), stream=wl.stream, defer_join=True)
+        eng_g.join(wl.stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(steps):
+            eng_g.step_device(wl.S, wl.d_audio[i % wl.NF].data_ptr(), wl.hop, wl.d_out.data_ptr(), stream=wl.stream, defer_join=True)
+        eng_g.join(wl.stream)
+        torch.cuda.synchronize()
+        dtg = time.perf_counter() - t1
+        eng_g.close()
+        return {"groups": 2, "defer_join": True, "value": wl.S * steps / dtg, "unit": "frames/s", "ms_per_step": dtg / steps * 1e3}
 
     S, hz, ctx_sec, mode, dsteps, dwarm = WORKLOADS[args.workload]
     S = args.streams or S
@@ -471,9 +756,7 @@ def main():
     mode = args.mode or mode
     steps = args.steps if args.steps is not None else dsteps
     warmup = args.warmup if args.warmup is not None else dwarm
-    head, wl = run_workload(args.workload, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=args.groups, split_f16=args.split_f16,
-                            defer_join=args.defer_join)
-    T = wl.T
+    head, hx = full_record(args.workload, S, hz, ctx_sec, mode, steps, warmup, headline=True)
     result = {
         "metric": "VAP frames/sec (concurrent 16 kHz stereo streams, one frame per stream per step)",
         "value": head["value"], "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -482,96 +765,31 @@ def main():
     }
     result.update({k: v for k, v in head.items() if k not in result})
     result["config"] = head["config"]
+    if args.split_f16:
+        result["dtype"] = "f16x3 split products, f32 accumulate (opt-in)"
     # kept from round 1 for continuity: throughput priced with the reference's DENSE FLOP count
     if "dense_tflops" in head:
         result["step_tflops"] = head["dense_tflops"]
         result["step_frac_of_fp32_mfma_peak"] = head["dense_frac_of_fp32_mfma_peak"]
+    if hx.get("lat"):
+        result["latency_ms_host_inclusive"] = hx["lat"]
+    if hx.get("groups"):
+        result["overlap_groups"] = hx["groups"]
 
-    side = rank == 0 and world == 1 and not args.no_latency and not wl.followers
-    from vap_realtime_amd import engine, weights as W
-    if side and args.groups <= 1:
-        # the same workload with the tick split into two overlap groups that free-run across ticks (VAPX_DEFER_JOIN):
-        # reported next to `value`, not as `value`, because co-running kernels stretch each other's launch time and the
-        # per-kernel roofline above would stop meaning anything
-        eng_g = engine.Engine(W.pack_blob(wl.cpc, wl.vap, wl.modes[0]), hz, ctx_sec, max_streams=S, device_id=local_rank,
-                              groups=2, mode=wl.modes[0])
-        for i in range(T + 5):
-            eng_g.step_device(S, wl.d_audio[i % wl.NF].data_ptr(), wl.hop, wl.d_out.data_ptr(), stream=wl.stream, defer_join=True)
-        eng_g.join(wl.stream)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(steps):
-            eng_g.step_device(S, wl.d_audio[i % wl.NF].data_ptr(), wl.hop, wl.d_out.data_ptr(), stream=wl.stream, defer_join=True)
-        eng_g.join(wl.stream)
-        torch.cuda.synchronize()
-        dtg = time.perf_counter() - t1
-        result["overlap_groups"] = {"groups": 2, "defer_join": True, "value": S * steps / dtg, "unit": "frames/s",
-                                    "ms_per_step": dtg / steps * 1e3}
-        eng_g.close()
-
-    if side:
-        # host-inclusive tick latency: host audio -> results on host (pinned H2D + kernels + D2H + sync)
-        pin_in = engine.pinned_empty((S, 2, wl.hop))
-        pin_out = engine.pinned_empty((S, engine.OUT_STRIDE))
-        lat = []
-        for i in range(210):
-            pin_in[...] = wl.audio[i % wl.NF]
-            t1 = time.perf_counter()
-            wl.eng.step(pin_in, out=pin_out)
-            lat.append((time.perf_counter() - t1) * 1e3)
-        lat = np.array(lat[10:])
-        result["latency_ms_host_inclusive"] = {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)),
-                                               "max": float(lat.max()), "staging": "pinned (vapx_host_alloc)"}
-        del pin_in, pin_out
-    cpc, vap = wl.cpc, wl.vap
-    audio_one = wl.audio[:, :1].copy()                       # [NF,1,2,hop] for the CPU leg
-    NF = wl.NF
-    wl.close()
-    del wl
-    torch.cuda.empty_cache()
-
-    if side and not args.split_f16 and mode == "vap":
-        # the same workload on the opt-in split-precision path (VAPX_FLAG_SPLIT_F16): every GEMM-shaped contraction as
-        # three f16 MFMA products with fp32 accumulation — same deviation from the reference as the fp32-MFMA path
-        # (tests/test_split_precision_gpu.py).  Reported next to `value`, never as `value`, with its own roofline record.
-        rec, w2 = run_workload(args.workload + "_split_f16", S, hz, ctx_sec, mode, steps, warmup, ctx, split_f16=True)
-        w2.close()
-        rec["arithmetic"] = ("x = hi + lo (f16); hi.hi + lo.hi + hi.lo on v_mfma_f32_32x32x16_f16, fp32 accumulate; FFN block, attention "
-                             "projections, conv / projection GEMMs; opt-in, not the default")
-        result["split_f16"] = rec
-
-    # ---- the other single-GPU configurations of BASELINE.json, each with its own roofline ----
+    # ---- the other single-GPU configurations of BASELINE.json, each a full record ----
     result["configs"] = {}
+    overridden = bool(args.streams or args.frame_hz or args.ctx_sec or args.mode)
     for name in [c for c in args.configs.split(",") if c]:
-        if name == args.workload and not (args.streams or args.frame_hz or args.ctx_sec or args.mode):
+        if name == args.workload and not overridden:
             continue
         cS, chz, cctx, cmode, csteps, cwarm = WORKLOADS[name]
-        rec, w2 = run_workload(name, cS, chz, cctx, cmode, csteps, cwarm, ctx)
-        w2.close()
-        del w2
-        torch.cuda.empty_cache()
+        rec, _ = full_record(name, cS, chz, cctx, cmode, csteps, cwarm)
         result["configs"][name] = rec
 
-    if rank == 0 and world == 1 and not args.no_latency and args.paced_sec > 0 and hz == 20 and mode == "vap":
-        result["paced_latency"] = paced_latency(cpc, vap, hz, ctx_sec, local_rank, args.paced_sec)
-        result["concurrent_streams_at_10ms"] = result["paced_latency"].get("sustained_streams", 0)
+    if rank == 0 and world == 1 and side and args.front_end_streams > 0:
+        result["front_end"] = front_end_record(args.front_end_streams, 10.0)
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and mode == "vap":
-        from oracle.vap_oracle import ServerFramer, VapOracle
-        torch.set_num_threads(1)
-        o = VapOracle(cpc, vap, hz, ctx_sec)
-        st, fr = o.new_state(1), ServerFramer(1, 16000 // hz)
-        for i in range(T):                                        # fill the window (not timed)
-            o.step(fr.frame(audio_one[i % NF]), st)
-        n, t1 = 0, time.perf_counter()
-        while time.perf_counter() - t1 < args.cpu_baseline_sec:
-            o.step(fr.frame(audio_one[n % NF]), st)
-            n += 1
-        cdt = time.perf_counter() - t1
-        result["cpu_baseline"] = {"value": n / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
-                                  "sample": f"{n} frames of 1 stream (batch 1, window full, torch-CPU fp32, 1 thread) in {cdt:.1f} s; host has "
-                                            f"{physical_cores()} physical / {os.cpu_count()} logical cores",
-                                  "ms_per_frame": cdt / n * 1e3}
+    if rank == 0 and not args.no_cpu_baseline and mode == "vap":
         P = args.cpu_procs if args.cpu_procs >= 0 else physical_cores()
         if P > 1:
             # the reference deployed on every core: P independent single-threaded processes (one stream each), P = the
@@ -583,12 +801,12 @@ def main():
                 pass
             os.environ["OMP_NUM_THREADS"] = os.environ["MKL_NUM_THREADS"] = "1"    # inherited by the workers: one thread each, really
             with mp.get_context("spawn").Pool(P) as pool:
-                res = pool.map(_cpu_worker, [(i, hz, ctx_sec, 8.0) for i in range(P)], chunksize=1)
+                res = pool.map(_cpu_worker, [(i, hz, ctx_sec, 6.0) for i in range(P)], chunksize=1)
             agg = sum(n_ / dt_ for n_, dt_ in res)
             result["cpu_baseline_multiprocess"] = {
                 "value": agg, "unit": "frames/s", "cores": P, "kind": "port",
-                "sample": f"{P} single-threaded oracle processes (= physical cores) x 8 s, one stream each ({sum(r[0] for r in res)} frames); "
-                          f"host has {physical_cores()} physical / {os.cpu_count()} logical cores", "per_core": agg / P}
+                "sample": f"{P} single-threaded oracle processes (= physical cores) x 6 s at {hz} Hz / T={int(ctx_sec * hz)}, one stream each "
+                          f"({sum(r[0] for r in res)} frames); host has {physical_cores()} physical / {os.cpu_count()} logical cores", "per_core": agg / P}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

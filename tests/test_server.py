@@ -18,7 +18,7 @@ class FakeVap:
         self.n_streams, self.hop = n_streams, hop
         self.calls, self.resets = [], []
 
-    def process(self, frames, ids):
+    def process(self, frames, ids, on_numeric="raise"):
         self.calls.append((frames.shape, list(ids)))
         m = np.abs(frames).mean(axis=2)
         return {"p_now": m, "p_future": m[:, ::-1], "vad": (m > 0.5).astype(np.float32)}
@@ -167,7 +167,7 @@ class FakeAuxVap:
         self.mode, self.n_streams, self.hop, self.z = mode, 2, hop, z
         self.resets = []
 
-    def process(self, frames, ids):
+    def process(self, frames, ids, on_numeric="raise"):
         R = len(ids)
         aux = np.zeros((R, 4), np.float32)
         logits = np.zeros((R, 256), np.float32)
@@ -223,7 +223,7 @@ def test_non_finite_stream_is_reset_and_skipped_while_the_others_are_served():
     hop = 800
 
     class Poisoned(FakeVap):
-        def process(self, frames, ids):
+        def process(self, frames, ids, on_numeric="raise"):
             r = super().process(frames, ids)
             r["status"] = np.array([1 if s == 1 else 0 for s in ids], np.int32)
             return r

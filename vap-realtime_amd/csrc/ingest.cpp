@@ -90,7 +90,10 @@ int encode_tail(int mode, const float* row, uint8_t* dst) {
     put_u32(p, 1); put_f64(p, (double)row[VAPX_OUT_AUX + 1]);
     put_u32(p, 1); put_f64(p, (double)row[VAPX_OUT_AUX + 2]);
   } else {                                // u32 n | p_bc rows | 3 x (u32 1 | p)              (util.py:213-237, vap_nod_main.py:276)
-    const int n = (int)row[VAPX_OUT_NVALID];
+    // clamped to the tail buffer's 256 rows: a step function of vapx_ingest_open_fn that leaves the column unset must not
+    // turn into an out-of-bounds write here (vapx_wire_encode_result validates the same range)
+    int n = (int)row[VAPX_OUT_NVALID];
+    n = n < 0 ? 0 : (n > 256 ? 256 : n);
     put_u32(p, (uint32_t)n);
     for (int i = 0; i < n; ++i) put_f64(p, (double)row[VAPX_OUT_LOGITS + i]);
     for (int k = 1; k <= 3; ++k) { put_u32(p, 1); put_f64(p, (double)row[VAPX_OUT_AUX + k]); }
@@ -363,9 +366,15 @@ size_t feed(vapx_ingest* g, int slot, const uint8_t* p, size_t n) {
   return used;
 }
 
-void on_data(vapx_ingest* g, int r, int slot, uint8_t* scratch, size_t cap) {
+void on_data(vapx_ingest* g, int r, int slot, uint8_t* scratch, size_t cap, uint32_t events) {
   Slot& s = g->slots[slot];
   if (s.fd_in < 0) return;
+  if (s.paused) {
+    // a paused slot is armed with events = 0, but EPOLLHUP / EPOLLERR are reported regardless (level-triggered): never read
+    // new bytes past the parked backlog (they would overtake it), and a peer that is gone is dropped instead of spinning here
+    if (events & (EPOLLHUP | EPOLLERR)) drop_input(g, r, slot);
+    return;
+  }
   for (int round = 0; round < 4; ++round) {   // bounded work per wake-up: fairness between streams
     ssize_t n = recv(s.fd_in, scratch, cap, 0);
     if (n < 0) {
@@ -377,7 +386,7 @@ void on_data(vapx_ingest* g, int r, int slot, uint8_t* scratch, size_t cap) {
     g->rx_bytes.fetch_add(n, std::memory_order_relaxed);
     size_t used = feed(g, slot, scratch, (size_t)n);
     if (used < (size_t)n) {                 // no free frame buffer: park the rest and stop reading this socket
-      s.backlog.assign(scratch + used, scratch + n);
+      s.backlog.insert(s.backlog.end(), scratch + used, scratch + n);   // (append: never overwrite bytes parked earlier)
       {
         std::lock_guard<std::mutex> lk(g->resume_mu[r]);
         s.paused = true;
@@ -510,7 +519,7 @@ void rx_main(vapx_ingest* g, int r) {
           todo.swap(g->resume[r]);
         }
         for (int slot : todo) do_resume(g, r, slot);
-      } else on_data(g, r, (int)(tag & 0xffffffffu), scratch.data(), scratch.size());
+      } else on_data(g, r, (int)(tag & 0xffffffffu), scratch.data(), scratch.size(), evs[i].events);
     }
     if (n > 0) {
       t_last_busy = mono_now();
@@ -734,6 +743,7 @@ int open_common(vapx_ingest* g, const vapx_ingest_config* cfg) {
   g->batch_ids.assign(g->max_batch, 0);
   for (auto& j : g->jobs) {
     j.out = grab(ob);
+    if (j.out) memset(j.out, 0, ob * sizeof(float));   // hipHostMalloc memory is not zeroed: a step function may leave columns unset
     j.rows.reserve(g->max_batch);
   }
   if (!g->stage || !g->batch_audio || !g->jobs[0].out || !g->jobs[1].out) return VAPX_E_NOMEM;

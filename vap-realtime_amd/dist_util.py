@@ -51,11 +51,12 @@ def _parse_cpulist(txt: str):
     return cpus
 
 
-def pin_rank_to_cores(local_rank: int, local_world: int):
+def pin_rank_to_cores(local_rank: int, local_world: int, device_index=None):
     """Pin this process to host cores near its GPU: the NUMA node of the GPU's PCI function when sysfs exposes it
     (shared evenly by the ranks of that node), else an even split of the visible cores.  The host side of a shard (audio
-    staging, result fan-out) then stays off the other ranks' cores.  Returns the core list or None (single rank / no
-    affinity support)."""
+    staging, result fan-out) then stays off the other ranks' cores.  ``device_index`` = the torch device this rank really uses
+    when it is not ``local_rank`` (``--share-gpu``, a remapped CUDA_VISIBLE_DEVICES); ranks on one device share its node's cores
+    evenly.  Returns the core list or None (single rank / no affinity support)."""
     if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
         return None
     try:
@@ -65,8 +66,12 @@ def pin_rank_to_cores(local_rank: int, local_world: int):
             import torch
             if torch.cuda.is_available():
                 nodes = []
+                ndev = torch.cuda.device_count()
                 for r in range(local_world):
-                    p = torch.cuda.get_device_properties(r)
+                    # device of rank r: everyone on `device_index` when it was given and differs from the rank (shared GPU),
+                    # else rank r -> device r (clamped to the visible devices)
+                    d = device_index if (device_index is not None and device_index != local_rank) else min(r, ndev - 1)
+                    p = torch.cuda.get_device_properties(d)
                     bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
                     with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
                         nodes.append(int(f.read()))
@@ -92,7 +97,8 @@ def pin_rank_to_cores(local_rank: int, local_world: int):
 
 def barrier(dist, device_sync=None):
     """Device synchronise, rendezvous of all ranks, device synchronise.  With a CUDA backend the rendezvous is an all-reduce
-    of one CUDA scalar (RCCL over xGMI), otherwise a CPU barrier."""
+    of one CUDA scalar (RCCL over xGMI), otherwise a CPU barrier.  Either way the HOST returns only after every rank has
+    arrived (the all-reduce result is read back), also without ``device_sync``."""
     if device_sync:
         device_sync()
     if dist is not None:
@@ -102,6 +108,7 @@ def barrier(dist, device_sync=None):
             if torch.cuda.is_available() and "nccl" in str(dist.get_backend()):
                 t = torch.ones(1, device="cuda")
                 dist.all_reduce(t)
+                t.item()                                          # block the host: an enqueued collective is not a barrier yet
                 done = True
         except Exception:                                         # noqa: BLE001
             done = False

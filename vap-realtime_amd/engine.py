@@ -250,11 +250,16 @@ class Engine:
         self._check(self.lib.vapx_attach_trunk(self._h, leader._h), "vapx_attach_trunk")
         self._leader = leader                                # keeps the leader alive as long as the follower
 
-    def step_follow(self, n: int) -> np.ndarray:
-        """Follower step on the host path: consumes the encoder output of the leader's latest ``step``."""
-        out = np.empty((n, OUT_STRIDE), dtype=np.float32)
-        self._check(self.lib.vapx_step(self._h, n, None, None, 0, _np_ptr(out), 0, None), "vapx_step")
-        return out
+    def step_follow(self, n: int, out: Optional[np.ndarray] = None, on_numeric: str = "raise") -> np.ndarray:
+        """Follower step on the host path: consumes the encoder output of the leader's latest ``step`` (``out`` / ``on_numeric``
+        as in ``step``)."""
+        if out is None:
+            out = np.empty((n, OUT_STRIDE), dtype=np.float32)
+        assert out.dtype == np.float32 and out.flags.c_contiguous and out.size >= n * OUT_STRIDE
+        rc = self.lib.vapx_step(self._h, n, None, None, 0, _np_ptr(out), 0, None)
+        if not (rc == E_NUMERIC and on_numeric == "status"):
+            self._check(rc, "vapx_step")
+        return out.reshape(-1, OUT_STRIDE)[:n]
 
     def step_follow_device(self, n: int, out_ptr: int, stream: int = 0):
         self._check(self.lib.vapx_step(self._h, n, None, None, 0, out_ptr, OUT_DEVICE, stream or None), "vapx_step")

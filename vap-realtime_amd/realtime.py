@@ -196,9 +196,13 @@ class ManyStreamVAP:
         self.hop = 16000 // frame_rate
         self.mode = mode
 
-    def process(self, new_samples: np.ndarray, stream_ids: Optional[Sequence[int]] = None) -> Dict[str, np.ndarray]:
-        """new_samples float [n,2,hop] (or [n,2,hop+320] complete frames) -> dict of [n,...] arrays."""
-        res = _engine.split_outputs(self.engine.step(new_samples, stream_ids, on_numeric="status"))
+    def process(self, new_samples: np.ndarray, stream_ids: Optional[Sequence[int]] = None,
+                on_numeric: str = "raise") -> Dict[str, np.ndarray]:
+        """new_samples float [n,2,hop] (or [n,2,hop+320] complete frames) -> dict of [n,...] arrays.  A stream with non-finite
+        results raises ``VapxError`` (the engine's fail-loudly rule: an offline run must not write 'nan' rows for the rest of a
+        file); a caller that handles the per-stream ``status`` column itself — the TCP front-end resets that dialogue and keeps
+        serving the others — passes ``on_numeric="status"``."""
+        res = _engine.split_outputs(self.engine.step(new_samples, stream_ids, on_numeric=on_numeric))
         if self.mode == "nod":      # p_bc of every window row (vap_nod_main.py:276 quirk) sits in the logits columns
             res["p_bc"] = [res["logits"][k, :int(res["n"][k])] for k in range(len(res["n"]))]
         return res

@@ -143,7 +143,7 @@ class ManyStreamServer:
             return
         frames = self.asm.pop(ready)
         echo = self.asm.last_echo
-        res = self.vap.process(frames, ready.astype(np.int32))
+        res = self.vap.process(frames, ready.astype(np.int32), on_numeric="status")
         t = time.time()
         # a stream whose results are not finite (poisoned state, engine status column) is reset and gets no packet this
         # tick; every other stream of the batch is served as usual
