@@ -82,6 +82,14 @@ struct PerDeviceOnce {
   }
 };
 
+// The same value as a NEW SSA definition the optimiser cannot look through: index expressions derived from it are not commoned with
+// the ones of an earlier kernel phase, so they die with their phase instead of occupying registers across the whole kernel
+// (hipcc otherwise keeps e.g. the 32 accumulator-row indices of a 64-row tile live from the softmax to the final stores and spills).
+__device__ __forceinline__ int opaque_vgpr(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 // value of lane `l` (wave-uniform index) in every lane: v_readlane_b32, no LDS
 __device__ __forceinline__ float lane_bcast(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));

@@ -90,16 +90,15 @@ struct vapx_engine {
   hipEvent_t gdone[kMaxGroups] = {};
   hipEvent_t gstart = nullptr;
   int n_groups = 1;
-  int ffn_tile_rows = 0;   // tuning knob (env VAPX_FFN_TILE): 32 or 64 rows per FFN-block workgroup
-  int group0_streams = 0;    // experiment knob (env VAPX_GROUP0_STREAMS): size of the first of two overlap groups
   // debug knob (env VAPX_POISON_SCRATCH): every scratch buffer is refilled with NaN bit patterns before each step and the rings start as
   // NaNs, so a kernel that consumes anything it (or an earlier kernel of the same tick) did not write shows up as a non-finite output
   std::vector<std::pair<void*, size_t>> poison;
-  int split_mask = 15;       // diagnostic knob (env VAPX_SPLIT_MASK): which kernel families of a VAPX_FLAG_SPLIT_F16 engine run split (1 GEMM, 2 attn_block, 4 FFN block, 8 unfused conv tail)
-  bool force_long = false;   // experiment knob (env VAPX_FORCE_LONG): short windows through the long-window kernel chain
+#ifdef VAPX_TRACE   // debug build only (make trace -> libvapx_trace.so): per-workgroup phase stamps, tools/ffn_trace.py / tools/attn_trace.py
   unsigned long long* ffn_trace = nullptr;   // env VAPX_FFN_TRACE=<file>: phase stamps of the layer-0 FFN block's workgroups
-  size_t ffn_trace_wgs = 0;
-  std::string ffn_trace_path;
+  unsigned long long* attn_trace = nullptr;  // env VAPX_ATTN_TRACE=<file>: phase stamps of the layer-1 self-attention block's workgroups
+  size_t ffn_trace_wgs = 0, attn_trace_wgs = 0;
+  std::string ffn_trace_path, attn_trace_path;
+#endif
   float* out_pinned = nullptr;
   float* audio_pinned = nullptr;          // staging for pageable host audio (callers holding vapx_host_alloc memory skip it)
   hipEvent_t audio_evt = nullptr;         // the H2D copy out of audio_pinned has completed
@@ -250,7 +249,7 @@ struct ProfScope {
 
 hipError_t gemm(vapx_engine* h, const GemmArgs& g, int epi, hipStream_t st) {
   ProfScope ps(h, epi, st);
-  if ((h->cfg.flags & VAPX_FLAG_SPLIT_F16) && (h->split_mask & 1)) {
+  if (h->cfg.flags & VAPX_FLAG_SPLIT_F16) {
     GemmArgs gs = g;
     gs.split = 1;
     return launch_gemm_f32(gs, epi, 0, st);
@@ -286,7 +285,7 @@ int run_encoder(vapx_engine* h, const Scratch& sc, const StateView& sv, int B, c
   // one stream per workgroup pays 27 % row padding: worth it only while the three GEMMs cannot fill the chip
   // (on the split-precision path the three GEMMs are 2x cheaper and beat the fp32 fused tail even at 256 streams)
   const bool fused_tail = conv_tail_supported(P[1], h->ncpc) && !(h->cfg.flags & VAPX_FLAG_UNFUSED_CONV) &&
-                          !((h->cfg.flags & VAPX_FLAG_SPLIT_F16) && (h->split_mask & 8)) && B <= 512;
+                          !(h->cfg.flags & VAPX_FLAG_SPLIT_F16) && B <= 512;
   char nm[32];
   for (int i = 0; i < (fused_tail ? 1 : 3); ++i) {
     const ConvSpec& c = cs[i];
@@ -358,25 +357,31 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
         HIPCHK(h, gemm(h, g, EPI_STORE, st));
       }
     }
-    if (T <= 64 && !h->force_long) {
+    if (T <= 64) {
       // fused: attention + output projection + residual + LayerNorm (+ cross-attention queries)
       AttnBlockArgs ab;
       memset(&ab, 0, sizeof ab);
       ab.q = sc.qkv; ab.k = sc.qkv + 256; ab.v = sc.qkv + 512; ab.ldq = 768; ab.ldkv = 768; ab.swap_kv = 0;
-      const bool asplit = (h->cfg.flags & VAPX_FLAG_SPLIT_F16) != 0 && (h->split_mask & 2);
+      const bool asplit = (h->cfg.flags & VAPX_FLAG_SPLIT_F16) != 0;
       ab.split = asplit ? 1 : 0;
-      ab.bn = sc.bn; ab.T = T; ab.wprojf = asplit ? Lw.wprojh : Lw.wprojf; ab.resid = xin; ab.xmid = sc.xmid; ab.xn = nullptr;
+      ab.bn = sc.bn; ab.T = T; ab.wprojf = asplit ? Lw.wprojh : Lw.wprojf; ab.resid = xin; ab.xmid = sc.xmid;
       if (l == 0 && rv && rv->ring) {   // Q|K|V and the residual straight from the per-stream rings
         ab.q = rv->ring_qkv; ab.k = rv->ring_qkv + 256; ab.v = rv->ring_qkv + 512; ab.resid = rv->ring;
         ab.ring_rot = sc.rot; ab.ids = rv->ids;
       }
       if (l == 0) { ab.ln_g = Lw.ln_ffn_g; ab.ln_b = Lw.ln_ffn_b; }
-      else { ab.ln_g = Lw.ln_src_g; ab.ln_b = Lw.ln_src_b; ab.wqxf = asplit ? Lw.wqxh : Lw.wqxf; ab.qx = sc.qx; ab.xn = nullptr; }
+      else { ab.ln_g = Lw.ln_src_g; ab.ln_b = Lw.ln_src_b; ab.wqxf = asplit ? Lw.wqxh : Lw.wqxf; ab.qx = sc.qx; }
+#ifdef VAPX_TRACE
+      if (h->attn_trace && l == 1 && (size_t)B * 2 <= 16384) { ab.trace = h->attn_trace; h->attn_trace_wgs = (size_t)B * 2; }
+#endif
       { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attn_block(ab, B, st)); }
+#ifdef VAPX_TRACE
+      ab.trace = nullptr;
+#endif
       if (l > 0) {
         ab.q = sc.qx; ab.k = sc.kvx; ab.v = sc.kvx + 256; ab.ldq = 256; ab.ldkv = 512; ab.swap_kv = 1;
         ab.wprojf = asplit ? Lw.wprojxh : Lw.wprojxf; ab.resid = sc.xmid; ab.ln_g = Lw.ln_ffn_g; ab.ln_b = Lw.ln_ffn_b;
-        ab.wqxf = nullptr; ab.qx = nullptr; ab.xn = nullptr; ab.ring_rot = nullptr; ab.ids = nullptr;
+        ab.wqxf = nullptr; ab.qx = nullptr; ab.ring_rot = nullptr; ab.ids = nullptr;
         { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attn_block(ab, B, st)); }
       }
     } else if (!(h->cfg.flags & (VAPX_FLAG_UNFUSED_PROJ | VAPX_FLAG_SPLIT_F16))) {
@@ -422,14 +427,13 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
       }
     }
     // feed-forward (+ next layer's projections)
-    const bool split = (h->cfg.flags & VAPX_FLAG_SPLIT_F16) != 0 && (h->split_mask & 4);   // fp32-accurate products on the f16 matrix cores
+    const bool split = (h->cfg.flags & VAPX_FLAG_SPLIT_F16) != 0;   // fp32-accurate products on the f16 matrix cores
     FfnArgs fa;
     memset(&fa, 0, sizeof fa);
     fa.xmid = sc.xmid; fa.lnf_g = Lw.ln_ffn_g; fa.lnf_b = Lw.ln_ffn_b; fa.xout = xout; fa.M = M;
     if (pre_att) { fa.mode = 1; fa.att = pre_att; fa.wprojf = pre_w; fa.resid = pre_resid; fa.xmid_out = sc.xmid; }
     if (pre_ring) { fa.resid_rot = sc.rot; fa.resid_ids = rv->ids; fa.resid_T = T; }
     fa.w0f = split ? Lw.w0h : Lw.w0f; fa.w3f = split ? Lw.w3h : Lw.w3f;
-    fa.tile_rows = h->ffn_tile_rows ? h->ffn_tile_rows : (split ? 0 : 32);
     if (l + 1 < l_end) {
       const Layer& Ln = h->layer[l + 1];
       const float* nqkv = split ? Ln.wqkvh : Ln.wqkvf;
@@ -444,11 +448,13 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
         }
       }
     }
+#ifdef VAPX_TRACE
     if (h->ffn_trace && l == 0) {
       fa.trace = h->ffn_trace;
       h->ffn_trace_wgs = std::min<size_t>(16384, (size_t)(M + 31) / 32);
       if ((size_t)(M + 31) / 32 > 16384) fa.trace = nullptr;
     }
+#endif
     if (split) { ProfScope ps(h, CLS_FFN, st); HIPCHK(h, launch_ffn_block_f16x3(fa, st)); }
     else
     { ProfScope ps(h, CLS_FFN, st); HIPCHK(h, launch_ffn_block(fa, st)); }
@@ -757,13 +763,18 @@ void vapx_destroy(vapx_handle h) {
   for (vapx_engine* f : h->followers) { f->trunk = nullptr; f->orphaned = true; }
   (void)hipSetDevice(h->cfg.device_id);
   (void)hipDeviceSynchronize();
-  if (h->ffn_trace) {   // dump the stamps of the last traced launch: [wgs][32] u64
-    std::vector<unsigned long long> host(h->ffn_trace_wgs * 32);
-    if (!host.empty() && hipMemcpy(host.data(), h->ffn_trace, host.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
-      if (FILE* f = fopen(h->ffn_trace_path.c_str(), "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
+#ifdef VAPX_TRACE
+  auto dump_trace = [&](unsigned long long* buf, size_t wgs, const std::string& path) {   // stamps of the last traced launch: [wgs][32] u64
+    if (!buf) return;
+    std::vector<unsigned long long> host(wgs * 32);
+    if (!host.empty() && hipMemcpy(host.data(), buf, host.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+      if (FILE* f = fopen(path.c_str(), "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
     }
-    dfree(h->ffn_trace);
-  }
+    dfree(buf);
+  };
+  dump_trace(h->ffn_trace, h->ffn_trace_wgs, h->ffn_trace_path);
+  dump_trace(h->attn_trace, h->attn_trace_wgs, h->attn_trace_path);
+#endif
   float* fp[] = {h->w, h->ring, h->ring_qkv, h->h_state, h->c_state, h->carry, h->audio_dev, h->out_dev, h->sc.h0, h->sc.h1, h->sc.h2, h->sc.h3,
                  h->sc.z, h->sc.lstm_out, h->sc.e, h->sc.xl[0], h->sc.xl[1], h->sc.xl[2], h->sc.xl[3], h->sc.xl[4], h->sc.xn, h->sc.xmid, h->sc.att,
                  h->sc.qkv, h->sc.qx, h->sc.kvx, h->sc.ffn, h->sc.gx, h->sc.last[0], h->sc.last[1], h->sc.last[2],
@@ -890,14 +901,16 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
     for (int i = 0; i < 6; ++i) add(h->sc.last[i], B * 2 * 256);
     add(h->sc.en, B * 2 * 256); add(h->sc.qkv_new, B * 2 * 768); add(h->sc.lffn, B * 2 * 768); add(h->out_dev, B * VAPX_OUT_STRIDE);
   }
-  if (const char* ev = getenv("VAPX_FFN_TILE")) h->ffn_tile_rows = atoi(ev);
-  if (const char* ev = getenv("VAPX_GROUP0_STREAMS")) h->group0_streams = atoi(ev);
-  if (getenv("VAPX_FORCE_LONG")) h->force_long = true;
-  if (const char* e = getenv("VAPX_SPLIT_MASK")) h->split_mask = atoi(e);
+#ifdef VAPX_TRACE
   if (const char* ev = getenv("VAPX_FFN_TRACE")) {
     h->ffn_trace_path = ev;
     CR(dalloc(&h->ffn_trace, (size_t)16384 * 32));
   }
+  if (const char* ev = getenv("VAPX_ATTN_TRACE")) {
+    h->attn_trace_path = ev;
+    CR(dalloc(&h->attn_trace, (size_t)16384 * 32));
+  }
+#endif
   h->n_groups = cfg->flags & 0xF;
   if (h->n_groups == 0) h->n_groups = 1;   // measured: no gain at 256 streams, +2 % at 4096 with 2
   if (h->n_groups > vapx_engine::kMaxGroups) h->n_groups = vapx_engine::kMaxGroups;
@@ -982,10 +995,6 @@ int vapx_step(vapx_handle h, int32_t n, const int32_t* stream_ids, const float* 
   }
   for (int g = 0; g < G; ++g) {
     int b0 = (int)((long)n * g / G), b1 = (int)((long)n * (g + 1) / G);
-    if (G == 2 && h->group0_streams > 0 && h->group0_streams < n) {   // uneven split (experiment knob VAPX_GROUP0_STREAMS)
-      b0 = g == 0 ? 0 : h->group0_streams;
-      b1 = g == 0 ? h->group0_streams : n;
-    }
     const int nb = b1 - b0;
     hipStream_t gs = G > 1 ? h->gstream[g] : st;
     const Scratch sc = h->sc.slice(b0, h->P, h->ncpc, h->T);

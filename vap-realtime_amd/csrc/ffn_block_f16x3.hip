@@ -278,12 +278,9 @@ hipError_t launch_ffn_block_f16x3(const FfnArgs& a, hipStream_t st) {
   static PerDeviceOnce attr_set;
   attr_set.run([] {
     (void)hipFuncSetAttribute((const void*)ffn_block_f16x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)ffn_block_f16x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  // 64-row tiles (VAPX_FFN_TILE=64) halve the weight stream but leave one wave per SIMD: measured 8 % slower at 4096 streams
-  const int mt = a.tile_rows == 64 ? 2 : 1;
-  const size_t lds = (size_t)4 * 32 * mt * LD16 * sizeof(_Float16) + 4 * 32 * mt * sizeof(float);
-  if (mt == 2) hipLaunchKernelGGL(ffn_block_f16x3_kernel<2>, dim3((a.M + 63) / 64), dim3(256), lds, st, a);
-  else hipLaunchKernelGGL(ffn_block_f16x3_kernel<1>, dim3((a.M + 31) / 32), dim3(256), lds, st, a);
+  // (64-row tiles — MT = 2 — halve the weight stream but leave one wave per SIMD: measured 8 % slower at 4096 streams, not instantiated)
+  const size_t lds = (size_t)4 * 32 * LD16 * sizeof(_Float16) + 4 * 32 * sizeof(float);
+  hipLaunchKernelGGL(ffn_block_f16x3_kernel<1>, dim3((a.M + 31) / 32), dim3(256), lds, st, a);
   return hipGetLastError();
 }

@@ -17,9 +17,10 @@ struct FfnArgs {
   const float* wkvxf;  // next layer's cross K,V projections, 2 fragment-major chunks (null: skip)
   float* kvx;          // [M][512]
   int n_qkv_chunks;    // 3 (Q,K,V) or 2 (K,V only: pass wqkvf + 65536)
-  int tile_rows;       // 32 (default) or 64 rows per workgroup
   int M;
-  unsigned long long* trace;   // optional [grid][32] s_memtime stamps of workgroup phases (env VAPX_FFN_TRACE), null in production
+#ifdef VAPX_TRACE
+  unsigned long long* trace;   // debug build: optional [grid][32] s_memtime stamps of workgroup phases (env VAPX_FFN_TRACE)
+#endif
   // Long-window path (T > 64): the attention output projection rides in front of the block instead of a separate GEMM:
   //   xmid = resid + att . Wproj^T   (-> xmid_out, the residual stream), then LayerNorm as usual.
   // mode 0: xmid is read from global (fused attention block wrote it).  mode 1: pre-projection + the whole block.
@@ -44,18 +45,20 @@ struct AttnBlockArgs {
   const int* bn;
   const float* wprojf;  // output projection, fragment-major 256x256
   const float* resid;   // [B*2*T][256]
-  const float* ln_g;
+  const float* ln_g;    // ln_src_attn (only read with wqxf)
   const float* ln_b;
   float* xmid;          // resid + att.Wproj^T
-  float* xn;            // LayerNorm(xmid) -> global, or null (the FFN block re-normalises xmid itself; only the
-                        // unfused cross-q GEMM of long windows needs this copy)
-  const float* wqxf;    // optional: cross-attention query projection (fragment-major), null to skip
+  const float* wqxf;    // optional: cross-attention query projection (fragment-major), null to skip (then no LayerNorm either:
+                        // the FFN block normalises xmid itself)
   float* qx;            // [B*2*T][256]
   const int* ring_rot;  // [B] or null.  Non-null: q/k/v/resid are per-stream RINGS (slab = slot*2+channel, logical
                         // row i in ring slot (i + ring_rot[b]) % T) instead of chronological batch buffers
   const int* ids;       // [B] stream slots (null: identity); only used with ring_rot
   int T, ldq, ldkv, swap_kv;
   int split;            // 1: wprojf / wqxf are f16 hi/lo fragment copies, projections run as 3-term split products
+#ifdef VAPX_TRACE
+  unsigned long long* trace;   // debug build: optional [grid][32] s_memtime stamps of workgroup phases (env VAPX_ATTN_TRACE)
+#endif
 };
 
 struct ConvTailArgs {

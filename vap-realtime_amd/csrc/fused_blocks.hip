@@ -25,8 +25,9 @@ constexpr int LDH = 260;   // resident [32][256] buffer row stride (256 + 4 pad)
 // fragments are shared with nobody: they go global -> VGPR directly (one coalesced 1 KiB load per
 // 4 MFMAs) and the K loops contain no barrier and no LDS store at all.  Only the A operand (the 32
 // activation rows all four waves share) lives in LDS.
-// MT = 32-row sub-tiles per workgroup (1: 32 rows, 67 KB LDS, 2 workgroups/CU; 2: 64 rows, 133 KB,
-// 1 workgroup/CU but every weight fragment feeds two MFMAs -> half the L2->VGPR weight traffic).
+// MT = 32-row sub-tiles per workgroup.  Shipped: MT = 1 (32 rows, 67 KB LDS, 2 workgroups / CU).  MT = 2 (64 rows, 133 KB, 1 workgroup / CU,
+// every weight fragment feeds two MFMAs) measured slower at every batch size (one wave per SIMD: nothing fills the barrier phases) and is not
+// instantiated.
 template <int MT, int MODE = 0>
 __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const FfnArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -40,13 +41,17 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5, kh = hi * 4;
   const int m0 = blockIdx.x * BM;
+#ifdef VAPX_TRACE
   int stamp_k = 0;
-  auto STAMP = [&]() {   // phase time stamps of wave 0 (debug builds of the timeline: tools/ffn_trace.py)
+  auto STAMP = [&]() {   // phase time stamps of wave 0 (debug build `make trace`: tools/ffn_trace.py)
     if (g.trace && tid == 0 && stamp_k < 32) g.trace[(long)blockIdx.x * 32 + stamp_k] = __builtin_amdgcn_s_memtime();
     ++stamp_k;
   };
   STAMP();
   if (g.trace && tid == 0) g.trace[(long)blockIdx.x * 32 + 28] = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz, chip-wide
+#else
+  auto STAMP = [] {};
+#endif
 
   // acc[mt][2] += A[BM x 256] (LDS) . Wsub^T for this wave's 64 columns; wfrag = 256x256 fragment
   // block.  Weight fragments run through an in-place register ring one 8-kc block ahead (~4k MFMA
@@ -322,7 +327,9 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
       STAMP();   // 23, 25, 27
     }
   }
+#ifdef VAPX_TRACE
   if (g.trace && tid == 0) g.trace[(long)blockIdx.x * 32 + 29] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -347,13 +354,15 @@ typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 constexpr int ALD16 = 264;   // halves per sAtt row in SPLIT mode
 
-template <bool SPLIT>
+// QX: the launch also produces the cross-attention queries, qx = LayerNorm(x'; ln_src) . Wq_x^T (self-attention half of a stereo layer).
+// Without QX nothing in the launch consumes LayerNorm(x') — the FFN block normalises xmid itself when it stages its tile — so the
+// block stores x' straight from the accumulators and skips the LayerNorm altogether (3 of the 5 attention launches of a tick).
+template <bool SPLIT, bool QX>
 __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[4 * 64 * KV_LD2 + 256];
+  __shared__ __attribute__((aligned(16))) float lds[4 * 64 * KV_LD2];
   float* sAtt = lds;                        // [64][260] (aliases the V tiles after a barrier)
   _Float16* sAh = (_Float16*)lds;           // SPLIT: [64][264] halves, hi then lo
   _Float16* sAl = sAh + 64 * ALD16;
-  float* red = lds + 4 * 64 * KV_LD2;       // [4][64]
   const int tid = threadIdx.x, lane = tid & 63;
   const int h = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar wave / head index (see ffn_block_kernel)
   const int l31 = lane & 31, hi = lane >> 5, kh = hi * 4;
@@ -371,10 +380,23 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
   const float* vp = a.v + slab_kv * T * a.ldkv + h * 64;
   const float* kp = a.k + slab_kv * T * a.ldkv + h * 64;
   const bool two = n > 32;                  // second query/key tile holds valid rows
-  // All global loads of the first query tile are issued before anything waits: this head's V tile (-> LDS), the
-  // K fragments (A operand of S^T = K.Q^T: key row j, k-slots kc*8 + 4*hi ..+3; rows >= n are clamped, their
-  // scores are masked below) and the Q fragments of tile 0 — one memory latency instead of three.
-  f32x4 kf0[8], qf0[8];
+#ifdef VAPX_TRACE
+  int stamp_k = 0;
+  auto STAMP = [&]() {   // phase time stamps of wave 0 (debug build `make trace`: tools/attn_trace.py)
+    if (a.trace && tid == 0 && stamp_k < 28) a.trace[(long)blockIdx.x * 32 + stamp_k] = __builtin_amdgcn_s_memtime();
+    ++stamp_k;
+  };
+  STAMP();   // 0: entry
+  if (a.trace && tid == 0) a.trace[(long)blockIdx.x * 32 + 28] = __builtin_amdgcn_s_memrealtime();
+#else
+  auto STAMP = [] {};
+#endif
+  // EVERY global load of the attention phase is issued before anything waits (one memory latency for the whole phase): this head's
+  // V tile (-> LDS), then the A operands of S^T = K.Q^T (key row j, k-slots kc*8 + 4*hi ..+3; rows >= n are clamped, their scores
+  // are masked below) and the Q fragments of BOTH query tiles.  V goes first: loads return in order, so the LDS stores that wait
+  // for V leave the 32 K / Q loads in flight.  (Round 2 fetched the second tile's K / Q fragments inside its MFMA loop: ten exposed
+  // L2 / HBM latencies per workgroup, the largest single cost of the block.)
+  f32x4 kf0[8], qf0[8], kf1[8], qf1[8];
   {
     f32x4 vv[16];
     const int q4 = (lane & 15) * 4, jb = lane >> 4;
@@ -385,13 +407,22 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
       vv[u] = *(const f32x4*)(vp + (long)prow(jc) * a.ldkv + q4);
     }
     {
-      int j0 = l31 < n ? l31 : n - 1;
+      const int j0 = l31 < n ? l31 : n - 1;
       const float* k0 = kp + (long)prow(j0) * a.ldkv + kh;
 #pragma unroll
       for (int kc = 0; kc < 8; ++kc) kf0[kc] = *(const f32x4*)(k0 + kc * 8);
       const float* qp = a.q + (slab_q * T + prow(j0)) * a.ldq + h * 64 + kh;
 #pragma unroll
       for (int kc = 0; kc < 8; ++kc) qf0[kc] = *(const f32x4*)(qp + kc * 8);
+    }
+    if (two) {
+      const int j1 = 32 + l31 < n ? 32 + l31 : n - 1;
+      const float* k1 = kp + (long)prow(j1) * a.ldkv + kh;
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc) kf1[kc] = *(const f32x4*)(k1 + kc * 8);
+      const float* qp = a.q + (slab_q * T + prow(j1)) * a.ldq + h * 64 + kh;
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc) qf1[kc] = *(const f32x4*)(qp + kc * 8);
     }
     __builtin_amdgcn_sched_barrier(0);      // keep the K / Q loads above the LDS stores that wait for V
 #pragma unroll
@@ -400,87 +431,89 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
       *(f32x4*)&Vs[j * KV_LD2 + q4] = j < n ? vv[u] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
+  STAMP();   // 1: V tile in LDS (first memory latency)
   const float slope = exp2f(-2.0f * (float)(h + 1));
 
-  // one query tile `it` against key tiles 0..NJ-1; returns O^T tiles scaled by 1/rowsum
-  auto qtile = [&](int it, bool use_j1, f32x16& o0, f32x16& o1) {
-    const int i = it * 32 + l31;
-    const int iq = i < n ? i : n - 1;
-    f32x4 qf[8];
-    if (it == 0) {
+  // S^T tile = K_tile . Q_tile^T (unscaled: the 1/16 is a power of two and rides in the softmax fma, bit-identical)
+  auto scores = [&](f32x16& s, const f32x4 (&kf)[8], const f32x4 (&qf)[8]) {
 #pragma unroll
-      for (int kc = 0; kc < 8; ++kc) qf[kc] = qf0[kc] * 0.0625f;
-    } else {
-      const float* qp = a.q + (slab_q * T + prow(iq)) * a.ldq + h * 64 + kh;
-#pragma unroll
-      for (int kc = 0; kc < 8; ++kc) qf[kc] = *(const f32x4*)(qp + kc * 8) * 0.0625f;
-    }
-    f32x16 s0, s1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
     for (int kc = 0; kc < 8; ++kc)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf0[kc][s], qf[kc][s], s0, 0, 0, 0);
-    if (use_j1) {   // second key tile: fragments fetched here (L2-hot) to keep tile 0 light on registers
-      int j1 = 32 + l31 < n ? 32 + l31 : n - 1;
-      const float* k1 = kp + (long)prow(j1) * a.ldkv + kh;
-#pragma unroll
-      for (int kc = 0; kc < 8; ++kc) {
-        f32x4 kf1 = *(const f32x4*)(k1 + kc * 8);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf1[s], qf[kc][s], s1, 0, 0, 0);
-      }
-    }
-    float mx = -1e30f;
+      for (int c = 0; c < 4; ++c) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[kc][c], qf[kc][c], s, 0, 0, 0);
+  };
+  // accumulator r of a key tile jt <-> key j = 32 jt + (r&3) + 8 (r>>2) + 4 hi, query i = 32 it + l31 (one query column per lane pair:
+  // the softmax is lane-local + one exchange across the halves).  s := exp(score - max), returns the row sum.
+  // (key j = C_r + 4 hi with C_r a compile-time constant: the causal / window tests compare C_r with the per-lane i - 4 hi, n - 4 hi, so no
+  // per-element index register exists)
+  const float hi4f = (float)kh;
+  auto masked = [&](f32x16& s, int jt, int i, float& mx) {
+    const int i4 = i - kh, n4 = n - kh;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      int j = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      float v0 = s0[r] + slope * (float)j;
-      v0 = ((j <= i) && (j < n)) ? v0 : -1e30f;
-      s0[r] = v0;
-      mx = fmaxf(mx, v0);
-      int j2 = j + 32;
-      float v1 = s1[r] + slope * (float)j2;
-      v1 = (use_j1 && (j2 <= i) && (j2 < n)) ? v1 : -1e30f;
-      s1[r] = v1;
-      mx = fmaxf(mx, v1);
+      const int c = jt * 32 + (r & 3) + 8 * (r >> 2);
+      float v = fmaf(s[r], 0.0625f, slope * ((float)c + hi4f));
+      v = ((c <= i4) && (c < n4)) ? v : -1e30f;
+      s[r] = v;
+      mx = fmaxf(mx, v);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+  };
+  auto expsum = [&](f32x16& s, float mx) {
     float sum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float p0 = s0[r] > -1e29f ? expf(s0[r] - mx) : 0.f;
-      float p1 = s1[r] > -1e29f ? expf(s1[r] - mx) : 0.f;
-      s0[r] = p0; s1[r] = p1;
-      sum += p0 + p1;
+      const float pr = s[r] > -1e29f ? __expf(s[r] - mx) : 0.f;   // v_exp_f32 path: arguments <= 0, |rel err| ~1e-6 (as attention_long2_kernel)
+      s[r] = pr;
+      sum += pr;
     }
-    sum += __shfl_xor(sum, 32);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    return sum;
+  };
+  // O^T[d][i] += sum_j V[j][d] P^T[j][i] for the 32 keys of tile jt: accumulator register r of S^T IS the B operand of MFMA step r
+  auto pv = [&](f32x16& o0, f32x16& o1, const f32x16& pr, int jt) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float* va = &Vs[((r & 3) + 8 * (r >> 2) + 4 * hi) * KV_LD2 + l31];
-      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[0], s0[r], o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32], s0[r], o1, 0, 0, 0);
+      const float* va = &Vs[(jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * KV_LD2 + l31];
+      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[0], pr[r], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32], pr[r], o1, 0, 0, 0);
     }
-    if (use_j1) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float* va = &Vs[(32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * KV_LD2 + l31];
-        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[0], s1[r], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32], s1[r], o1, 0, 0, 0);
-      }
-    }
-    const float inv = i < n ? 1.0f / sum : 0.f;    // rows beyond the window -> zeros
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] *= inv; o1[r] *= inv; }
   };
-  f32x16 oa0, oa1, ob0, ob1;   // query tile 0 / 1, feature tile 0 / 1
-  qtile(0, false, oa0, oa1);
+  f32x16 oa0, oa1, ob0, ob1;   // query tile 0 / 1, feature tile 0 / 1 (O^T, scaled by 1 / rowsum)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { ob0[r] = 0.f; ob1[r] = 0.f; }
-  if (two) qtile(1, true, ob0, ob1);
+  for (int r = 0; r < 16; ++r) { oa0[r] = 0.f; oa1[r] = 0.f; ob0[r] = 0.f; ob1[r] = 0.f; }
+  {
+    // the three score tiles back to back (96 MFMAs): the softmax VALU of tile 0 then overlaps the matrix pipe draining
+    f32x16 sa, sb0, sb1;
+    scores(sa, kf0, qf0);
+    if (two) { scores(sb0, kf0, qf1); scores(sb1, kf1, qf1); }
+    {
+      const int i = l31;
+      float mx = -1e30f;
+      masked(sa, 0, i, mx);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sum = expsum(sa, mx);
+      sum += __shfl_xor(sum, 32);
+      pv(oa0, oa1, sa, 0);
+      const float inv = i < n ? 1.0f / sum : 0.f;    // rows beyond the window -> zeros
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { oa0[r] *= inv; oa1[r] *= inv; }
+    }
+    if (two) {
+      const int i = 32 + l31;
+      float mx = -1e30f;
+      masked(sb0, 0, i, mx);
+      masked(sb1, 1, i, mx);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sum = expsum(sb0, mx) + expsum(sb1, mx);
+      sum += __shfl_xor(sum, 32);
+      pv(ob0, ob1, sb0, 0);
+      pv(ob0, ob1, sb1, 1);
+      const float inv = i < n ? 1.0f / sum : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { ob0[r] *= inv; ob1[r] *= inv; }
+    }
+  }
+  STAMP();   // 2: attention (scores, softmax, P.V) done
   // projection weights: start the ring fill now, it flies under the barrier and the sAtt stores
   const int w = h;
   f32x4 ring[16];
@@ -490,7 +523,29 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
 #pragma unroll
     for (int i = 0; i < 16; ++i) ring[i] = wf[i * 64 + lane];
   }
+  // acc[mt*2 + ns][r] <-> row i = mt*32 + (r&3) + 8*(r>>2) + 4*hi, column 64w + 32ns + l31.  The projection accumulates ON TOP of the
+  // residual rows: their 64 loads per lane are issued here, fly under the barriers and the sAtt stores, and are consumed by the first
+  // MFMA of each accumulator — no separate load-wait-add phase after the projection (and 64 registers less at the LayerNorm).
+  const int ccol = w * 64 + l31;
+  f32x16 acc[4];
+  __builtin_amdgcn_sched_barrier(0);   // (the row offsets below must not be hoisted above the attention phase: 32 live registers)
+  {
+    const float* rbase = a.resid + slab_q * T * 256;           // workgroup-uniform base + 32-bit per-lane offsets
+    const int h4 = opaque_vgpr(kh);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int i = mt * 32 + (r & 3) + 8 * (r >> 2) + h4;
+        i = i < T ? i : T - 1;
+        const unsigned off = (unsigned)prow(i) * 256u + (unsigned)ccol;
+        acc[mt * 2][r] = SPLIT ? rbase[off] * 256.0f : rbase[off];          // (split: the accumulator carries 2^8 x, undone exactly at the end)
+        acc[mt * 2 + 1][r] = SPLIT ? rbase[off + 32] * 256.0f : rbase[off + 32];
+      }
+  }
+  STAMP();   // 3: residual + weight-ring loads issued
   __syncthreads();             // every head is done with its V tile: the bytes become sAtt
+  STAMP();   // 4: barrier passed (all heads done)
   // O^T accumulator r <-> feature d = dt*32 + (r&3) + 8*(r>>2) + 4*hi, query i = it*32 + l31
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
@@ -591,108 +646,110 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
       }
     }
   };
-  // acc[mt*2 + ns][r] <-> row i = mt*32 + (r&3) + 8*(r>>2) + 4*hi, column 64w + 32ns + l31
-  const int ccol = w * 64 + l31;
-  f32x16 acc[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  mm(acc, a.wprojf, a.wqxf);
-  // residual: all 64 loads of a lane are issued back to back (the weight ring is dead here, so the
-  // registers are free) and then added — one memory latency instead of one per 8 rows
-  {
-    float rv[2][32];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int i = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        i = i < T ? i : T - 1;
-        const float* rp = a.resid + (slab_q * T + prow(i)) * 256 + ccol;
-        rv[0][mt * 16 + r] = rp[0];
-        rv[1][mt * 16 + r] = rp[32];
-      }
+  STAMP();   // 5: attention output in LDS
+  f32x4 lg, lb;                 // LayerNorm weight / bias of this lane's 4 columns (row-per-wave form below): in flight under the projection
+  if constexpr (QX) { lg = *(const f32x4*)(a.ln_g + lane * 4); lb = *(const f32x4*)(a.ln_b + lane * 4); }
+  mm(acc, a.wprojf, QX ? a.wqxf : nullptr);   // acc = resid + att . Wproj^T
+  STAMP();   // 6: projection MFMAs done
+  // Accumulator (mt, r) <-> tile row C + 4 hi with C = 32 mt + (r&3) + 8 (r>>2) a compile-time constant: every address below is ONE
+  // per-lane base register plus a constant, and the row tests compare C with the per-lane T - 4 hi.
+  if constexpr (!QX) {
+    const int h4 = opaque_vgpr(kh);
+    float* xbase = a.xmid + (long)bc * T * 256;                  // workgroup-uniform base + 32-bit per-lane offsets
+    const unsigned o0 = (unsigned)h4 * 256u + (unsigned)ccol;
+    const int T4 = T - h4;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        acc[mt * 2][r] += rv[0][mt * 16 + r];
-        acc[mt * 2 + 1][r] += rv[1][mt * 16 + r];
-      }
-  }
-  // LayerNorm over the 256 columns of each row (two-pass), partials across the 4 waves via LDS
-  float s[32], mean[32];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s[mt * 16 + r] = half_sum(acc[mt * 2][r] + acc[mt * 2 + 1][r]);
-  if (l31 == 0)
-#pragma unroll
-    for (int t = 0; t < 32; ++t) red[w * 64 + (t >> 4) * 32 + (t & 3) + 8 * ((t & 15) >> 2) + 4 * hi] = s[t];
-  __syncthreads();
-#pragma unroll
-  for (int t = 0; t < 32; ++t) {
-    int lr = (t >> 4) * 32 + (t & 3) + 8 * ((t & 15) >> 2) + 4 * hi;
-    mean[t] = (red[lr] + red[64 + lr] + red[128 + lr] + red[192 + lr]) * (1.0f / 256.0f);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float d0 = acc[mt * 2][r] - mean[mt * 16 + r], d1 = acc[mt * 2 + 1][r] - mean[mt * 16 + r];
-      s[mt * 16 + r] = half_sum(d0 * d0 + d1 * d1);
-    }
-  if (l31 == 0)
-#pragma unroll
-    for (int t = 0; t < 32; ++t) red[w * 64 + (t >> 4) * 32 + (t & 3) + 8 * ((t & 15) >> 2) + 4 * hi] = s[t];
-  __syncthreads();   // (also: every wave has finished reading sAtt in mm)
-  const float g0 = a.ln_g[ccol], g1 = a.ln_g[ccol + 32], b0 = a.ln_b[ccol], b1 = a.ln_b[ccol + 32];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int t = mt * 16 + r;
-      const int i = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      float var = (red[i] + red[64 + i] + red[128 + i] + red[192 + i]) * (1.0f / 256.0f);
-      float rstd = rsqrtf(var + 1e-5f);
-      float y0 = (acc[mt * 2][r] - mean[t]) * rstd * g0 + b0;
-      float y1 = (acc[mt * 2 + 1][r] - mean[t]) * rstd * g1 + b1;
-      if (i < T) {
-        float* xm = a.xmid + ((long)bc * T + i) * 256 + ccol;
-        xm[0] = acc[mt * 2][r]; xm[32] = acc[mt * 2 + 1][r];
-        if (a.xn) {   // LN output is only needed in global when another kernel consumes it (ffn_block)
-          float* xo = a.xn + ((long)bc * T + i) * 256 + ccol;
-          xo[0] = y0; xo[32] = y1;
+        const int c = mt * 32 + (r & 3) + 8 * (r >> 2);
+        if (c < T4) {
+          const unsigned off = o0 + (unsigned)c * 256u;
+          xbase[off] = acc[mt * 2][r]; xbase[off + 32] = acc[mt * 2 + 1][r];
         }
       }
-      if (a.wqxf) {
-        if constexpr (SPLIT) {
-          const _Float16 h0 = (_Float16)y0, h1 = (_Float16)y1;
-          sAh[i * ALD16 + ccol] = h0; sAl[i * ALD16 + ccol] = (_Float16)(y0 - (float)h0);
-          sAh[i * ALD16 + ccol + 32] = h1; sAl[i * ALD16 + ccol + 32] = (_Float16)(y1 - (float)h1);
-        } else { sAtt[i * 260 + ccol] = y0; sAtt[i * 260 + ccol + 32] = y1; }
+    STAMP();   // 7: xmid stores issued
+  } else {
+    // x' tile -> LDS (fp32 rows), then ROW-PER-WAVE LayerNorm: wave w owns rows w, w + 4, ...; a lane holds 4 columns of the row, the
+    // statistics are two wave reductions (two-pass, exactly the arithmetic of the FFN block's staging LayerNorm) — no cross-wave
+    // exchange, no partial-sum buffer, and x' leaves as 1 KiB-contiguous 16-byte stores.  (Round 2 normalised in accumulator layout:
+    // 256 LDS reads, 3 barriers and 64 scalar stores per lane — 7 us of a 49 us workgroup alone, 15-21 us next to a partner.)
+    __syncthreads();            // every wave has finished reading sAtt in mm
+    {
+      const int h4 = opaque_vgpr(kh);
+      float* ps = sAtt + h4 * 260 + ccol;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = mt * 32 + (r & 3) + 8 * (r >> 2);
+          ps[c * 260] = acc[mt * 2][r]; ps[c * 260 + 32] = acc[mt * 2 + 1][r];
+        }
+    }
+    __syncthreads();
+    float* xbase = a.xmid + (long)bc * T * 256 + lane * 4;
+    f32x4 y[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int row = 4 * k + w;                                 // wave-uniform
+      if (row < T) {
+        const f32x4 x = *(const f32x4*)&sAtt[row * 260 + lane * 4];
+        *(f32x4*)(xbase + row * 256) = x;
+        const float mean = wave_sum(x[0] + x[1] + x[2] + x[3]) * (1.0f / 256.0f);
+        const f32x4 d = x - mean;
+        const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.0f / 256.0f);
+        y[k] = d * rsqrtf(var + 1e-5f) * lg + lb;
       }
     }
-  if (a.wqxf) {
+    if constexpr (SPLIT) __syncthreads();   // the f16 (hi, lo) rows alias OTHER waves' fp32 rows: every row must be in registers first
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int row = 4 * k + w;
+      if (row < T) {
+        if constexpr (SPLIT) {
+          const h16x4 hh = __builtin_convertvector(y[k], h16x4);
+          const h16x4 ll = __builtin_convertvector(y[k] - __builtin_convertvector(hh, f32x4), h16x4);
+          *(h16x4*)&sAh[row * ALD16 + lane * 4] = hh;
+          *(h16x4*)&sAl[row * ALD16 + lane * 4] = ll;
+        } else {
+          *(f32x4*)&sAtt[row * 260 + lane * 4] = y[k];
+        }
+      }
+    }
+    if constexpr (SPLIT) {   // rows >= T keep fp32 bit patterns: as f16 operands they may read as NaN / Inf — harmless (an MFMA output row depends on
+                             // its own A row only, and rows >= T are never stored), but keep the tile defined: zero them
+      for (int row = T + w; row < 64; row += 4) {
+        *(h16x4*)&sAh[row * ALD16 + lane * 4] = h16x4{0, 0, 0, 0};
+        *(h16x4*)&sAl[row * ALD16 + lane * 4] = h16x4{0, 0, 0, 0};
+      }
+    }
+    STAMP();   // 7: LayerNorm + xmid stores issued
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     mm(acc, a.wqxf, nullptr);
+    STAMP();   // 8: cross-q projection MFMAs done
+    const int h4 = opaque_vgpr(kh);
+    float* qbase = a.qx + (long)bc * T * 256;
+    const unsigned o0 = (unsigned)h4 * 256u + (unsigned)ccol;
+    const int T4 = T - h4;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int i = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (i < T) {
-          float* qo = a.qx + ((long)bc * T + i) * 256 + ccol;
-          qo[0] = acc[mt * 2][r]; qo[32] = acc[mt * 2 + 1][r];
+        const int c = mt * 32 + (r & 3) + 8 * (r >> 2);
+        if (c < T4) {
+          const unsigned off = o0 + (unsigned)c * 256u;
+          qbase[off] = acc[mt * 2][r]; qbase[off + 32] = acc[mt * 2 + 1][r];
         }
       }
   }
+#ifdef VAPX_TRACE
+  STAMP();   // 8 or 9: stores issued
+  if (a.trace && tid == 0) { a.trace[(long)blockIdx.x * 32 + 29] = __builtin_amdgcn_s_memrealtime(); a.trace[(long)blockIdx.x * 32 + 30] = (unsigned long long)stamp_k; }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -898,8 +955,14 @@ hipError_t launch_conv_tail(const ConvTailArgs& a, int B, hipStream_t st) {
 
 hipError_t launch_attn_block(const AttnBlockArgs& a, int B, hipStream_t st) {
   if (a.T > 64) return hipErrorInvalidValue;
-  if (a.split) hipLaunchKernelGGL(attn_block_kernel<true>, dim3(B * 2), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(attn_block_kernel<false>, dim3(B * 2), dim3(256), 0, st, a);
+  const dim3 grid(B * 2), block(256);
+  if (a.split) {
+    if (a.wqxf) hipLaunchKernelGGL((attn_block_kernel<true, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((attn_block_kernel<true, false>), grid, block, 0, st, a);
+  } else {
+    if (a.wqxf) hipLaunchKernelGGL((attn_block_kernel<false, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((attn_block_kernel<false, false>), grid, block, 0, st, a);
+  }
   return hipGetLastError();
 }
 
@@ -908,10 +971,8 @@ hipError_t launch_ffn_block(const FfnArgs& a, hipStream_t st) {
   static PerDeviceOnce attr_set;
   attr_set.run([] {
     (void)hipFuncSetAttribute((const void*)ffn_block_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)ffn_block_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  const int mt = (a.tile_rows == 64 && a.mode == 0) ? 2 : 1;
-  const size_t lds = (size_t)(2 * 32 * mt * LDH + 4 * 32 * mt) * sizeof(float);
+  const size_t lds = (size_t)(2 * 32 * LDH + 4 * 32) * sizeof(float);
   if (a.mode == 1 || a.mode == 2) {
     static PerDeviceOnce attr2;
     attr2.run([] {
@@ -923,7 +984,6 @@ hipError_t launch_ffn_block(const FfnArgs& a, hipStream_t st) {
     else hipLaunchKernelGGL((ffn_block_kernel<1, 2>), dim3((a.M + 31) / 32), dim3(256), lds, st, a);
     return hipGetLastError();
   }
-  if (mt == 2) hipLaunchKernelGGL(ffn_block_kernel<2>, dim3((a.M + 63) / 64), dim3(256), lds, st, a);
-  else hipLaunchKernelGGL(ffn_block_kernel<1>, dim3((a.M + 31) / 32), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(ffn_block_kernel<1>, dim3((a.M + 31) / 32), dim3(256), lds, st, a);
   return hipGetLastError();
 }

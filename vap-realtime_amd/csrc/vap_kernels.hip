@@ -407,307 +407,20 @@ __global__ __launch_bounds__(256) void gather_ln_kernel(GatherArgs a) {
 //    exactly the B operand of MFMA step r of   O^T[d][i] = sum_j V[j][d] P^T[j][i]
 //    (lane half h holds key j0(r)+4h, which is the k-slot that half supplies), so P never moves.
 // ------------------------------------------------------------------------------------------------
-constexpr int KV_LD = 68;  // 64 + 4 pad floats: ds_read_b128 rows and ds_read_b32 columns conflict-free
-
-// one 32-query tile against NJT = it+1 causal key tiles (NJT is compile-time so the accumulator
-// array is statically indexed and never conditionally updated — see the spill note in gemm_f32.hip)
-template <int NJT>
-__device__ __forceinline__ void attn_tile(const AttnArgs& a, const float* Ks, const float* Vs, int bc, int h, int n,
-                                          int it, int l31, int hi, float slope) {
-  const int T = a.T;
-  const int i = it * 32 + l31;
-  float* op = a.out + ((long)bc * T + i) * 256 + h * 64;
-  // Q fragments (B operand): row i, k-slots kc*8 + 4*hi .. +3, pre-scaled by 1/16
-  const int iq = i < n ? i : n - 1;
-  const float* qp = a.q + ((long)bc * T + iq) * a.ldq + h * 64 + hi * 4;
-  f32x4 qf[8];
-#pragma unroll
-  for (int kc = 0; kc < 8; ++kc) qf[kc] = *(const f32x4*)(qp + kc * 8) * 0.0625f;
-
-  f32x16 acc[NJT];
-#pragma unroll
-  for (int jt = 0; jt < NJT; ++jt) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
-    const float* ka = &Ks[(jt * 32 + l31) * KV_LD + hi * 4];
-#pragma unroll
-    for (int kc = 0; kc < 8; ++kc) {
-      f32x4 av = *(const f32x4*)(ka + kc * 8);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], qf[kc][s], acc[jt], 0, 0, 0);
-    }
-  }
-  // softmax over keys j for query column i (lane-local + one cross-half exchange)
-  float mx = -1e30f;
-#pragma unroll
-  for (int jt = 0; jt < NJT; ++jt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      float sc = acc[jt][r] + slope * (float)j;
-      sc = ((j <= i) && (j < n)) ? sc : -1e30f;
-      acc[jt][r] = sc;
-      mx = fmaxf(mx, sc);
-    }
-  mx = fmaxf(mx, __shfl_xor(mx, 32));
-  float sum = 0.f;
-#pragma unroll
-  for (int jt = 0; jt < NJT; ++jt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float sc = acc[jt][r];
-      float pv = sc > -1e29f ? expf(sc - mx) : 0.f;
-      acc[jt][r] = pv;
-      sum += pv;
-    }
-  sum += __shfl_xor(sum, 32);
-  const float inv = 1.0f / sum;
-  // O^T[d][i] = sum_j V[j][d] * P^T[j][i]
-  f32x16 o0, o1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-#pragma unroll
-  for (int jt = 0; jt < NJT; ++jt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float* va = &Vs[(jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * KV_LD + l31];
-      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[0], acc[jt][r], o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32], acc[jt][r], o1, 0, 0, 0);
-    }
-  if (i < T) {
-    const float sc = i < n ? inv : 0.f;   // rows beyond the valid window: deterministic zeros
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      f32x4 v0 = {o0[rr * 4 + 0], o0[rr * 4 + 1], o0[rr * 4 + 2], o0[rr * 4 + 3]};
-      f32x4 v1 = {o1[rr * 4 + 0], o1[rr * 4 + 1], o1[rr * 4 + 2], o1[rr * 4 + 3]};
-      *(f32x4*)(op + rr * 8 + hi * 4) = v0 * sc;
-      *(f32x4*)(op + 32 + rr * 8 + hi * 4) = v1 * sc;
-    }
-  }
-}
-
-template <int MAXJT>
-__global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float kv[];
-  const int T = a.T;
-  const int n_tiles = (T + 31) >> 5;
-  float* Ks = kv;
-  float* Vs = kv + (long)n_tiles * 32 * KV_LD;
-  const int h = blockIdx.x & 3, bc = blockIdx.x >> 2, b = bc >> 1;
-  const int n = a.bn[b];
-  const int kvbc = a.swap_kv ? (bc ^ 1) : bc;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, NW = blockDim.x >> 6;
-  const int l31 = lane & 31, hi = lane >> 5;
-  const float* kp = a.k + (long)kvbc * T * a.ldkv + h * 64;
-  const float* vp = a.v + (long)kvbc * T * a.ldkv + h * 64;
-  const int nt_valid = (n + 31) >> 5;          // key/query tiles that contain valid rows
-  for (int i = tid; i < nt_valid * 32 * 16; i += blockDim.x) {
-    int j = i >> 4, q = (i & 15) * 4;
-    f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = kk;
-    if (j < n) {
-      kk = *(const f32x4*)(kp + (long)j * a.ldkv + q);
-      vv = *(const f32x4*)(vp + (long)j * a.ldkv + q);
-    }
-    *(f32x4*)&Ks[j * KV_LD + q] = kk;
-    *(f32x4*)&Vs[j * KV_LD + q] = vv;
-  }
-  __syncthreads();
-  const float slope = exp2f(-2.0f * (float)(h + 1));  // [1/4, 1/16, 1/64, 1/256]
-
-  for (int pass = 0; pass * NW < n_tiles; ++pass) {
-    // boustrophedon tile order balances the triangular work across waves
-    const int it = pass * NW + ((pass & 1) ? (NW - 1 - w) : w);
-    if (it >= n_tiles) continue;
-    if (it >= nt_valid) {  // whole tile beyond the valid rows: deterministic zeros
-      const int i = it * 32 + l31;
-      if (i < T) {
-        float* op = a.out + ((long)bc * T + i) * 256 + h * 64;
-#pragma unroll
-        for (int d = 0; d < 8; ++d) *(f32x4*)(op + hi * 32 + d * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-      continue;
-    }
-    switch (it) {
-      case 0: attn_tile<1>(a, Ks, Vs, bc, h, n, it, l31, hi, slope); break;
-      case 1: attn_tile<2>(a, Ks, Vs, bc, h, n, it, l31, hi, slope); break;
-      default:
-        if constexpr (MAXJT > 2) {
-          switch (it) {
-            case 2: attn_tile<3>(a, Ks, Vs, bc, h, n, it, l31, hi, slope); break;
-            case 3: attn_tile<4>(a, Ks, Vs, bc, h, n, it, l31, hi, slope); break;
-            case 4: attn_tile<5>(a, Ks, Vs, bc, h, n, it, l31, hi, slope); break;
-            case 5: attn_tile<6>(a, Ks, Vs, bc, h, n, it, l31, hi, slope); break;
-            case 6: attn_tile<7>(a, Ks, Vs, bc, h, n, it, l31, hi, slope); break;
-            case 7: attn_tile<8>(a, Ks, Vs, bc, h, n, it, l31, hi, slope); break;
-          }
-        }
-    }
-  }
-}
-
+// Long windows (64 < T <= 256): TWO workgroups per CU so that one workgroup's V staging / Q loads / output stores hide behind the
+// other's MFMAs.  Only V sits in LDS (64 KB for 256 keys, unpadded: its reads are lane-consecutive); K fragments come straight from
+// global / L2 as the MFMA A operand (as in attn_block_kernel), double-buffered one key tile ahead; the softmax is online per 32-key
+// tile, so one score accumulator is live (~190 registers).  Four waves, each takes query tiles w and 7 - w (9 causal key tiles per
+// wave: balanced).  Optional ring addressing lets layer 0 read the per-stream Q|K|V rings in place (no chronological gather).
+// (Two earlier generations — K+V in LDS with 4 and with 8 waves — are in the history: profiles/r02_experiments/c3_attention_*.json.)
 // ------------------------------------------------------------------------------------------------
-// 4a. long windows (64 < T <= 256), second generation: one workgroup per (stream, channel, head) with EIGHT waves — one
-//     32-query tile each — so that every SIMD hosts two waves whose MFMA and softmax / load phases overlap (the first
-//     generation above runs one wave per SIMD with up to 476 registers: nothing hides its exp / max / rescale phases or the
-//     K / V staging).  Register budget <= 256: the key tiles of a query tile are processed in chunks of <= 4 with an
-//     online (running max / sum) softmax, so only 4 score accumulators are live.  Triangular work is balanced per SIMD:
-//     waves w and w + 4 share a SIMD and take query tiles w and 7 - w (w + 1 and 8 - w key tiles: 9 per SIMD).
-// ------------------------------------------------------------------------------------------------
-// NT (1..4) key tiles jt0 .. jt0 + NT - 1 against the wave's query tile; (m, l, o0, o1) = running max / sum / O^T
-template <int NT>
-__device__ __forceinline__ void attn_chunk(const float* Ks, const float* Vs, const f32x4 (&qf)[8], int jt0, int i, int n, int l31, int hi,
-                                           float slope, float& m, float& l, f32x16& o0, f32x16& o1) {
-  f32x16 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    const float* ka = &Ks[((jt0 + t) * 32 + l31) * KV_LD + hi * 4];
-#pragma unroll
-    for (int kc = 0; kc < 8; ++kc) {
-      f32x4 av = *(const f32x4*)(ka + kc * 8);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], qf[kc][s], acc[t], 0, 0, 0);
-    }
-  }
-  float cm = -1e30f;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int j = (jt0 + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      float sc = acc[t][r] + slope * (float)j;
-      sc = ((j <= i) && (j < n)) ? sc : -1e30f;
-      acc[t][r] = sc;
-      cm = fmaxf(cm, sc);
-    }
-  cm = fmaxf(cm, __shfl_xor(cm, 32));
-  const float mn = fmaxf(m, cm);
-  const float alpha = __expf(m - mn);       // m = -1e30 on the first chunk: exp(-huge) = 0, and l, o are 0 anyway
-  float sum = 0.f;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float sc = acc[t][r];
-      const float pv = sc > -1e29f ? __expf(sc - mn) : 0.f;   // v_exp_f32 path: arguments <= 0, |rel err| ~1e-6
-      acc[t][r] = pv;
-      sum += pv;
-    }
-  sum += __shfl_xor(sum, 32);
-  l = l * alpha + sum;
-  m = mn;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float* va = &Vs[((jt0 + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * KV_LD + l31];
-      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[0], acc[t][r], o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32], acc[t][r], o1, 0, 0, 0);
-    }
-}
-
-__global__ __launch_bounds__(512) void attention_long_kernel(AttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float kv[];
-  const int T = a.T;
-  const int n_tiles = (T + 31) >> 5;                 // <= 8
-  float* Ks = kv;
-  float* Vs = kv + (long)n_tiles * 32 * KV_LD;
-  const int h = blockIdx.x & 3, bc = blockIdx.x >> 2, b = bc >> 1;
-  const int n = a.bn[b];
-  const int kvbc = a.swap_kv ? (bc ^ 1) : bc;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, hi = lane >> 5;
-  const float* kp = a.k + (long)kvbc * T * a.ldkv + h * 64;
-  const float* vp = a.v + (long)kvbc * T * a.ldkv + h * 64;
-  const int nt_valid = (n + 31) >> 5;                // key / query tiles that contain valid rows
-  // this wave's query tile (waves w and w + 4 share a SIMD: light + heavy tile)
-  const int it = w < 4 ? w : 11 - w;
-  const bool active = it < nt_valid;
-  const int i = it * 32 + l31;
-  // Q fragments first (B operand: query row i, k-slots kc*8 + 4*hi .. +3, pre-scaled by 1/16): in flight under the staging
-  f32x4 qf[8];
-  {
-    const int iq = i < n ? i : n - 1;
-    const float* qp = a.q + ((long)bc * T + iq) * a.ldq + h * 64 + hi * 4;
-#pragma unroll
-    for (int kc = 0; kc < 8; ++kc) qf[kc] = *(const f32x4*)(qp + kc * 8);
-  }
-  for (int idx = tid; idx < nt_valid * 32 * 16; idx += 512) {
-    const int j = idx >> 4, q = (idx & 15) * 4;
-    f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = kk;
-    if (j < n) {
-      kk = *(const f32x4*)(kp + (long)j * a.ldkv + q);
-      vv = *(const f32x4*)(vp + (long)j * a.ldkv + q);
-    }
-    *(f32x4*)&Ks[j * KV_LD + q] = kk;
-    *(f32x4*)&Vs[j * KV_LD + q] = vv;
-  }
-#pragma unroll
-  for (int kc = 0; kc < 8; ++kc) qf[kc] *= 0.0625f;
-  __syncthreads();
-  if (it >= n_tiles) return;
-  float* op = a.out + ((long)bc * T + i) * 256 + h * 64;
-  if (!active) {                                     // whole tile beyond the valid rows: deterministic zeros
-    if (i < T) {
-#pragma unroll
-      for (int d = 0; d < 8; ++d) *(f32x4*)(op + hi * 32 + d * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    return;
-  }
-  const float slope = exp2f(-2.0f * (float)(h + 1));  // [1/4, 1/16, 1/64, 1/256]
-  float m = -1e30f, l = 0.f;
-  f32x16 o0, o1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-  switch (it) {
-    case 0: attn_chunk<1>(Ks, Vs, qf, 0, i, n, l31, hi, slope, m, l, o0, o1); break;
-    case 1: attn_chunk<2>(Ks, Vs, qf, 0, i, n, l31, hi, slope, m, l, o0, o1); break;
-    case 2: attn_chunk<3>(Ks, Vs, qf, 0, i, n, l31, hi, slope, m, l, o0, o1); break;
-    default:
-      attn_chunk<4>(Ks, Vs, qf, 0, i, n, l31, hi, slope, m, l, o0, o1);
-      switch (it) {
-        case 4: attn_chunk<1>(Ks, Vs, qf, 4, i, n, l31, hi, slope, m, l, o0, o1); break;
-        case 5: attn_chunk<2>(Ks, Vs, qf, 4, i, n, l31, hi, slope, m, l, o0, o1); break;
-        case 6: attn_chunk<3>(Ks, Vs, qf, 4, i, n, l31, hi, slope, m, l, o0, o1); break;
-        case 7: attn_chunk<4>(Ks, Vs, qf, 4, i, n, l31, hi, slope, m, l, o0, o1); break;
-        default: break;
-      }
-  }
-  if (i < T) {
-    const float sc = i < n ? 1.0f / l : 0.f;           // rows beyond the valid window: deterministic zeros
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      f32x4 v0 = {o0[rr * 4 + 0], o0[rr * 4 + 1], o0[rr * 4 + 2], o0[rr * 4 + 3]};
-      f32x4 v1 = {o1[rr * 4 + 0], o1[rr * 4 + 1], o1[rr * 4 + 2], o1[rr * 4 + 3]};
-      *(f32x4*)(op + rr * 8 + hi * 4) = v0 * sc;
-      *(f32x4*)(op + 32 + rr * 8 + hi * 4) = v1 * sc;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// 4a'. long windows, third generation: TWO workgroups per CU so that one workgroup's V staging / Q loads / output stores
-//      hide behind the other's MFMAs.  Only V sits in LDS (64 KB for 256 keys, unpadded: its reads are lane-consecutive);
-//      K fragments come straight from global / L2 as the MFMA A operand (as in attn_block_kernel), double-buffered one key
-//      tile ahead; the softmax is online per 32-key tile, so one score accumulator is live (~190 registers).  Four waves,
-//      each takes query tiles w and 7 - w (9 causal key tiles per wave: balanced).  Optional ring addressing lets layer 0
-//      read the per-stream Q|K|V rings in place (no chronological gather for long windows either).
-// ------------------------------------------------------------------------------------------------
-// SHORT (T <= 64, two tiles): one workgroup per (stream, channel), wave = head, each wave walks its head's two query tiles
-// (its V tile is wave-private in LDS) — the same 64 KB of LDS and two workgroups per CU.
-template <bool SHORT>
 __global__ __launch_bounds__(256, 2) void attention_long2_kernel(AttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float Vs_all[];   // [n_tiles * 32][64]  (SHORT: x 4 heads)
+  extern __shared__ __attribute__((aligned(16))) float Vs[];   // [n_tiles * 32][64]
   const int T = a.T;
   const int n_tiles = (T + 31) >> 5;                 // <= 8
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = SHORT ? w : (int)(blockIdx.x & 3), bc = SHORT ? (int)blockIdx.x : (int)(blockIdx.x >> 2), b = bc >> 1;
-  float* Vs = SHORT ? Vs_all + w * n_tiles * 32 * 64 : Vs_all;
+  const int h = (int)(blockIdx.x & 3), bc = (int)(blockIdx.x >> 2), b = bc >> 1;
   const int n = a.bn[b];
   const int kvbc = a.swap_kv ? (bc ^ 1) : bc;
   const int l31 = lane & 31, hi = lane >> 5;
@@ -719,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void attention_long2_kernel(AttnArgs a) {
   const float* kp = a.k + slab_kv * T * a.ldkv + h * 64;
   const float* vp = a.v + slab_kv * T * a.ldkv + h * 64;
   const int nt_valid = (n + 31) >> 5;
-  for (int idx = SHORT ? lane : tid; idx < nt_valid * 32 * 16; idx += SHORT ? 64 : 256) {
+  for (int idx = tid; idx < nt_valid * 32 * 16; idx += 256) {
     const int j = idx >> 4, q = (idx & 15) * 4;
     f32x4 vv = {0.f, 0.f, 0.f, 0.f};
     if (j < n) vv = *(const f32x4*)(vp + (long)prow(j) * a.ldkv + q);
@@ -735,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void attention_long2_kernel(AttnArgs a) {
     for (int kc = 0; kc < 8; ++kc) kf[kc] = *(const f32x4*)(kr + kc * 8);
   };
   for (int pass = 0; pass < 2; ++pass) {
-    const int it = SHORT ? pass : (pass == 0 ? w : 7 - w);
+    const int it = pass == 0 ? w : 7 - w;
     if (it >= n_tiles) continue;
     const int i = it * 32 + l31;
     float* op = a.out + ((long)bc * T + i) * 256 + h * 64;
@@ -1132,36 +845,10 @@ hipError_t launch_gather_ln(const GatherArgs& a, hipStream_t st) {
 }
 hipError_t launch_attention(const AttnArgs& a, int B, hipStream_t st) {
   const int n_tiles = (a.T + 31) / 32;
-  const int nw = n_tiles < 4 ? n_tiles : 4;
-  const size_t lds = (size_t)n_tiles * 32 * KV_LD * 2 * sizeof(float);
+  if (n_tiles > 8) return hipErrorInvalidValue;          // T <= 256 (vapx_create enforces it)
   static PerDeviceOnce attr_set;
-  attr_set.run([] {
-    (void)hipFuncSetAttribute((const void*)attention_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)attention_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  });
-  static const bool gen1 = getenv("VAPX_ATTN_GEN1") != nullptr;   // A/B: the first-generation 4-wave kernel
-  static const bool gen2 = getenv("VAPX_ATTN_GEN2") != nullptr;   // A/B: the 8-wave, K+V-in-LDS kernel
-  if (n_tiles <= 8 && !gen1 && !gen2) {
-    static PerDeviceOnce attr4;
-    attr4.run([] {
-      (void)hipFuncSetAttribute((const void*)attention_long2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      (void)hipFuncSetAttribute((const void*)attention_long2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    });
-    if (n_tiles <= 2)   // short windows: workgroup = (stream, channel), wave = head
-      hipLaunchKernelGGL(attention_long2_kernel<true>, dim3(B * 2), dim3(256), (size_t)4 * n_tiles * 32 * 64 * sizeof(float), st, a);
-    else
-      hipLaunchKernelGGL(attention_long2_kernel<false>, dim3(B * 2 * 4), dim3(256), (size_t)n_tiles * 32 * 64 * sizeof(float), st, a);
-    return hipGetLastError();
-  }
-  if (n_tiles <= 2) hipLaunchKernelGGL(attention_mfma_kernel<2>, dim3(B * 2 * 4), dim3(64 * nw), lds, st, a);
-  else if (n_tiles <= 8 && !gen1) {
-    static PerDeviceOnce attr3;
-    attr3.run([] {
-      (void)hipFuncSetAttribute((const void*)attention_long_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
-    hipLaunchKernelGGL(attention_long_kernel, dim3(B * 2 * 4), dim3(512), lds, st, a);
-  } else if (n_tiles <= 8) hipLaunchKernelGGL(attention_mfma_kernel<8>, dim3(B * 2 * 4), dim3(64 * nw), lds, st, a);
-  else return hipErrorInvalidValue;
+  attr_set.run([] { (void)hipFuncSetAttribute((const void*)attention_long2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); });
+  hipLaunchKernelGGL(attention_long2_kernel, dim3(B * 2 * 4), dim3(256), (size_t)n_tiles * 32 * 64 * sizeof(float), st, a);
   return hipGetLastError();
 }
 hipError_t launch_gather_last_ln(const LastRowArgs& a, hipStream_t st) {

@@ -54,7 +54,7 @@ def load_library(path: Optional[str] = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("VAPX_LIBRARY") or LIB_PATH     # VAPX_LIBRARY: the debug build with phase stamps (make trace)
     if not os.path.exists(p):
         raise VapxError(f"{p} not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         f"(or `make -C vap-realtime_amd/csrc`). There is no CPU fallback.")
