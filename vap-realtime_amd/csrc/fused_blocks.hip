@@ -688,39 +688,39 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
     }
     __syncthreads();
     float* xbase = a.xmid + (long)bc * T * 256 + lane * 4;
-    f32x4 y[16];
+    // All 16 row slots of the wave are normalised unconditionally (slots >= T hold finite garbage and are never stored): one basic
+    // block, so the 32 reduction chains interleave instead of running one after the other behind a branch per row.
+    f32x4 x[16], y[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = *(const f32x4*)&sAtt[(4 * k + w) * 260 + lane * 4];
+    float sm[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sm[k] = wave_sum(x[k][0] + x[k][1] + x[k][2] + x[k][3]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      y[k] = x[k] - sm[k] * (1.0f / 256.0f);
+      sm[k] = y[k][0] * y[k][0] + y[k][1] * y[k][1] + y[k][2] * y[k][2] + y[k][3] * y[k][3];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sm[k] = wave_sum(sm[k]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) y[k] = y[k] * __builtin_amdgcn_rsqf(sm[k] * (1.0f / 256.0f) + 1e-5f) * lg + lb;   // (argument >= 1e-5: never denormal)
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int row = 4 * k + w;                                 // wave-uniform
-      if (row < T) {
-        const f32x4 x = *(const f32x4*)&sAtt[row * 260 + lane * 4];
-        *(f32x4*)(xbase + row * 256) = x;
-        const float mean = wave_sum(x[0] + x[1] + x[2] + x[3]) * (1.0f / 256.0f);
-        const f32x4 d = x - mean;
-        const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.0f / 256.0f);
-        y[k] = d * rsqrtf(var + 1e-5f) * lg + lb;
-      }
+      if (row < T) *(f32x4*)(xbase + row * 256) = x[k];
     }
     if constexpr (SPLIT) __syncthreads();   // the f16 (hi, lo) rows alias OTHER waves' fp32 rows: every row must be in registers first
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < 16; ++k) {          // all 64 rows are written (rows >= T: finite, never stored): the A tile of the next MFMAs is fully defined
       const int row = 4 * k + w;
-      if (row < T) {
-        if constexpr (SPLIT) {
-          const h16x4 hh = __builtin_convertvector(y[k], h16x4);
-          const h16x4 ll = __builtin_convertvector(y[k] - __builtin_convertvector(hh, f32x4), h16x4);
-          *(h16x4*)&sAh[row * ALD16 + lane * 4] = hh;
-          *(h16x4*)&sAl[row * ALD16 + lane * 4] = ll;
-        } else {
-          *(f32x4*)&sAtt[row * 260 + lane * 4] = y[k];
-        }
-      }
-    }
-    if constexpr (SPLIT) {   // rows >= T keep fp32 bit patterns: as f16 operands they may read as NaN / Inf — harmless (an MFMA output row depends on
-                             // its own A row only, and rows >= T are never stored), but keep the tile defined: zero them
-      for (int row = T + w; row < 64; row += 4) {
-        *(h16x4*)&sAh[row * ALD16 + lane * 4] = h16x4{0, 0, 0, 0};
-        *(h16x4*)&sAl[row * ALD16 + lane * 4] = h16x4{0, 0, 0, 0};
+      if constexpr (SPLIT) {
+        const h16x4 hh = __builtin_convertvector(y[k], h16x4);
+        const h16x4 ll = __builtin_convertvector(y[k] - __builtin_convertvector(hh, f32x4), h16x4);
+        *(h16x4*)&sAh[row * ALD16 + lane * 4] = hh;
+        *(h16x4*)&sAl[row * ALD16 + lane * 4] = ll;
+      } else {
+        *(f32x4*)&sAtt[row * 260 + lane * 4] = y[k];
       }
     }
     STAMP();   // 7: LayerNorm + xmid stores issued
