@@ -265,7 +265,8 @@ typedef struct vapx_ingest* vapx_ingest_handle;
 
 typedef struct vapx_ingest_config {
   int32_t struct_size;      /* sizeof(vapx_ingest_config) */
-  int32_t port_in;          /* 50007 in the reference (vap_main.py:470); 0 = ephemeral, see vapx_ingest_ports */
+  int32_t port_in;          /* 50007 in the reference (vap_main.py:470); 0 = ephemeral, see vapx_ingest_ports; -1 (both ports) = passive
+                               shard of a vapx_frontdoor: no listening sockets of its own */
   int32_t port_out;         /* 50008 */
   int32_t rx_threads;       /* 0 = 2 */
   int32_t tx_threads;       /* 0 = 2 */
@@ -301,9 +302,25 @@ typedef int (*vapx_ingest_step_fn)(void* user, int32_t n, const int32_t* stream_
 typedef void (*vapx_ingest_reset_fn)(void* user, int32_t stream_id);
 int vapx_ingest_open_fn(vapx_ingest_step_fn step, vapx_ingest_reset_fn reset, void* user, int32_t n_streams, int32_t max_batch,
                         int32_t frame_hz, int32_t mode, const vapx_ingest_config* cfg, vapx_ingest_handle* out);
-int vapx_ingest_ports(vapx_ingest_handle g, int32_t* port_in, int32_t* port_out);
+int vapx_ingest_ports(vapx_ingest_handle g, int32_t* port_in, int32_t* port_out);   /* (0, 0) for a passive shard */
 int vapx_ingest_stats_read(vapx_ingest_handle g, vapx_ingest_stats* out, int32_t reset_latency_window);
 void vapx_ingest_close(vapx_ingest_handle g);
+
+/* ---- one front door for N GPUs -----------------------------------------------------------------------------------------------------
+ * The reference serves ONE port pair (proc_serv_in / proc_serv_out_dist bind port_num_in / port_num_out, vap_main.py:338-366,470-471).
+ * For N GPUs in one process: create one engine per device (vapx_create, device_id = r), open one PASSIVE front-end per engine
+ * (vapx_ingest_config.port_in = port_out = -1: it listens on nothing) and put them behind vapx_frontdoor_open, which owns the single
+ * port pair and hands every accepted connection to a shard.  Dialogue slots are numbered globally g = local_slot * N + shard:
+ *   - an input connection takes the lowest free global slot (GPUs fill evenly; a dialogue that reconnects while its slot is still the
+ *     lowest free one returns to the GPU that holds its state);
+ *   - the k-th output connection hears the k-th dialogue (fewest listeners, lowest global slot), as with a single front-end.
+ * All shards must have the same frame rate and mode.  Close the front door first, then the shards, then the engines. */
+typedef struct vapx_frontdoor* vapx_frontdoor_handle;
+int vapx_frontdoor_open(vapx_ingest_handle* shards, int32_t n_shards, int32_t port_in, int32_t port_out, int32_t bind_any,
+                        vapx_frontdoor_handle* out);
+int vapx_frontdoor_ports(vapx_frontdoor_handle d, int32_t* port_in, int32_t* port_out);
+int vapx_frontdoor_counts(vapx_frontdoor_handle d, int64_t* accepted_in, int64_t* accepted_out, int64_t* refused);
+void vapx_frontdoor_close(vapx_frontdoor_handle d);
 
 /* The wire codec on its own (byte-parity tests against the reference's util.py output, tests/golden/wire.npz).
  * decode: n_bytes (a multiple of 16) of input packets -> n_bytes / 16 samples per channel as the engine sees them (f32) and as

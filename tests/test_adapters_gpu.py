@@ -312,10 +312,12 @@ def test_library_twin_vap_class_with_microphone_sources(tmp_path):
     vap._stop_worker = True
 
 
-def test_serve_program_end_to_end():
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_serve_program_end_to_end(gpus):
     """``python -m vap_realtime_amd.serve`` — the twin of ``python vap_main.py --vap_model ... --port_num_in ... --gpu`` (vap_main.py:461-530)
     for many dialogues: started as a subprocess with the reference's argument names, fed the golden audio over TCP, answers compared
-    with the golden of the imported reference; SIGTERM stops it."""
+    with the golden of the imported reference; SIGTERM stops it.  gpus = 2: two engines (both on this box's one GPU, ``--share-gpu``)
+    behind ONE port pair — the front door sends dialogue k to engine k mod 2, every dialogue still gets its own golden numbers."""
     import os
     import re
     import signal
@@ -326,7 +328,8 @@ def test_serve_program_end_to_end():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     proc = subprocess.Popen([sys.executable, "-u", "-m", "vap_realtime_amd.serve", "--synthetic-weights", str(c.seed), "--streams", "4",
                              "--port_num_in", "0", "--port_num_out", "0", "--vap_process_rate", str(c.frame_hz),
-                             "--context_len_sec", str(c.ctx_sec), "--gpu", "--stats_sec", "0"],
+                             "--context_len_sec", str(c.ctx_sec), "--gpu", "--stats_sec", "0"]
+                            + (["--gpus", str(gpus), "--share-gpu"] if gpus > 1 else []),
                             cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     try:
         line = ""
@@ -336,10 +339,13 @@ def test_serve_program_end_to_end():
             assert line or proc.poll() is None, "serve exited early"
         pin, pout = (int(x) for x in re.search(r"input :(\d+), output :(\d+)", line).groups())
         S = len(c.streams)
-        ins = [socket.create_connection(("127.0.0.1", pin)) for _ in range(S)]
-        time.sleep(0.3)
-        outs = [socket.create_connection(("127.0.0.1", pout)) for _ in range(S)]
-        time.sleep(0.3)
+        ins, outs = [], []
+        for _ in range(S):                       # one by one: arrival order = dialogue index (the wire carries no stream id)
+            ins.append(socket.create_connection(("127.0.0.1", pin)))
+            time.sleep(0.1)
+        for _ in range(S):
+            outs.append(socket.create_connection(("127.0.0.1", pout)))
+            time.sleep(0.1)
         for f in range(8):
             new = c.new_samples(f).astype(np.float64)
             for s in range(S):

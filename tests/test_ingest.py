@@ -312,3 +312,73 @@ def test_random_segmentation_and_reconnects_keep_every_stream_exact():
         for c in ins + outs:
             c.close()
         srv.close()
+
+
+class TaggedModel(Model):
+    """Model whose VAD columns carry the shard tag: which back-end answered is visible in every result packet."""
+
+    def __init__(self, tag):
+        super().__init__()
+        self.tag = tag
+
+    def step(self, ids, audio, out):
+        rc = super().step(ids, audio, out)
+        out[:, 4] = self.tag
+        out[:, 5] = ids
+        return rc
+
+
+def test_one_front_door_routes_dialogues_over_two_back_ends_and_reconnects_stick():
+    """vapx_frontdoor_*: ONE port pair (the reference's, vap_main.py:338-366) in front of two passive front-ends (= two GPUs).  Dialogue k
+    takes the lowest free GLOBAL slot g = local * N + shard, i.e. shard k mod 2; the k-th output connection hears the k-th dialogue; a
+    dialogue that drops and reconnects gets its old slot back (lowest free) — the shard that holds its state — and a full house refuses."""
+    hop = 800
+    models = [TaggedModel(10.0), TaggedModel(20.0)]
+    shards = [ingest.NativeServer.over_function(m.step, 2, 20, reset=m.reset, max_wait_s=0.05, port_in=-1, port_out=-1) for m in models]
+    assert all(s.port_in == 0 and s.port_out == 0 for s in shards)         # passive: listening on nothing
+    door = ingest.FrontDoor(shards, port_in=0, port_out=0)
+    try:
+        ins, outs = [], []
+        for k in range(4):                                                  # connect one by one: arrival order = dialogue index
+            ins.append(socket.create_connection(("127.0.0.1", door.port_in)))
+            _wait(lambda: door.counts()["accepted_in"] == k + 1)
+        for k in range(4):
+            outs.append(socket.create_connection(("127.0.0.1", door.port_out)))
+            _wait(lambda: door.counts()["accepted_out"] == k + 1)
+        assert [s.stats()["in_connections"] for s in shards] == [2, 2] and [s.stats()["out_connections"] for s in shards] == [2, 2]
+        rng = np.random.default_rng(11)
+        x = rng.standard_normal((4, 2, hop)) * np.array([0.1, 0.5, 1.0, 2.0])[:, None, None]
+
+        def frame_all(which):
+            for k in which:
+                ins[k].sendall(wire.encode_input(x[k, 0], x[k, 1]))
+            res = {}
+            for k in which:
+                _, r = _read_result(outs[k])
+                np.testing.assert_array_equal(r["x1"], x[k, 0])             # the k-th output connection hears the k-th dialogue
+                res[k] = r
+            return res
+
+        res = frame_all(range(4))
+        for k in range(4):
+            shard, local = ingest.FrontDoor.owner_of(k, 2)
+            assert res[k]["vad"] == [models[shard].tag, float(local)], (k, res[k]["vad"])
+            np.testing.assert_allclose(res[k]["p_now"], np.abs(x[k].astype(np.float32)).mean(axis=1), rtol=1e-6)
+        # a fifth dialogue finds every slot of every shard taken
+        extra = socket.create_connection(("127.0.0.1", door.port_in))
+        _wait(lambda: door.counts()["refused"] == 1)
+        extra.settimeout(5)
+        assert extra.recv(1) == b""                                         # closed by the front door
+        extra.close()
+        # dialogue 1 (shard 1, local 0) drops and reconnects: lowest free global slot = its old one -> same back-end, same slot
+        ins[1].close()
+        _wait(lambda: shards[1].stats()["in_connections"] == 1)
+        ins[1] = socket.create_connection(("127.0.0.1", door.port_in))
+        _wait(lambda: shards[1].stats()["in_connections"] == 2)
+        assert shards[0].stats()["in_connections"] == 2
+        res = frame_all([1])
+        assert res[1]["vad"] == [20.0, 0.0]
+        assert sorted(models[1].resets) == [0, 0, 1] and sorted(models[0].resets) == [0, 1]     # reset_on_connect per (re)connection
+        assert door.counts() == {"accepted_in": 5, "accepted_out": 4, "refused": 1}
+    finally:
+        door.close()

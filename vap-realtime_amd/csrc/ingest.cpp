@@ -423,55 +423,78 @@ void do_resume(vapx_ingest* g, int r, int slot) {
   ep_mod(g->ep[r], s.fd_in, K_DATA | (uint32_t)slot, true);
 }
 
+// lowest free input slot, or -1 (the front door compares this across shards)
+int lowest_free_slot(vapx_ingest* g) {
+  std::lock_guard<std::mutex> lk(g->slots_mu);
+  for (int i = 0; i < g->S; ++i)
+    if (g->slots[i].fd_in < 0) return i;
+  return -1;
+}
+
+// take over an accepted input connection: the lowest free stream slot gets it; false = every slot is taken (fd untouched)
+bool adopt_in(vapx_ingest* g, int fd) {
+  int slot = -1;
+  {
+    std::lock_guard<std::mutex> lk(g->slots_mu);
+    for (int i = 0; i < g->S; ++i)
+      if (g->slots[i].fd_in < 0) { slot = i; break; }
+    if (slot >= 0) g->slots[slot].fd_in = fd;
+  }
+  if (slot < 0) return false;
+  int one = 1;
+  setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+  Slot& s = g->slots[slot];
+  s.wbuf = -1; s.fill = 0; s.npartial = 0; s.backlog.clear(); s.paused = false;
+  {
+    // the carry restarts from zeros for every connection (vap_main.py:368-369); reset_on_connect also clears the
+    // model state, which the reference keeps.  Applied by the tick thread before its next step.
+    std::lock_guard<std::mutex> lk(g->ready_mu);
+    g->resets.push_back({slot, g->cfg.reset_on_connect ? 0 : 1});
+  }
+  g->in_conns.fetch_add(1);
+  ep_add(g->ep[slot % g->R], fd, K_DATA | (uint32_t)slot);
+  return true;
+}
+
 void accept_in(vapx_ingest* g) {
   for (;;) {
     int fd = accept4(g->lin, nullptr, nullptr, SOCK_NONBLOCK);
     if (fd < 0) return;
-    int slot = -1;
-    {
-      std::lock_guard<std::mutex> lk(g->slots_mu);
-      for (int i = 0; i < g->S; ++i)
-        if (g->slots[i].fd_in < 0) { slot = i; break; }
-      if (slot >= 0) g->slots[slot].fd_in = fd;
-    }
-    if (slot < 0) { close(fd); continue; }   // every stream slot is taken
-    int one = 1;
-    setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
-    Slot& s = g->slots[slot];
-    s.wbuf = -1; s.fill = 0; s.npartial = 0; s.backlog.clear(); s.paused = false;
-    {
-      // the carry restarts from zeros for every connection (vap_main.py:368-369); reset_on_connect also clears the
-      // model state, which the reference keeps.  Applied by the tick thread before its next step.
-      std::lock_guard<std::mutex> lk(g->ready_mu);
-      g->resets.push_back({slot, g->cfg.reset_on_connect ? 0 : 1});
-    }
-    g->in_conns.fetch_add(1);
-    ep_add(g->ep[slot % g->R], fd, K_DATA | (uint32_t)slot);
+    if (!adopt_in(g, fd)) close(fd);        // every stream slot is taken
   }
+}
+
+// the (listener count, slot) an output connection attached now would get: fewest listeners, lowest index first
+// (amortised O(1): a cursor walks the slots that still have `lmin` listeners and wraps with lmin + 1)
+std::pair<int, int> next_listener_slot(vapx_ingest* g) {
+  std::lock_guard<std::mutex> lk(g->slots_mu);
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int i = g->lcursor; i < g->S; ++i)
+      if (g->lcount[i] == g->lmin) { g->lcursor = i; return {g->lmin, i}; }
+    ++g->lmin; g->lcursor = 0;
+  }
+  return {g->lmin, 0};
+}
+
+// take over an accepted output connection (non-blocking like vap_main.py:346-347): the k-th output connection hears the k-th stream
+void adopt_out(vapx_ingest* g, int fd) {
+  int one = 1;
+  setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+  g->out_conns.fetch_add(1);
+  if (g->broadcast) { std::lock_guard<std::mutex> lk(g->slots_mu); g->out_all.push_back(fd); return; }
+  const int best = next_listener_slot(g).second;
+  std::lock_guard<std::mutex> lk(g->slots_mu);
+  g->lcursor = best + 1;
+  ++g->lcount[best];
+  std::lock_guard<std::mutex> l2(g->slots[best].lmu);
+  g->slots[best].listeners.push_back(fd);
 }
 
 void accept_out(vapx_ingest* g) {
   for (;;) {
-    int fd = accept4(g->lout, nullptr, nullptr, SOCK_NONBLOCK);   // non-blocking like vap_main.py:346-347
+    int fd = accept4(g->lout, nullptr, nullptr, SOCK_NONBLOCK);
     if (fd < 0) return;
-    int one = 1;
-    setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
-    g->out_conns.fetch_add(1);
-    std::lock_guard<std::mutex> lk(g->slots_mu);
-    if (g->broadcast) { g->out_all.push_back(fd); continue; }
-    // the stream with the fewest listeners, lowest index first (the k-th output connection hears the k-th stream); amortised
-    // O(1): a cursor walks the slots that still have `lmin` listeners and wraps with lmin + 1
-    int best = -1;
-    for (int pass = 0; pass < 2 && best < 0; ++pass) {
-      for (int i = g->lcursor; i < g->S; ++i)
-        if (g->lcount[i] == g->lmin) { best = i; break; }
-      if (best < 0) { ++g->lmin; g->lcursor = 0; }
-    }
-    if (best < 0) best = 0;
-    g->lcursor = best + 1;
-    ++g->lcount[best];
-    std::lock_guard<std::mutex> l2(g->slots[best].lmu);
-    g->slots[best].listeners.push_back(fd);
+    adopt_out(g, fd);
   }
 }
 
@@ -747,9 +770,13 @@ int open_common(vapx_ingest* g, const vapx_ingest_config* cfg) {
     j.rows.reserve(g->max_batch);
   }
   if (!g->stage || !g->batch_audio || !g->jobs[0].out || !g->jobs[1].out) return VAPX_E_NOMEM;
-  g->lin = listen_on(cfg->port_in, cfg->bind_any != 0, &g->port_in);
-  g->lout = listen_on(cfg->port_out, cfg->bind_any != 0, &g->port_out);
-  if (g->lin < 0 || g->lout < 0) return VAPX_E_INVAL;
+  // port_in < 0: a PASSIVE shard of a multi-GPU front door (vapx_frontdoor_open): it listens on nothing, connections are handed to it
+  const bool passive = cfg->port_in < 0;
+  if (!passive) {
+    g->lin = listen_on(cfg->port_in, cfg->bind_any != 0, &g->port_in);
+    g->lout = listen_on(cfg->port_out, cfg->bind_any != 0, &g->port_out);
+    if (g->lin < 0 || g->lout < 0) return VAPX_E_INVAL;
+  }
   g->resume_mu = std::vector<std::mutex>(g->R);
   g->resume.assign(g->R, {});
   for (int r = 0; r < g->R; ++r) {
@@ -758,10 +785,12 @@ int open_common(vapx_ingest* g, const vapx_ingest_config* cfg) {
     ep_add(g->ep[r], g->wake[r], K_WAKE);
   }
   g->lcount.assign(g->S, 0);
-  g->ep_accept = epoll_create1(0);          // own thread: a connect storm must not starve the streams of a receive thread
-  ep_add(g->ep_accept, g->lin, K_LISTEN_IN);
-  ep_add(g->ep_accept, g->lout, K_LISTEN_OUT);
-  g->accept_thread = std::thread(accept_main, g);
+  if (!passive) {
+    g->ep_accept = epoll_create1(0);          // own thread: a connect storm must not starve the streams of a receive thread
+    ep_add(g->ep_accept, g->lin, K_LISTEN_IN);
+    ep_add(g->ep_accept, g->lout, K_LISTEN_OUT);
+    g->accept_thread = std::thread(accept_main, g);
+  }
   for (int r = 0; r < g->R; ++r) g->rx_threads.emplace_back(rx_main, g, r);
   for (int x = 0; x < g->X; ++x) g->tx_threads.emplace_back(tx_main, g);
   g->tick_thread = std::thread(tick_main, g);
@@ -881,6 +910,115 @@ void vapx_ingest_close(vapx_ingest_handle g) {
   drop(g->jobs[0].out);
   drop(g->jobs[1].out);
   delete g;
+}
+
+// ---- one front door for N per-GPU front-ends ------------------------------------------------------------------------------------
+// The reference listens on ONE port pair (vap_main.py:338-366).  N GPUs = N passive shards (each with its own engine, receive / tick /
+// send threads) behind one accept thread on that pair.  Dialogue slots are numbered GLOBALLY g = local_slot * N + shard, so that
+//   - a new input connection takes the lowest free global slot: GPUs fill evenly at any load (round-robin), and a dialogue that
+//     reconnects while its slot is still the lowest free one lands on the GPU that holds its state (ring, LSTM) — stickiness;
+//   - the k-th output connection hears the k-th dialogue, exactly as a single front-end does (fewest listeners, lowest global slot).
+// A dialogue never moves between GPUs: its state lives there (vapx_get_state / vapx_set_state migrate one on purpose).
+}  // extern "C"
+
+struct vapx_frontdoor {
+  std::vector<vapx_ingest*> shards;
+  int lin = -1, lout = -1, port_in = 0, port_out = 0, ep = -1;
+  std::thread th;
+  std::atomic<bool> stop{false};
+  std::atomic<int64_t> accepted_in{0}, accepted_out{0}, refused{0};
+};
+
+namespace {
+
+void frontdoor_main(vapx_frontdoor* d) {
+  epoll_event evs[8];
+  const int N = (int)d->shards.size();
+  while (!d->stop.load()) {
+    int n = epoll_wait(d->ep, evs, 8, 100);
+    for (int i = 0; i < n; ++i) {
+      const uint64_t kind = evs[i].data.u64 & ~0xffffffffull;
+      for (;;) {
+        int fd = accept4(kind == K_LISTEN_IN ? d->lin : d->lout, nullptr, nullptr, SOCK_NONBLOCK);
+        if (fd < 0) break;
+        if (kind == K_LISTEN_IN) {
+          bool placed = false;
+          for (int attempt = 0; attempt < N && !placed; ++attempt) {      // (a shard can fill up between the query and the adoption)
+            long best = -1; int who = -1;
+            for (int k = 0; k < N; ++k) {
+              const int ls = lowest_free_slot(d->shards[k]);
+              if (ls < 0) continue;
+              const long gslot = (long)ls * N + k;
+              if (who < 0 || gslot < best) { best = gslot; who = k; }
+            }
+            if (who < 0) break;
+            placed = adopt_in(d->shards[who], fd);
+          }
+          if (placed) d->accepted_in.fetch_add(1);
+          else { close(fd); d->refused.fetch_add(1); }               // every dialogue slot of every GPU is taken
+        } else {
+          int who = 0; long bestc = -1, bestg = -1;
+          for (int k = 0; k < N; ++k) {
+            if (d->shards[k]->broadcast) continue;
+            const auto c = next_listener_slot(d->shards[k]);
+            const long gslot = (long)c.second * N + k;
+            if (bestc < 0 || c.first < bestc || (c.first == bestc && gslot < bestg)) { bestc = c.first; bestg = gslot; who = k; }
+          }
+          adopt_out(d->shards[who], fd);
+          d->accepted_out.fetch_add(1);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vapx_frontdoor_open(vapx_ingest_handle* shards, int32_t n_shards, int32_t port_in, int32_t port_out, int32_t bind_any,
+                        vapx_frontdoor_handle* out) {
+  if (!shards || n_shards < 1 || !out || port_in < 0 || port_out < 0) return VAPX_E_INVAL;
+  for (int k = 0; k < n_shards; ++k) {
+    if (!shards[k] || shards[k]->lin >= 0) return VAPX_E_INVAL;      // shards must be passive (vapx_ingest_config.port_in = -1)
+    if (shards[k]->hz != shards[0]->hz || shards[k]->mode != shards[0]->mode) return VAPX_E_INVAL;
+  }
+  vapx_frontdoor* d = new vapx_frontdoor();
+  d->shards.assign(shards, shards + n_shards);
+  d->lin = listen_on(port_in, bind_any != 0, &d->port_in);
+  d->lout = listen_on(port_out, bind_any != 0, &d->port_out);
+  if (d->lin < 0 || d->lout < 0) { vapx_frontdoor_close(d); return VAPX_E_INVAL; }
+  d->ep = epoll_create1(0);
+  ep_add(d->ep, d->lin, K_LISTEN_IN);
+  ep_add(d->ep, d->lout, K_LISTEN_OUT);
+  d->th = std::thread(frontdoor_main, d);
+  *out = d;
+  return VAPX_OK;
+}
+
+int vapx_frontdoor_ports(vapx_frontdoor_handle d, int32_t* port_in, int32_t* port_out) {
+  if (!d) return VAPX_E_INVAL;
+  if (port_in) *port_in = d->port_in;
+  if (port_out) *port_out = d->port_out;
+  return VAPX_OK;
+}
+
+int vapx_frontdoor_counts(vapx_frontdoor_handle d, int64_t* accepted_in, int64_t* accepted_out, int64_t* refused) {
+  if (!d) return VAPX_E_INVAL;
+  if (accepted_in) *accepted_in = d->accepted_in.load();
+  if (accepted_out) *accepted_out = d->accepted_out.load();
+  if (refused) *refused = d->refused.load();
+  return VAPX_OK;
+}
+
+void vapx_frontdoor_close(vapx_frontdoor_handle d) {
+  if (!d) return;
+  d->stop.store(true);
+  if (d->th.joinable()) d->th.join();
+  if (d->ep >= 0) close(d->ep);
+  if (d->lin >= 0) close(d->lin);
+  if (d->lout >= 0) close(d->lout);
+  delete d;                                  // the shards stay open: close them with vapx_ingest_close
 }
 
 int64_t vapx_wire_decode_input(const uint8_t* bytes, size_t n_bytes, double gain, float* x1_f32, float* x2_f32, double* x1_f64,

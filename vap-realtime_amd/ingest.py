@@ -152,3 +152,53 @@ def encode_result(mode: str, t: float, x1: np.ndarray, x2: np.ndarray, out_row: 
                                       row.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p), need)
     assert got == need
     return dst.tobytes()
+
+
+class FrontDoor:
+    """ONE port pair in front of N per-GPU front-ends (``vapx_frontdoor_*``): the reference's single ``port_num_in`` / ``port_num_out``
+    (vap_main.py:338-366,470-471) for a whole node.  ``shards`` are ``NativeServer`` objects opened PASSIVE (``port_in=-1, port_out=-1``),
+    one per engine / GPU.  Dialogue slots are global, ``g = local_slot * N + shard``: input connections take the lowest free one (GPUs
+    fill evenly; a reconnecting dialogue returns to the GPU holding its state while its slot is the lowest free one), the k-th output
+    connection hears the k-th dialogue."""
+
+    def __init__(self, shards, port_in: int = 50007, port_out: int = 50008, bind_any: bool = False):
+        self.lib = _engine.load_library()
+        self.shards = list(shards)
+        arr = (C.c_void_p * len(self.shards))(*[s._h.value for s in self.shards])
+        h = C.c_void_p()
+        rc = self.lib.vapx_frontdoor_open(arr, len(self.shards), port_in, port_out, int(bool(bind_any)), C.byref(h))
+        if rc != 0:
+            raise _engine.VapxError(f"vapx_frontdoor_open failed ({rc}): shards must be passive front-ends of one frame rate and mode, ports free")
+        self._h = h
+        a, b = C.c_int32(0), C.c_int32(0)
+        self.lib.vapx_frontdoor_ports(self._h, C.byref(a), C.byref(b))
+        self.port_in, self.port_out = a.value, b.value
+
+    @staticmethod
+    def owner_of(global_slot: int, n_shards: int):
+        """(shard, local slot) of a global dialogue slot."""
+        return global_slot % n_shards, global_slot // n_shards
+
+    def counts(self) -> dict:
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self.lib.vapx_frontdoor_counts(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return {"accepted_in": a.value, "accepted_out": b.value, "refused": c.value}
+
+    def stats(self, reset_latency_window: bool = False) -> list:
+        return [s.stats(reset_latency_window) for s in self.shards]
+
+    def close(self, close_shards: bool = True):
+        if getattr(self, "_h", None):
+            self.lib.vapx_frontdoor_close(self._h)
+            self._h = None
+        if close_shards:
+            for s in self.shards:
+                s.close()
+
+    stop = close
+
+    def __del__(self):
+        try:
+            self.close(close_shards=False)
+        except Exception:
+            pass
