@@ -93,7 +93,7 @@ def test_create_destroy_does_not_leak_device_memory():
             eng.step(audio)
         eng.close()
 
-    for k in range(6):                      # warm the allocator / code objects
+    for k in range(12):                     # warm the allocator / code objects: every (mode, rate, groups, split) combination of the cycle once
         cycle(k)
     torch.cuda.synchronize()
     free0, _ = torch.cuda.mem_get_info()

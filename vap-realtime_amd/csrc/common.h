@@ -90,6 +90,16 @@ __device__ __forceinline__ int opaque_vgpr(int v) {
   return v;
 }
 
+// Split-precision path: power of two s with |x| s < 2^14 for every |x| <= bound (bound >= 0, finite).  s in [2^-100, 2^40]: a tiny or
+// all-zero row is not blown up beyond what fp32 holds exactly.  Scaling an f16 (hi, lo) operand by a power of two and the fp32
+// accumulator by its inverse changes no bit of the product as long as nothing overflows — which is what the scale guarantees.
+__device__ __forceinline__ float pow2_scale_for(float bound) {
+  const int eb = (__builtin_bit_cast(int, bound) >> 23) & 0xff;     // bound < 2^(eb - 126)
+  int es = 267 - eb;                                                // biased exponent of 2^(13 - (eb - 127))
+  es = es < 27 ? 27 : (es > 167 ? 167 : es);
+  return __builtin_bit_cast(float, es << 23);
+}
+
 // value of lane `l` (wave-uniform index) in every lane: v_readlane_b32, no LDS
 __device__ __forceinline__ float lane_bcast(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));

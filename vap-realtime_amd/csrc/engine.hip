@@ -30,6 +30,7 @@ struct Layer {
   const float *ln_ffn_g, *ln_ffn_b, *w0, *w3;
   const float *w0f, *w3f, *wqkvf, *wkvxf, *wprojf, *wqxf, *wprojxf;   // fragment-major copies (fused blocks)
   const float *w0h, *w3h, *wqkvh, *wkvxh, *wprojh, *wqxh, *wprojxh;                             // split-precision (f16 hi/lo) fragment copies
+  float hid_scale = 1.0f;   // split-precision path: static power-of-two scale of the GELU hidden row (1 unless the weights allow |gelu(h)| >= 2^15)
 };
 
 }  // namespace
@@ -247,9 +248,11 @@ struct ProfScope {
   }
 };
 
-hipError_t gemm(vapx_engine* h, const GemmArgs& g, int epi, hipStream_t st) {
+// bounded_A: the A operand is bounded by construction (a LayerNorm / ChannelNorm+ReLU output, LSTM outputs): only then may the opt-in
+// split-precision product run (f16 operands overflow at 65504); GEMMs on RAW residual-stream / attention rows stay on the fp32 MFMA
+hipError_t gemm(vapx_engine* h, const GemmArgs& g, int epi, hipStream_t st, bool bounded_A = true) {
   ProfScope ps(h, epi, st);
-  if (h->cfg.flags & VAPX_FLAG_SPLIT_F16) {
+  if ((h->cfg.flags & VAPX_FLAG_SPLIT_F16) && bounded_A) {
     GemmArgs gs = g;
     gs.split = 1;
     return launch_gemm_f32(gs, epi, 0, st);
@@ -347,6 +350,7 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
     const float* xin = sc.xl[l];
     float* xout = sc.xl[l + 1];
     GemmArgs g;
+    const bool split = (h->cfg.flags & VAPX_FLAG_SPLIT_F16) != 0;   // fp32-accurate products on the f16 matrix cores
     const float *pre_att = nullptr, *pre_w = nullptr, *pre_resid = nullptr;   // long window: projection fused into the FFN block
     bool pre_ring = false;
     if (l == l_begin && !(l == 0 && qkv0_ready)) {
@@ -354,7 +358,7 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
       HIPCHK(h, gemm(h, g, EPI_STORE, st));
       if (l > 0) {
         g = gemm_args(xin, r256, Lw.wkv_x, M, 512, 256, sc.kvx, r512);
-        HIPCHK(h, gemm(h, g, EPI_STORE, st));
+        HIPCHK(h, gemm(h, g, EPI_STORE, st, /*bounded_A=*/false));   // raw residual rows
       }
     }
     if (T <= 64) {
@@ -384,7 +388,7 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
         ab.wqxf = nullptr; ab.qx = nullptr; ab.ring_rot = nullptr; ab.ids = nullptr;
         { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attn_block(ab, B, st)); }
       }
-    } else if (!(h->cfg.flags & (VAPX_FLAG_UNFUSED_PROJ | VAPX_FLAG_SPLIT_F16))) {
+    } else if (!(h->cfg.flags & VAPX_FLAG_UNFUSED_PROJ)) {
       // long window: plain attention kernels; every projection rides in a fused flat-row block (no [rows x 256] GEMM launches)
       AttnArgs aa{sc.qkv, sc.qkv + 256, sc.qkv + 512, sc.att, sc.bn, T, 768, 768, 0};
       const bool ring0 = l == 0 && rv && rv->ring;
@@ -393,18 +397,18 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
         aa.ring_rot = sc.rot; aa.ids = rv->ids;
       }
       { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attention(aa, B, st)); }
-      pre_att = sc.att; pre_w = Lw.wprojf; pre_resid = ring0 ? rv->ring : xin;
+      pre_att = sc.att; pre_w = split ? Lw.wprojh : Lw.wprojf; pre_resid = ring0 ? rv->ring : xin;
       pre_ring = ring0;
       if (l > 0) {
         // self half: xmid = xin + att.Wproj^T ; qx = LN_src(xmid).Wq_x^T
         FfnArgs fp;
         memset(&fp, 0, sizeof fp);
-        fp.mode = 2; fp.M = M; fp.att = sc.att; fp.wprojf = Lw.wprojf; fp.resid = xin; fp.xmid_out = sc.xmid;
-        fp.ln_g = Lw.ln_src_g; fp.ln_b = Lw.ln_src_b; fp.wqkvf = Lw.wqxf; fp.n_qkv_chunks = 1; fp.qkv = sc.qx;
-        { ProfScope ps(h, CLS_FFN, st); HIPCHK(h, launch_ffn_block(fp, st)); }
+        fp.mode = 2; fp.M = M; fp.att = sc.att; fp.wprojf = split ? Lw.wprojh : Lw.wprojf; fp.resid = xin; fp.xmid_out = sc.xmid;
+        fp.ln_g = Lw.ln_src_g; fp.ln_b = Lw.ln_src_b; fp.wqkvf = split ? Lw.wqxh : Lw.wqxf; fp.n_qkv_chunks = 1; fp.qkv = sc.qx;
+        { ProfScope ps(h, CLS_FFN, st); HIPCHK(h, split ? launch_ffn_block_f16x3(fp, st) : launch_ffn_block(fp, st)); }
         AttnArgs ax{sc.qx, sc.kvx, sc.kvx + 256, sc.att, sc.bn, T, 256, 512, 1};
         { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attention(ax, B, st)); }
-        pre_w = Lw.wprojxf; pre_resid = sc.xmid;
+        pre_w = split ? Lw.wprojxh : Lw.wprojxf; pre_resid = sc.xmid;
       }
     } else {
     // self attention
@@ -414,7 +418,7 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
       g.resid = xin; g.C2 = sc.xn;
       if (l == 0) { g.gamma = Lw.ln_ffn_g; g.beta = Lw.ln_ffn_b; }
       else { g.gamma = Lw.ln_src_g; g.beta = Lw.ln_src_b; }
-      HIPCHK(h, gemm(h, g, EPI_RESID_LN, st));
+      HIPCHK(h, gemm(h, g, EPI_RESID_LN, st, /*bounded_A=*/false));   // raw attention rows
       if (l > 0) {
         // cross attention: Q from LN_src(x), K/V from the OTHER channel's raw layer input
         g = gemm_args(sc.xn, r256, Lw.wq_x, M, 256, 256, sc.qx, r256);
@@ -423,17 +427,16 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
         { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attention(ax, B, st)); }
         g = gemm_args(sc.att, r256, Lw.wproj_x, M, 256, 256, sc.xmid, r256);
         g.resid = sc.xmid; g.C2 = sc.xn; g.gamma = Lw.ln_ffn_g; g.beta = Lw.ln_ffn_b;
-        HIPCHK(h, gemm(h, g, EPI_RESID_LN, st));
+        HIPCHK(h, gemm(h, g, EPI_RESID_LN, st, /*bounded_A=*/false));
       }
     }
     // feed-forward (+ next layer's projections)
-    const bool split = (h->cfg.flags & VAPX_FLAG_SPLIT_F16) != 0;   // fp32-accurate products on the f16 matrix cores
     FfnArgs fa;
     memset(&fa, 0, sizeof fa);
     fa.xmid = sc.xmid; fa.lnf_g = Lw.ln_ffn_g; fa.lnf_b = Lw.ln_ffn_b; fa.xout = xout; fa.M = M;
     if (pre_att) { fa.mode = 1; fa.att = pre_att; fa.wprojf = pre_w; fa.resid = pre_resid; fa.xmid_out = sc.xmid; }
     if (pre_ring) { fa.resid_rot = sc.rot; fa.resid_ids = rv->ids; fa.resid_T = T; }
-    fa.w0f = split ? Lw.w0h : Lw.w0f; fa.w3f = split ? Lw.w3h : Lw.w3f;
+    fa.w0f = split ? Lw.w0h : Lw.w0f; fa.w3f = split ? Lw.w3h : Lw.w3f; fa.hid_scale = Lw.hid_scale;
     if (l + 1 < l_end) {
       const Layer& Ln = h->layer[l + 1];
       const float* nqkv = split ? Ln.wqkvh : Ln.wqkvf;
@@ -665,7 +668,7 @@ int run_combinator_all_rows(vapx_engine* h, const Scratch& sc, int n, hipStream_
     GemmArgs g = gemm_args(sc.xl[4] + (long)c * T * 256, am, h->W(c ? "comb.wb" : "comb.wa"), M, 256, 256,
                            c ? sc.qx : sc.att, contiguous_rows(256));
     g.gamma = h->W("comb.g"); g.beta = h->W("comb.b");
-    HIPCHK(h, gemm(h, g, EPI_BIAS_LN_GELU, st));
+    HIPCHK(h, gemm(h, g, EPI_BIAS_LN_GELU, st, /*bounded_A=*/false));   // raw last-layer rows
   }
   const long tot = (long)M * 256;
   hipLaunchKernelGGL(add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, sc.xmid, sc.att, sc.qx, tot);
@@ -708,7 +711,7 @@ int step_group(vapx_engine* h, const Scratch& sc_own, int nb, int b0, const int*
   // layer 0 reads the rings in place (no chronological copy): always for the fused short-window block, and for long windows
   // when they run the fused long-window chain (the GEMM-chain variants need x0 as a plain buffer)
   const bool ring_direct = !(h->cfg.flags & VAPX_FLAG_MATERIALIZE_X0) &&
-                           (h->T <= 64 || !(h->cfg.flags & (VAPX_FLAG_UNFUSED_PROJ | VAPX_FLAG_SPLIT_F16)));
+                           (h->T <= 64 || !(h->cfg.flags & VAPX_FLAG_UNFUSED_PROJ));
   ga.rot = sc.rot;
   if (ring_direct) { ProfScope ps(h, CLS_GATHER, st); HIPCHK(h, launch_ring_append(ga, st)); }
   else { ProfScope ps(h, CLS_GATHER, st); HIPCHK(h, launch_gather_ln(ga, st)); }
@@ -850,6 +853,38 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
     Lw.wprojf = get("wprojf"); Lw.wqxf = get("wqxf"); Lw.wprojxf = get("wprojxf");
     Lw.w0h = get("w0h"); Lw.w3h = get("w3h"); Lw.wqkvh = get("wqkvh"); Lw.wkvxh = get("wkvxh");
     Lw.wprojh = get("wprojh"); Lw.wqxh = get("wqxh"); Lw.wprojxh = get("wprojxh");
+  }
+  if (cfg->flags & VAPX_FLAG_SPLIT_F16) {
+    // Static guarantees of the split-precision path, from the weights alone (host copy of the blob):
+    //  * every weight w satisfies |2^8 w| < 65504 (its f16 hi part is finite);
+    //  * the GELU hidden row h = LN_ffn(x) . W0^T obeys |h_j| <= sum_k |W0[j][k]| (16 |gamma_k| + |beta_k|) because a LayerNorm output is
+    //    bounded by 16 |gamma| + |beta|: a layer whose bound reaches 2^15 gets a power-of-two down-scale of the hidden operand.
+    for (int l = 0; l < 4; ++l) {
+      Layer& Lw = h->layer[l];
+      auto host = [&](const float* dev) { return blob + (dev - h->w); };
+      const struct { const float* p; size_t n; } mats[] = {{Lw.w0, 768 * 256}, {Lw.w3, 256 * 768}, {Lw.wqkv, 768 * 256}, {Lw.wproj, 65536},
+                                                          {Lw.wq_x, 65536}, {Lw.wkv_x, 512 * 256}, {Lw.wproj_x, 65536}};
+      for (const auto& m : mats) {
+        if (!m.p) continue;
+        const float* q = host(m.p);
+        for (size_t i = 0; i < m.n; ++i)
+          if (!(fabsf(q[i]) < 255.0f)) {
+            int rc = fail(nullptr, VAPX_E_INVAL, "VAPX_FLAG_SPLIT_F16: a transformer weight of layer %d has |w| >= 255 (or is not finite); use the fp32 path", l);
+            vapx_destroy(h);
+            return rc;
+          }
+      }
+      const float *w0 = host(Lw.w0), *gm = host(Lw.ln_ffn_g), *bt = host(Lw.ln_ffn_b);
+      double worst = 0.0;
+      for (int j = 0; j < 768; ++j) {
+        double b = 0.0;
+        for (int k = 0; k < 256; ++k) b += fabs((double)w0[j * 256 + k]) * (16.0 * fabs((double)gm[k]) + fabs((double)bt[k]));
+        worst = std::max(worst, b);
+      }
+      float hs = 1.0f;
+      while ((double)hs * worst >= 32768.0 && hs > 1e-30f) hs *= 0.5f;
+      Lw.hid_scale = hs;
+    }
   }
   const size_t S = cfg->max_streams, B = cfg->max_batch, T = h->T;
   const int* P = h->P;
@@ -1280,7 +1315,7 @@ int64_t vapx_peek(vapx_handle h, const char* name, float* dst, size_t max_floats
   else if (!strcmp(name, "lstm_out")) { src = h->sc.lstm_out; n = B * 2 * h->ncpc * 256; }
   else if (!strcmp(name, "e")) { src = h->sc.e; n = B * 2 * 256; }
   else if (!strcmp(name, "x0")) {
-    if (!(h->cfg.flags & VAPX_FLAG_MATERIALIZE_X0) && (h->T <= 64 || !(h->cfg.flags & (VAPX_FLAG_UNFUSED_PROJ | VAPX_FLAG_SPLIT_F16))))
+    if (!(h->cfg.flags & VAPX_FLAG_MATERIALIZE_X0) && (h->T <= 64 || !(h->cfg.flags & VAPX_FLAG_UNFUSED_PROJ)))
       return fail(h, VAPX_E_INVAL, "\"x0\" is read straight from the ring; create the engine with VAPX_FLAG_MATERIALIZE_X0 to peek it");
     src = h->sc.xl[0]; n = B * 2 * T * 256;
   }

@@ -18,6 +18,8 @@ struct FfnArgs {
   float* kvx;          // [M][512]
   int n_qkv_chunks;    // 3 (Q,K,V) or 2 (K,V only: pass wqkvf + 65536)
   int M;
+  float hid_scale;     // split-precision path only: static power-of-two scale (<= 1) of the GELU hidden row, from the weights' bound on
+                       // |gelu(h)| (engine.hip, vapx_create); 0 = 1
 #ifdef VAPX_TRACE
   unsigned long long* trace;   // debug build: optional [grid][32] s_memtime stamps of workgroup phases (env VAPX_FFN_TRACE)
 #endif

@@ -360,6 +360,7 @@ constexpr int ALD16 = 264;   // halves per sAtt row in SPLIT mode
 template <bool SPLIT, bool QX>
 __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[4 * 64 * KV_LD2];
+  __shared__ float vmx[4];                  // SPLIT: max |V| of each head's tile (bounds the attention output: a convex combination of V rows)
   float* sAtt = lds;                        // [64][260] (aliases the V tiles after a barrier)
   _Float16* sAh = (_Float16*)lds;           // SPLIT: [64][264] halves, hi then lo
   _Float16* sAl = sAh + 64 * ALD16;
@@ -429,6 +430,13 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
     for (int u = 0; u < 16; ++u) {
       int j = u * 4 + jb;
       *(f32x4*)&Vs[j * KV_LD2 + q4] = j < n ? vv[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (SPLIT) {   // the cross-attention V rows come from RAW residual-stream rows: their magnitude is the input's to decide
+      float m = 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) m = fmaxf(m, fmaxf(fmaxf(fabsf(vv[u][0]), fabsf(vv[u][1])), fmaxf(fabsf(vv[u][2]), fabsf(vv[u][3]))));
+      m = wave_max(m);
+      if (lane == 0) vmx[h] = m;
     }
   }
   STAMP();   // 1: V tile in LDS (first memory latency)
@@ -539,13 +547,24 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
         int i = mt * 32 + (r & 3) + 8 * (r >> 2) + h4;
         i = i < T ? i : T - 1;
         const unsigned off = (unsigned)prow(i) * 256u + (unsigned)ccol;
-        acc[mt * 2][r] = SPLIT ? rbase[off] * 256.0f : rbase[off];          // (split: the accumulator carries 2^8 x, undone exactly at the end)
-        acc[mt * 2 + 1][r] = SPLIT ? rbase[off + 32] * 256.0f : rbase[off + 32];
+        acc[mt * 2][r] = rbase[off];
+        acc[mt * 2 + 1][r] = rbase[off + 32];
       }
   }
   STAMP();   // 3: residual + weight-ring loads issued
   __syncthreads();             // every head is done with its V tile: the bytes become sAtt
   STAMP();   // 4: barrier passed (all heads done)
+  // SPLIT: |att| <= max |V| over the slab (softmax weights are a convex combination).  The attention output goes into the f16 (hi, lo)
+  // tile as att * osc with osc a power of two keeping it below 2^14, the accumulator carries 2^8 osc x and is un-scaled exactly at the end.
+  float osc = 1.0f;
+  if constexpr (SPLIT) {
+    osc = pow2_scale_for(fmaxf(fmaxf(vmx[0], vmx[1]), fmaxf(vmx[2], vmx[3])));
+    const float up = 256.0f * osc;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] *= up;
+  }
   // O^T accumulator r <-> feature d = dt*32 + (r&3) + 8*(r>>2) + 4*hi, query i = it*32 + l31
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
@@ -555,6 +574,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
     const f32x4 v11 = f32x4{ob1[rr * 4], ob1[rr * 4 + 1], ob1[rr * 4 + 2], ob1[rr * 4 + 3]};
     if constexpr (SPLIT) {
       auto put = [&](int row, int col, f32x4 v) {
+        v *= osc;
         const h16x4 hh = __builtin_convertvector(v, h16x4);
         const h16x4 ll = __builtin_convertvector(v - __builtin_convertvector(hh, f32x4), h16x4);
         *(h16x4*)&sAh[row * ALD16 + col] = hh;
@@ -574,7 +594,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
   __syncthreads();
 
   // ---- projection(s): [64 x 256] (LDS) . W^T, wave h owns columns 64h..64h+63 ----
-  auto mm = [&](f32x16(&acc)[4], const float* wfrag, const float* next_wfrag) {
+  auto mm = [&](f32x16(&acc)[4], const float* wfrag, const float* next_wfrag, float split_inv) {
     const float* pa = sAtt + l31 * 260 + kh;
     const f32x4* wf = wbase(wfrag);
     const f32x4* wnext = next_wfrag ? wbase(next_wfrag) : wf;
@@ -612,7 +632,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] *= (1.0f / 256.0f);   // weights are packed as 2^8 w
+        for (int r = 0; r < 16; ++r) acc[t][r] *= split_inv;   // weights are packed as 2^8 w (and the operand rows may carry a power-of-two scale)
       return;
     }
     // A fragments ping-pong between two register sets so the LDS reads of step k+1 fly under the
@@ -649,7 +669,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
   STAMP();   // 5: attention output in LDS
   f32x4 lg, lb;                 // LayerNorm weight / bias of this lane's 4 columns (row-per-wave form below): in flight under the projection
   if constexpr (QX) { lg = *(const f32x4*)(a.ln_g + lane * 4); lb = *(const f32x4*)(a.ln_b + lane * 4); }
-  mm(acc, a.wprojf, QX ? a.wqxf : nullptr);   // acc = resid + att . Wproj^T
+  mm(acc, a.wprojf, QX ? a.wqxf : nullptr, (1.0f / 256.0f) * __builtin_amdgcn_rcpf(osc));   // acc = resid + att . Wproj^T
   STAMP();   // 6: projection MFMAs done
   // Accumulator (mt, r) <-> tile row C + 4 hi with C = 32 mt + (r&3) + 8 (r>>2) a compile-time constant: every address below is ONE
   // per-lane base register plus a constant, and the row tests compare C with the per-lane T - 4 hi.
@@ -729,7 +749,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    mm(acc, a.wqxf, nullptr);
+    mm(acc, a.wqxf, nullptr, 1.0f / 256.0f);
     STAMP();   // 8: cross-q projection MFMAs done
     const int h4 = opaque_vgpr(kh);
     float* qbase = a.qx + (long)bc * T * 256;
