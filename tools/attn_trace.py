@@ -2,12 +2,17 @@
 """Timeline of attn_block_kernel workgroups from the s_memtime phase stamps of the DEBUG build (make -C vap-realtime_amd/csrc trace;
 engine env VAPX_ATTN_TRACE=<file>: layer-1 self-attention block of the last step — attention + projection + LN_src + cross-q projection).
 Usage: VAPX_LIBRARY=vap-realtime_amd/libvapx_trace.so VAPX_ATTN_TRACE=/tmp/a.bin python bench.py --workload c2 --configs= --no-latency
-       --no-cpu-baseline ; tools/attn_trace.py /tmp/a.bin"""
+       --no-cpu-baseline ; tools/attn_trace.py /tmp/a.bin
+Long windows (attention_long2_kernel, layer-1 self-attention, first 16384 workgroups): same recipe with --workload c3, then
+       tools/attn_trace.py --long /tmp/a.bin"""
 import sys
 
 import numpy as np
 
-NAMES = ["entry", "V in LDS (1st latency)", "scores+softmax+PV", "resid/ring loads issued", "barrier (all heads)", "O -> LDS + barrier",
+LONG = "--long" in sys.argv
+if LONG:
+    sys.argv.remove("--long")
+NAMES = ["entry", "V tile staged", "query tile w (wave 0: 1 key tile)", "query tile 7-w (wave 0: 8 key tiles)"] if LONG else ["entry", "V in LDS (1st latency)", "scores+softmax+PV", "resid/ring loads issued", "barrier (all heads)", "O -> LDS + barrier",
          "proj mm", "LN + xmid stores", "cross-q mm", "qx stores"]
 t = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 32).astype(np.int64)
 nst = int(np.median(t[:, 30]))

@@ -396,6 +396,9 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
         aa.q = rv->ring_qkv; aa.k = rv->ring_qkv + 256; aa.v = rv->ring_qkv + 512;
         aa.ring_rot = sc.rot; aa.ids = rv->ids;
       }
+#ifdef VAPX_TRACE
+      if (h->attn_trace && l == 1) { aa.trace = h->attn_trace; h->attn_trace_wgs = std::min<size_t>(16384, (size_t)B * 8); }
+#endif
       { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attention(aa, B, st)); }
       pre_att = sc.att; pre_w = split ? Lw.wprojh : Lw.wprojf; pre_resid = ring0 ? rv->ring : xin;
       pre_ring = ring0;

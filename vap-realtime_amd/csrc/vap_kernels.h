@@ -63,6 +63,9 @@ struct AttnArgs {
   const int* ring_rot;  // [B] or null.  Non-null (long-window layer 0): q/k/v are the per-stream Q|K|V RINGS (slab = slot*2+channel,
                         // logical row i in ring slot (i + ring_rot[b]) % T) instead of chronological batch buffers
   const int* ids;       // [B] stream slots (null: identity); only used with ring_rot
+#ifdef VAPX_TRACE
+  unsigned long long* trace;   // debug build: optional [grid][32] s_memtime stamps of workgroup phases (env VAPX_ATTN_TRACE, long windows)
+#endif
 };
 
 struct LastRowArgs {

@@ -432,14 +432,30 @@ __global__ __launch_bounds__(256, 2) void attention_long2_kernel(AttnArgs a) {
   const float* kp = a.k + slab_kv * T * a.ldkv + h * 64;
   const float* vp = a.v + slab_kv * T * a.ldkv + h * 64;
   const int nt_valid = (n + 31) >> 5;
-  for (int idx = tid; idx < nt_valid * 32 * 16; idx += 256) {
-    const int j = idx >> 4, q = (idx & 15) * 4;
-    f32x4 vv = {0.f, 0.f, 0.f, 0.f};
-    if (j < n) vv = *(const f32x4*)(vp + (long)prow(j) * a.ldkv + q);
-    *(f32x4*)&Vs[j * 64 + q] = vv;
+#ifdef VAPX_TRACE
+  int stamp_k = 0;
+  auto STAMP = [&]() {   // phase time stamps of wave 0 (debug build `make trace`: tools/attn_trace.py --long)
+    if (a.trace && tid == 0 && stamp_k < 28 && blockIdx.x < 16384) a.trace[(long)blockIdx.x * 32 + stamp_k] = __builtin_amdgcn_s_memtime();
+    ++stamp_k;
+  };
+  STAMP();   // 0: entry
+  if (a.trace && tid == 0 && blockIdx.x < 16384) a.trace[(long)blockIdx.x * 32 + 28] = __builtin_amdgcn_s_memrealtime();
+#else
+  auto STAMP = [] {};
+#endif
+  // The V tile (up to 256 keys x 64 features of this head) goes to LDS, but NOTHING waits for it before the first score tile is done:
+  // all 16 loads of a lane are issued first, then this wave's Q and K fragments, then S = K.Q^T of key tile 0 and its softmax run while
+  // V is still in flight; only then V lands in LDS (one barrier) and the P.V products start.  (Round 2 staged V in a load -> store loop
+  // ahead of everything else: 5.6 us alone, 18 us of a 47 us workgroup under load — profiles/r03_experiments/attn_long_trace_*.)
+  f32x4 vv[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int idx = u * 256 + tid, j = idx >> 4, q = (idx & 15) * 4;
+    const int jc = j < n ? j : n - 1;
+    vv[u] = *(const f32x4*)(vp + (long)prow(jc) * a.ldkv + q);
   }
-  __syncthreads();
   const float slope = exp2f(-2.0f * (float)(h + 1));  // [1/4, 1/16, 1/64, 1/256]
+  const float hi4f = (float)(4 * hi);
   auto load_k = [&](f32x4 (&kf)[8], int jt) {          // A operand of S^T = K.Q^T: key row jt*32 + l31, k-slots kc*8 + 4*hi ..+3
     int j = jt * 32 + l31;
     j = j < n ? j : n - 1;                             // rows beyond the window: clamped, masked below
@@ -447,89 +463,108 @@ __global__ __launch_bounds__(256, 2) void attention_long2_kernel(AttnArgs a) {
 #pragma unroll
     for (int kc = 0; kc < 8; ++kc) kf[kc] = *(const f32x4*)(kr + kc * 8);
   };
-  for (int pass = 0; pass < 2; ++pass) {
-    const int it = pass == 0 ? w : 7 - w;
-    if (it >= n_tiles) continue;
-    const int i = it * 32 + l31;
-    float* op = a.out + ((long)bc * T + i) * 256 + h * 64;
-    if (it >= nt_valid) {                              // whole tile beyond the valid rows: deterministic zeros
-      if (i < T) {
+  auto load_q = [&](f32x4 (&qf)[8], int it) {          // B operand: query row it*32 + l31 (clamped), k-slots kc*8 + 4*hi ..+3
+    int i = it * 32 + l31;
+    i = i < n ? i : n - 1;
+    const float* qp = a.q + (slab_q * T + prow(i)) * a.ldq + h * 64 + hi * 4;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) *(f32x4*)(op + hi * 32 + d * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-      continue;
-    }
-    f32x4 qf[8], kfa[8], kfb[8];
-    {
-      const int iq = i < n ? i : n - 1;
-      const float* qp = a.q + (slab_q * T + prow(iq)) * a.ldq + h * 64 + hi * 4;
+    for (int kc = 0; kc < 8; ++kc) qf[kc] = *(const f32x4*)(qp + kc * 8);
+  };
+  f32x4 qf[8], qn[8], kfa[8], kfb[8];
+  float m = -1e30f, l = 0.f;
+  f32x16 o0, o1, sc;
+  auto scores = [&](const f32x4 (&kf)[8]) {   // S^T tile = K_tile . Q^T: 32 MFMAs into one accumulator (unscaled: the 1/16 rides in the softmax fma)
 #pragma unroll
-      for (int kc = 0; kc < 8; ++kc) qf[kc] = *(const f32x4*)(qp + kc * 8);
-    }
-    load_k(kfa, 0);
+    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
 #pragma unroll
-    for (int kc = 0; kc < 8; ++kc) qf[kc] *= 0.0625f;
-    float m = -1e30f, l = 0.f;
-    f32x16 o0, o1;
+    for (int kc = 0; kc < 8; ++kc)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    auto scores = [&](f32x16& sc, const f32x4 (&kf)[8]) {   // S^T tile = K_tile . Q^T: 32 MFMAs into one accumulator
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sc[r] = 0.f;
-#pragma unroll
-      for (int kc = 0; kc < 8; ++kc)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[kc][s], qf[kc][s], sc, 0, 0, 0);
-    };
-    auto softmax = [&](f32x16& sc, int jt) {            // online update for one 32-key tile: sc := P, returns the rescale factor
-      float cm = -1e30f;
+      for (int s = 0; s < 4; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[kc][s], qf[kc][s], sc, 0, 0, 0);
+  };
+  // online softmax update for one 32-key tile: sc := P, returns the rescale factor of the running output.  accumulator r <-> key
+  // j = 32 jt + C_r + 4 hi with C_r = (r&3) + 8 (r>>2) a constant.  MASKED only for the tiles that need it: the diagonal tile
+  // (causal) and the tile that holds the window end; interior tiles skip the compares and selects.
+  auto softmax = [&](int jt, int i, bool masked) {
+    float cm = -1e30f;
+    const float jb = (float)(jt * 32) + hi4f;
+    if (masked) {
+      const int i4 = i - jt * 32 - 4 * hi, n4 = n - jt * 32 - 4 * hi;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        float v = sc[r] + slope * (float)j;
-        v = ((j <= i) && (j < n)) ? v : -1e30f;
+        const int c = (r & 3) + 8 * (r >> 2);
+        float v = fmaf(sc[r], 0.0625f, slope * ((float)c + jb));
+        v = ((c <= i4) && (c < n4)) ? v : -1e30f;
         sc[r] = v;
         cm = fmaxf(cm, v);
       }
-      cm = fmaxf(cm, __shfl_xor(cm, 32));
-      const float mn = fmaxf(m, cm);
-      const float alpha = __expf(m - mn);
-      float sum = 0.f;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = (r & 3) + 8 * (r >> 2);
+        const float v = fmaf(sc[r], 0.0625f, slope * ((float)c + jb));
+        sc[r] = v;
+        cm = fmaxf(cm, v);
+      }
+    }
+    cm = fmaxf(cm, __shfl_xor(cm, 32));
+    const float mn = fmaxf(m, cm);
+    const float alpha = __expf(m - mn);
+    float sum = 0.f;
+    if (masked) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float pv = sc[r] > -1e29f ? __expf(sc[r] - mn) : 0.f;
         sc[r] = pv;
         sum += pv;
       }
-      sum += __shfl_xor(sum, 32);
-      l = l * alpha + sum;
-      m = mn;
-      return alpha;
-    };
-    auto pv = [&](const f32x16& p, int jt, float alpha) {  // O^T = alpha O^T + V_tile^T . P^T
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float* va = &Vs[(jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + l31];
-        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[0], p[r], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32], p[r], o1, 0, 0, 0);
-      }
-    };
-    f32x16 sc;
-#pragma unroll 1
-    for (int jt = 0; jt <= it; jt += 2) {             // K fragments ping-pong one tile ahead of their use
-      if (jt + 1 <= it) load_k(kfb, jt + 1);
-      scores(sc, kfa);
-      float al = softmax(sc, jt);
-      pv(sc, jt, al);
-      if (jt + 1 <= it) {
-        if (jt + 2 <= it) load_k(kfa, jt + 2);
-        scores(sc, kfb);
-        al = softmax(sc, jt + 1);
-        pv(sc, jt + 1, al);
+        const float pv = __expf(sc[r] - mn);
+        sc[r] = pv;
+        sum += pv;
       }
     }
+    sum += __shfl_xor(sum, 32);
+    l = l * alpha + sum;
+    m = mn;
+    return alpha;
+  };
+  auto pv = [&](int jt, float alpha) {  // O^T = alpha O^T + V_tile^T . P^T
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float* va = &Vs[(jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + l31];
+      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[0], sc[r], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32], sc[r], o1, 0, 0, 0);
+    }
+  };
+  auto needs_mask = [&](int jt, int it) { return jt == it || (jt + 1) * 32 > n; };
+  auto begin = [&]() {
+    m = -1e30f; l = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  };
+  // key tiles jt0 .. it of query tile `it`; kfa / kfb already hold tiles jt0 / jt0 + 1 (fragments ping-pong one tile ahead of their use)
+  auto tiles_from = [&](int jt0, int it) {
+#pragma unroll 1
+    for (int jt = jt0; jt <= it; jt += 2) {
+      scores(kfa);
+      if (jt + 2 <= it) load_k(kfa, jt + 2);
+      float al = softmax(jt, it * 32 + l31, needs_mask(jt, it));
+      pv(jt, al);
+      if (jt + 1 <= it) {
+        scores(kfb);
+        if (jt + 3 <= it) load_k(kfb, jt + 3);
+        al = softmax(jt + 1, it * 32 + l31, needs_mask(jt + 1, it));
+        pv(jt + 1, al);
+      }
+    }
+  };
+  auto store_tile = [&](int it) {
+    const int i = it * 32 + l31;
+    float* op = a.out + ((long)bc * T + i) * 256 + h * 64;
     if (i < T) {
       const float scl = i < n ? 1.0f / l : 0.f;         // rows beyond the valid window: deterministic zeros
 #pragma unroll
@@ -540,7 +575,68 @@ __global__ __launch_bounds__(256, 2) void attention_long2_kernel(AttnArgs a) {
         *(f32x4*)(op + 32 + rr * 8 + hi * 4) = v1 * scl;
       }
     }
+  };
+  auto zero_tile = [&](int it) {                          // whole tile beyond the valid rows: deterministic zeros
+    const int i = it * 32 + l31;
+    if (i < T) {
+      float* op = a.out + ((long)bc * T + i) * 256 + h * 64;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) *(f32x4*)(op + hi * 32 + d * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+  // ---- pass 0 prologue: query tile w against key tile 0, before V is needed ----
+  const int it0 = w, it1 = 7 - w;
+  const bool act0 = it0 < nt_valid, act1 = it1 < nt_valid;
+  float al0 = 0.f;
+  if (act0) {
+    load_q(qf, it0);
+    load_k(kfa, 0);
+    if (it0 >= 1) load_k(kfb, 1);
+    begin();
+    scores(kfa);
+    if (it0 >= 2) load_k(kfa, 2);
+    al0 = softmax(0, it0 * 32 + l31, needs_mask(0, it0));
   }
+  if (act1) load_q(qn, it1);                             // the second pass's Q fragments fly under the first pass
+  // ---- V tile -> LDS (rows >= n: zeros; masked keys have P = 0 exactly, and 0 x garbage must stay 0) ----
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int idx = u * 256 + tid, j = idx >> 4, q = (idx & 15) * 4;
+    if (j < nt_valid * 32) *(f32x4*)&Vs[j * 64 + q] = j < n ? vv[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  STAMP();   // 1: V tile staged (first score tile already done)
+  if (act0) {
+    pv(0, al0);
+    if (it0 >= 1) {   // kfb holds tile 1, kfa tile 2: continue with (kfb, kfa) swapped roles
+      scores(kfb);
+      if (it0 >= 3) load_k(kfb, 3);
+      float al = softmax(1, it0 * 32 + l31, needs_mask(1, it0));
+      pv(1, al);
+      tiles_from(2, it0);
+    }
+    store_tile(it0);
+  } else if (it0 < n_tiles) {
+    zero_tile(it0);
+  }
+  STAMP();   // 2: query tile w done
+  // ---- pass 1: query tile 7 - w ----
+  if (act1) {
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) qf[kc] = qn[kc];
+    load_k(kfa, 0);
+    if (it1 >= 1) load_k(kfb, 1);
+    begin();
+    tiles_from(0, it1);
+    store_tile(it1);
+  } else if (it1 < n_tiles) {
+    zero_tile(it1);
+  }
+  STAMP();   // 3: query tile 7 - w done
+#ifdef VAPX_TRACE
+  if (a.trace && tid == 0 && blockIdx.x < 16384) { a.trace[(long)blockIdx.x * 32 + 29] = __builtin_amdgcn_s_memrealtime(); a.trace[(long)blockIdx.x * 32 + 30] = (unsigned long long)stamp_k; }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
