@@ -9,17 +9,24 @@ import numpy as np
 NAMES = ["entry", "tile staged+LN", "ffn1.0 mm", "gelu.0", "h->LDS.0", "ffn2.0 mm", "ffn1.1 mm", "gelu.1", "h->LDS.1", "ffn2.1 mm",
          "ffn1.2 mm", "gelu.2", "h->LDS.2", "ffn2.2 mm", "resid add", "x_out store", "x->LDS", "kvx0 mm", "kvx0 store", "kvx1 mm",
          "kvx1 store", "LN_self->LDS", "q mm", "q store", "k mm", "k store", "v mm", "v store"]
+SPLIT = "--split" in sys.argv
+if SPLIT:       # ffn_block_f16x3_kernel<0>: coarser stamps (VAPX_FLAG_SPLIT_F16 engine, bench.py --split-f16)
+    sys.argv.remove("--split")
+    NAMES = ["entry", "tile staged+LN+split", "ffn1.0 mm", "gelu+split->LDS.0", "ffn2.0 mm", "ffn1.1 mm", "gelu+split->LDS.1", "ffn2.1 mm",
+             "ffn1.2 mm", "gelu+split->LDS.2", "ffn2.2 mm", "resid + x_out store", "row stats", "kvx0 mm+store", "kvx1 mm+store",
+             "LN->LDS + q mm+store", "k mm+store", "v mm+store"]
+NST = len(NAMES)
 t = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 32).astype(np.int64)
 tick_ns = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
 n = t.shape[0]
-valid = (t[:, :28] > 0).all(axis=1)
+valid = (t[:, :NST] > 0).all(axis=1)
 t = t[valid]
 # absolute times from s_memrealtime (constant 100 MHz, chip-wide); the phase stamps are s_memtime (per-XCD counter whose rate
 # is calibrated per workgroup against the realtime pair)
 rt0 = t[:, 28].min()
 start, end = (t[:, 28] - rt0) * 0.01, (t[:, 29] - rt0) * 0.01          # us
 dur = end - start
-ticks = (t[:, 27] - t[:, 0]).astype(np.float64)
+ticks = (t[:, NST - 1] - t[:, 0]).astype(np.float64)
 us_per_tick = dur / np.maximum(ticks, 1)
 print(f"s_memtime rate: median {1.0 / np.median(us_per_tick):.1f} ticks/us")
 tick_ns = float(np.median(us_per_tick)) * 1e3
@@ -29,10 +36,10 @@ order = np.argsort(start)
 q = [0, 0.25, 0.5, 0.75, 1.0]
 print("start time quantiles (us):", [round(float(np.quantile(start, x)), 1) for x in q])
 print("end   time quantiles (us):", [round(float(np.quantile(end, x)), 1) for x in q])
-d = np.diff(t[:, :28], axis=1) * tick_ns / 1e3
+d = np.diff(t[:, :NST], axis=1) * tick_ns / 1e3
 print("phase durations, median over WGs (us) [p10 .. p90]:")
 mm_tot = other_tot = 0.0
-for k in range(27):
+for k in range(NST - 1):
     med = float(np.median(d[:, k]))
     if "mm" in NAMES[k + 1]:
         mm_tot += med

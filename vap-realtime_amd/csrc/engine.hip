@@ -30,6 +30,7 @@ struct Layer {
   const float *ln_ffn_g, *ln_ffn_b, *w0, *w3;
   const float *w0f, *w3f, *wqkvf, *wkvxf, *wprojf, *wqxf, *wprojxf;   // fragment-major copies (fused blocks)
   const float *w0h, *w3h, *wqkvh, *wkvxh, *wprojh, *wqxh, *wprojxh;                             // split-precision (f16 hi/lo) fragment copies
+  const float *wproj8, *wqx8, *wprojx8;   // the attention projections in the 8-wave format of the 64-row flat-row blocks (long windows)
   float hid_scale = 1.0f;   // split-precision path: static power-of-two scale of the GELU hidden row (1 unless the weights allow |gelu(h)| >= 2^15)
 };
 
@@ -400,18 +401,18 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
       if (h->attn_trace && l == 1) { aa.trace = h->attn_trace; h->attn_trace_wgs = std::min<size_t>(16384, (size_t)B * 8); }
 #endif
       { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attention(aa, B, st)); }
-      pre_att = sc.att; pre_w = split ? Lw.wprojh : Lw.wprojf; pre_resid = ring0 ? rv->ring : xin;
+      pre_att = sc.att; pre_w = split ? Lw.wproj8 : Lw.wprojf; pre_resid = ring0 ? rv->ring : xin;
       pre_ring = ring0;
       if (l > 0) {
         // self half: xmid = xin + att.Wproj^T ; qx = LN_src(xmid).Wq_x^T
         FfnArgs fp;
         memset(&fp, 0, sizeof fp);
-        fp.mode = 2; fp.M = M; fp.att = sc.att; fp.wprojf = split ? Lw.wprojh : Lw.wprojf; fp.resid = xin; fp.xmid_out = sc.xmid;
-        fp.ln_g = Lw.ln_src_g; fp.ln_b = Lw.ln_src_b; fp.wqkvf = split ? Lw.wqxh : Lw.wqxf; fp.n_qkv_chunks = 1; fp.qkv = sc.qx;
+        fp.mode = 2; fp.M = M; fp.att = sc.att; fp.wprojf = split ? Lw.wproj8 : Lw.wprojf; fp.resid = xin; fp.xmid_out = sc.xmid;
+        fp.ln_g = Lw.ln_src_g; fp.ln_b = Lw.ln_src_b; fp.wqkvf = split ? Lw.wqx8 : Lw.wqxf; fp.n_qkv_chunks = 1; fp.qkv = sc.qx;
         { ProfScope ps(h, CLS_FFN, st); HIPCHK(h, split ? launch_ffn_block_f16x3(fp, st) : launch_ffn_block(fp, st)); }
         AttnArgs ax{sc.qx, sc.kvx, sc.kvx + 256, sc.att, sc.bn, T, 256, 512, 1};
         { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, launch_attention(ax, B, st)); }
-        pre_w = split ? Lw.wprojxh : Lw.wprojxf; pre_resid = sc.xmid;
+        pre_w = split ? Lw.wprojx8 : Lw.wprojxf; pre_resid = sc.xmid;
       }
     } else {
     // self attention
@@ -856,6 +857,7 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
     Lw.wprojf = get("wprojf"); Lw.wqxf = get("wqxf"); Lw.wprojxf = get("wprojxf");
     Lw.w0h = get("w0h"); Lw.w3h = get("w3h"); Lw.wqkvh = get("wqkvh"); Lw.wkvxh = get("wkvxh");
     Lw.wprojh = get("wprojh"); Lw.wqxh = get("wqxh"); Lw.wprojxh = get("wprojxh");
+    Lw.wproj8 = get("wproj8"); Lw.wqx8 = get("wqx8"); Lw.wprojx8 = get("wprojx8");
   }
   if (cfg->flags & VAPX_FLAG_SPLIT_F16) {
     // Static guarantees of the split-precision path, from the weights alone (host copy of the blob):

@@ -21,11 +21,19 @@
 // Power-of-two scales commute with every rounding here, so the scaled product equals the unscaled one bit for bit wherever the
 // latter does not overflow (tests/test_split_precision_gpu.py::test_split_f16_handles_activations_far_beyond_the_f16_range).
 //
-// Same structure as ffn_block_kernel<1, MODE>: 32-row tile, 4 waves x 64 columns, LN_ffn on load, hidden row in LDS, next
-// layer's projections from the on-chip tile.  Differences: the A operands sit in LDS as f16 (hi, lo) row-major pairs
-// ([32][264] halves each: one ds_read_b128 = the 8 k-values of a lane), weights stream from L2 as f16 fragment pairs
-// ([4 w][16 kc][2 ns][2 hi/lo][64 lane][8 halves], weights.frag_pack_f16x3), C/D layout is the fp32 one (dtype
-// independent on gfx950).  A and B use the same lane -> k mapping, so the k order inside a 16-chunk is immaterial.
+// TILING (round 3).  The fp32 block streams its weights L2 -> VGPR once per 32-row tile: 256 KB per contraction, hidden under 16 k-cycles
+// of fp32 MFMA.  With three f16 MFMAs per product the same contraction needs 3/16 of the matrix-core time (1.4 us) but the SAME 256 KB,
+// and a CU takes at most 64 B / clk from its vector memory path: 1.85 us — the round-2 kernel (32-row tiles, 2 workgroups / CU) sat
+// on that wall (measured 2.2 us per contraction alone, 3.7 with a partner; profiles/r03_experiments/ffn_split_trace_*).  So the tile is
+// now 64 rows x 256 columns per workgroup, EIGHT waves, wave w = the 32 output columns 32 w .. 32 w + 31 of BOTH 32-row sub-tiles: every
+// weight fragment feeds six MFMAs instead of three (half the bytes per row), and two waves share each SIMD, so one wave's epilogue
+// VALU / LDS work runs under the other's MFMAs.  136 KB of LDS, one workgroup per CU.
+//   * A operands in LDS as f16 (hi, lo) row-major pairs ([64][264] halves each: one ds_read_b128 = the 8 k-values of a lane);
+//   * weights as f16 fragment pairs [8 w][16 kc][2 hi/lo][64 lane][8 halves] (weights.frag_pack_f16x3_w8), ring 8 k-chunks ahead;
+//   * every row statistic (LayerNorm mean / variance, the row maximum behind the power-of-two operand scale) is computed ROW-PER-WAVE on
+//     an fp32 copy of the tile parked in the LDS bytes of the (hi, lo) pair it is about to become — no cross-wave partial sums.
+// C/D layout is the fp32 one (dtype independent on gfx950); A and B use the same lane -> k mapping, so the k order inside a 16-chunk is
+// immaterial.
 #include "fused_blocks.h"
 
 namespace {
@@ -33,6 +41,8 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int LD16 = 264;                  // halves per LDS row: 256 + 8 pad (528 B: conflict-free 16-byte row reads)
 constexpr float kWScaleInv = 1.0f / 256.0f;   // weights are packed as 2^8 w
+
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void split_store(_Float16* hi, _Float16* lo, int idx, float v) {
   const _Float16 h = (_Float16)v;
@@ -42,23 +52,34 @@ __device__ __forceinline__ void split_store(_Float16* hi, _Float16* lo, int idx,
 
 // MODE as FfnArgs::mode (0: xmid from global; 1: attention-output projection + the whole block; 2: projection + LN + wqkvf chunks only)
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void ffn_block_f16x3_kernel(const FfnArgs g) {
+__global__ __launch_bounds__(512, 1) void ffn_block_f16x3_kernel(const FfnArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  constexpr int BM = 32;
+  constexpr int BM = 64;
   _Float16* sXh = (_Float16*)lds_raw;     // LN_ffn(x) tile, hi / lo
   _Float16* sXl = sXh + BM * LD16;
   _Float16* sHh = sXl + BM * LD16;        // attention rows / gelu chunk / raw x / LN rows, hi / lo
   _Float16* sHl = sHh + BM * LD16;
-  float* red = (float*)(sHl + BM * LD16); // [4][BM] row partials
-  float* rinv = red + 4 * BM;             // [BM] 1 / s_row of the staged attention rows (modes 1, 2)
+  float* sHf = (float*)sHh;               // the same bytes as ONE fp32 tile [BM][LD16] (2 x BM x LD16 halves = BM x LD16 floats)
+  float* rinv = (float*)(sHl + BM * LD16);   // [BM] 1 / s_row of the rows staged with a power-of-two scale
   const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..7
   const int l31 = lane & 31, hi = lane >> 5;
   const int m0 = blockIdx.x * BM;
+#ifdef VAPX_TRACE
+  int stamp_k = 0;
+  auto STAMP = [&]() {   // phase time stamps of wave 0 (debug build `make trace`: tools/ffn_trace.py --split)
+    if (g.trace && tid == 0 && stamp_k < 28) g.trace[(long)blockIdx.x * 32 + stamp_k] = __builtin_amdgcn_s_memtime();
+    ++stamp_k;
+  };
+  STAMP();
+  if (g.trace && tid == 0) g.trace[(long)blockIdx.x * 32 + 28] = __builtin_amdgcn_s_memrealtime();
+#else
+  auto STAMP = [] {};
+#endif
 
-  // weight fragments: ring of 4 k-chunks (16 x 16-byte fragments) ahead, running on into the next unit
+  // weight fragments of this wave's 32 columns: ring of 8 k-chunks (hi, lo) ahead, running on into the next unit
   f32x4 ring[16];
-  auto wbase = [&](const float* wfrag) { return (const f32x4*)wfrag + (long)w * 16 * 4 * 64; };   // wave-uniform
+  auto wbase = [&](const float* wfrag) { return (const f32x4*)wfrag + (long)w * 16 * 2 * 64; };   // wave-uniform
   auto fetch = [&](const float* wfrag) {
     const f32x4* wf = wbase(wfrag);
 #pragma unroll
@@ -66,75 +87,87 @@ __global__ __launch_bounds__(256, 2) void ffn_block_f16x3_kernel(const FfnArgs g
   };
   fetch(MODE == 0 ? g.w0f : g.wprojf);   // the first weight fragments fly while the tile is staged
 
-  if constexpr (MODE == 0) {   // A operand of FFN1 = LayerNorm(xmid; ln_ffn), normalised and split while the tile is staged
-    const f32x4 lg = *(const f32x4*)(g.lnf_g + lane * 4), lb = *(const f32x4*)(g.lnf_b + lane * 4);
-    f32x4 xr[BM / 4];
+  // wave w stages rows w, w + 8, ..: a lane holds 4 columns of a whole row, row statistics are wave reductions
+  auto split_row = [&](_Float16* dh, _Float16* dl, int row, const f32x4& y) {
+    const h16x4 hh = __builtin_convertvector(y, h16x4);
+    const h16x4 ll = __builtin_convertvector(y - __builtin_convertvector(hh, f32x4), h16x4);
+    *(h16x4*)&dh[row * LD16 + lane * 4] = hh;
+    *(h16x4*)&dl[row * LD16 + lane * 4] = ll;
+  };
+  {
+    f32x4 xr[BM / 8];
+    const float* src = MODE == 0 ? g.xmid : g.att;
 #pragma unroll
-    for (int k = 0; k < BM / 4; ++k) {
-      int m = m0 + (tid >> 6) + 4 * k;
+    for (int k = 0; k < BM / 8; ++k) {
+      int m = m0 + w + 8 * k;
       m = m < g.M ? m : g.M - 1;
-      xr[k] = *(const f32x4*)(g.xmid + (long)m * 256 + lane * 4);
+      xr[k] = *(const f32x4*)(src + (long)m * 256 + lane * 4);
     }
+    if constexpr (MODE == 0) {   // A operand of FFN1 = LayerNorm(xmid; ln_ffn), normalised and split while the tile is staged
+      const f32x4 lg = *(const f32x4*)(g.lnf_g + lane * 4), lb = *(const f32x4*)(g.lnf_b + lane * 4);
+      float sm[BM / 8];
 #pragma unroll
-    for (int k = 0; k < BM / 4; ++k) {
-      float sm = half_sum(xr[k][0] + xr[k][1] + xr[k][2] + xr[k][3]);
-      sm += __shfl_xor(sm, 32);
-      const float mean = sm * (1.0f / 256.0f);
-      f32x4 d = xr[k] - mean;
-      float sv = half_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]);
-      sv += __shfl_xor(sv, 32);
-      const float rstd = rsqrtf(sv * (1.0f / 256.0f) + 1e-5f);
-      const f32x4 y = d * rstd * lg + lb;
-      const int base = ((tid >> 6) + 4 * k) * LD16 + lane * 4;
+      for (int k = 0; k < BM / 8; ++k) sm[k] = wave_sum(xr[k][0] + xr[k][1] + xr[k][2] + xr[k][3]);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) split_store(sXh, sXl, base + e, y[e]);
-    }
-  } else {   // raw attention rows -> sH (A operand of the output projection): a wave stages WHOLE rows, so the row maximum is one
-             // wave reduction; the row goes in as x * s_row (|.| < 2^14), 1 / s_row is kept for the accumulator rows
-    f32x4 xr[BM / 4];
+      for (int k = 0; k < BM / 8; ++k) {
+        xr[k] = xr[k] - sm[k] * (1.0f / 256.0f);
+        sm[k] = xr[k][0] * xr[k][0] + xr[k][1] * xr[k][1] + xr[k][2] * xr[k][2] + xr[k][3] * xr[k][3];
+      }
 #pragma unroll
-    for (int k = 0; k < BM / 4; ++k) {
-      int m = m0 + (tid >> 6) + 4 * k;
-      m = m < g.M ? m : g.M - 1;
-      xr[k] = *(const f32x4*)(g.att + (long)m * 256 + lane * 4);
-    }
+      for (int k = 0; k < BM / 8; ++k) sm[k] = wave_sum(sm[k]);
 #pragma unroll
-    for (int k = 0; k < BM / 4; ++k) {
-      const float mx = wave_max(fmaxf(fmaxf(fabsf(xr[k][0]), fabsf(xr[k][1])), fmaxf(fabsf(xr[k][2]), fabsf(xr[k][3]))));
-      const float s = pow2_scale_for(mx);
-      const int row = (tid >> 6) + 4 * k;
-      if (lane == 0) rinv[row] = __builtin_amdgcn_rcpf(s);     // (exact: s is a power of two)
-      const int base = row * LD16 + lane * 4;
+      for (int k = 0; k < BM / 8; ++k) split_row(sXh, sXl, w + 8 * k, xr[k] * rsqrtf(sm[k] * (1.0f / 256.0f) + 1e-5f) * lg + lb);
+    } else {   // raw attention rows -> sH (A operand of the output projection), each as x * s_row with |.| < 2^14; 1 / s_row kept
+      float mx[BM / 8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) split_store(sHh, sHl, base + e, xr[k][e] * s);
+      for (int k = 0; k < BM / 8; ++k) mx[k] = wave_max(fmaxf(fmaxf(fabsf(xr[k][0]), fabsf(xr[k][1])), fmaxf(fabsf(xr[k][2]), fabsf(xr[k][3]))));
+#pragma unroll
+      for (int k = 0; k < BM / 8; ++k) {
+        const float s = pow2_scale_for(mx[k]);
+        if (lane == 0) rinv[w + 8 * k] = __builtin_amdgcn_rcpf(s);     // (exact: s is a power of two)
+        split_row(sHh, sHl, w + 8 * k, xr[k] * s);
+      }
     }
   }
   __syncthreads();
+  STAMP();   // 1: tile staged
 
+  // acc[rt] += A[rows 32 rt ..][256 k] (LDS hi / lo) . W^T for this wave's 32 columns
   auto mm = [&](f32x16(&acc)[2], const _Float16* Ah, const _Float16* Al, const float* wfrag, const float* next_wfrag) {
     const _Float16* pah = Ah + l31 * LD16 + hi * 8;
     const _Float16* pal = Al + l31 * LD16 + hi * 8;
     const f32x4* wf = wbase(wfrag);
     const f32x4* wnext = next_wfrag ? wbase(next_wfrag) : wf;
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(1);
+    // A fragments ping-pong one k-chunk ahead of their use
+    f16x8 n0h = *(const f16x8*)(pah), n0l = *(const f16x8*)(pal);
+    f16x8 n1h = *(const f16x8*)(pah + 32 * LD16), n1l = *(const f16x8*)(pal + 32 * LD16);
 #pragma unroll 1
-    for (int blk = 0; blk < 4; ++blk) {
-      const f32x4* nx = blk < 3 ? wf + (blk + 1) * 16 * 64 : wnext;
+    for (int blk = 0; blk < 2; ++blk) {
+      const f32x4* nx = blk < 1 ? wf + 16 * 64 : wnext;
 #pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) {
-        const int kc = blk * 4 + k4;
-        const f16x8 ah = *(const f16x8*)(pah + kc * 16), al = *(const f16x8*)(pal + kc * 16);
-        const f16x8 b0h = __builtin_bit_cast(f16x8, ring[k4 * 4 + 0]), b0l = __builtin_bit_cast(f16x8, ring[k4 * 4 + 1]);
-        const f16x8 b1h = __builtin_bit_cast(f16x8, ring[k4 * 4 + 2]), b1l = __builtin_bit_cast(f16x8, ring[k4 * 4 + 3]);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0h, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1h, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b0h, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b1h, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0l, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1l, acc[1], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ring[k4 * 4 + i] = nx[(k4 * 4 + i) * 64 + lane];
-        __builtin_amdgcn_sched_barrier(0);   // keep the refills behind their MFMAs
+      for (int k8 = 0; k8 < 8; ++k8) {
+        const int kn = ((blk * 8 + k8 + 1) & 15) * 16;
+        const f16x8 a0h = n0h, a0l = n0l, a1h = n1h, a1l = n1l;
+        n0h = *(const f16x8*)(pah + kn); n0l = *(const f16x8*)(pal + kn);
+        n1h = *(const f16x8*)(pah + 32 * LD16 + kn); n1l = *(const f16x8*)(pal + 32 * LD16 + kn);
+        const f16x8 bh = __builtin_bit_cast(f16x8, ring[k8 * 2]), bl = __builtin_bit_cast(f16x8, ring[k8 * 2 + 1]);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bh, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, bh, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, bh, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bl, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bl, acc[1], 0, 0, 0);
+        ring[k8 * 2] = nx[(k8 * 2) * 64 + lane];
+        ring[k8 * 2 + 1] = nx[(k8 * 2 + 1) * 64 + lane];
+        // one memory instruction between two MFMAs (4 LDS reads, 2 weight loads per 6 MFMAs)
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);   // keep the refills of this chunk behind its MFMAs
       }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -143,67 +176,47 @@ __global__ __launch_bounds__(256, 2) void ffn_block_f16x3_kernel(const FfnArgs g
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
   };
-  // accumulator (ns, r) <-> tile row lr = (r&3) + 8*(r>>2) + 4*hi, chunk column w*64 + ns*32 + l31
-  const int ccol = w * 64 + l31;
+  // accumulator (rt, r) <-> tile row lr = 32 rt + (r&3) + 8 (r>>2) + 4 hi, chunk column 32 w + l31
+  const int ccol = w * 32 + l31;
+  // (row index = compile-time constant C + 4 hi: every phase derives its addresses from ONE fresh per-lane base — opaque_vgpr — plus
+  // constants, so no table of 32 row indices stays live across the phases; without it hipcc spills up to 188 registers here)
   auto store_global = [&](const f32x16(&acc)[2], float* base, int ld, int col0) {
+    const int h4 = opaque_vgpr(4 * hi);
+    float* bu = base + (long)m0 * ld + col0;                  // workgroup-uniform
+    const unsigned o0 = (unsigned)(h4 * ld + ccol);
+    const int lim = g.M - m0 - h4;                            // row C is inside the matrix iff C < lim
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (m < g.M) {
-        float* p = base + (long)m * ld + col0 + ccol;
-        p[0] = acc[0][r];
-        p[32] = acc[1][r];
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = rt * 32 + (r & 3) + 8 * (r >> 2);
+        if (c < lim) bu[o0 + (unsigned)(c * ld)] = acc[rt][r];
       }
-    }
   };
-  // Row statistics of the tile held in accumulator layout (two-pass, partials across the 4 waves via `red`): mean and variance
-  auto row_stats = [&](const f32x16(&v)[2], float (&mean)[16], float (&var)[16]) {
-    float s[16];
+  // accumulator tile -> fp32 rows in the sH bytes (row-per-wave statistics follow); callers fence sH before and after
+  auto park = [&](const f32x16(&acc)[2]) {
+    float* p = sHf + opaque_vgpr(4 * hi) * LD16 + ccol;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = half_sum(v[0][r] + v[1][r]);
-    __syncthreads();          // every wave is done reading `red` / the LDS tile of the previous phase
-    if (l31 == 0)
+    for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) red[w * BM + (r & 3) + 8 * (r >> 2) + 4 * hi] = s[r];
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      mean[r] = (red[lr] + red[BM + lr] + red[2 * BM + lr] + red[3 * BM + lr]) * (1.0f / 256.0f);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float d0 = v[0][r] - mean[r], d1 = v[1][r] - mean[r];
-      s[r] = half_sum(d0 * d0 + d1 * d1);
-    }
-    if (l31 == 0)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) red[w * BM + (r & 3) + 8 * (r >> 2) + 4 * hi] = s[r];
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      var[r] = (red[lr] + red[BM + lr] + red[2 * BM + lr] + red[3 * BM + lr]) * (1.0f / 256.0f);
-    }
+      for (int r = 0; r < 16; ++r) p[(rt * 32 + (r & 3) + 8 * (r >> 2)) * LD16] = acc[rt][r];
   };
-  // LayerNorm rows (given their statistics) -> LDS tile (hi / lo) and optionally global
-  auto ln_write = [&](const f32x16(&v)[2], const float (&mean)[16], const float (&var)[16], const float* gam, const float* bet,
-                      _Float16* dh, _Float16* dl, float* gout) {
-    const float g0 = gam[ccol], g1 = gam[ccol + 32], b0 = bet[ccol], b1 = bet[ccol + 32];
+  // rows w, w + 8, .. of the parked tile: mean, variance (two-pass) and max |x| of each, the rows themselves in registers
+  auto parked_stats = [&](f32x4 (&x)[BM / 8], float (&mean)[BM / 8], float (&var)[BM / 8], float (&amax)[BM / 8]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const float rstd = rsqrtf(var[r] + 1e-5f);
-      const float y0 = (v[0][r] - mean[r]) * rstd * g0 + b0;
-      const float y1 = (v[1][r] - mean[r]) * rstd * g1 + b1;
-      split_store(dh, dl, lr * LD16 + ccol, y0);
-      split_store(dh, dl, lr * LD16 + ccol + 32, y1);
-      if (gout && m0 + lr < g.M) {
-        gout[(long)(m0 + lr) * 256 + ccol] = y0;
-        gout[(long)(m0 + lr) * 256 + ccol + 32] = y1;
-      }
+    for (int k = 0; k < BM / 8; ++k) x[k] = *(const f32x4*)&sHf[(w + 8 * k) * LD16 + lane * 4];
+#pragma unroll
+    for (int k = 0; k < BM / 8; ++k) {
+      mean[k] = wave_sum(x[k][0] + x[k][1] + x[k][2] + x[k][3]) * (1.0f / 256.0f);
+      amax[k] = wave_max(fmaxf(fmaxf(fabsf(x[k][0]), fabsf(x[k][1])), fmaxf(fabsf(x[k][2]), fabsf(x[k][3]))));
     }
+#pragma unroll
+    for (int k = 0; k < BM / 8; ++k) {
+      const f32x4 d = x[k] - mean[k];
+      var[k] = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+    }
+#pragma unroll
+    for (int k = 0; k < BM / 8; ++k) var[k] = wave_sum(var[k]) * (1.0f / 256.0f);
   };
 
   const int nq = g.wqkvf ? g.n_qkv_chunks : 0;
@@ -213,112 +226,146 @@ __global__ __launch_bounds__(256, 2) void ffn_block_f16x3_kernel(const FfnArgs g
     // ---- attention output projection + residual: xmid = resid + att . Wproj^T (the separate GEMM of the long-window path) ----
     zero(out);
     mm(out, sHh, sHl, g.wprojf, MODE == 1 ? g.w0f : after_ffn);
+    const int h4p = opaque_vgpr(4 * hi);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      int m = m0 + lr;
-      m = m < g.M ? m : g.M - 1;
-      const float* rp;
-      if (MODE == 1 && g.resid_rot) {   // layer 0: residual rows straight from the embedding ring
-        const int T = g.resid_T;
-        const int bc = m / T, i = m - bc * T, b = bc >> 1;
-        const long slab = (long)(g.resid_ids ? g.resid_ids[b] : b) * 2 + (bc & 1);
-        int rr = i + g.resid_rot[b];
-        rr = rr >= T ? rr - T : rr;
-        rp = g.resid + (slab * T + rr) * 256 + ccol;
-      } else {
-        rp = g.resid + (long)m * 256 + ccol;
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lr = rt * 32 + (r & 3) + 8 * (r >> 2) + h4p;
+        int m = m0 + lr;
+        m = m < g.M ? m : g.M - 1;
+        const float* rp;
+        if (MODE == 1 && g.resid_rot) {   // layer 0: residual rows straight from the embedding ring
+          const int T = g.resid_T;
+          const int bc = m / T, i = m - bc * T, b = bc >> 1;
+          const long slab = (long)(g.resid_ids ? g.resid_ids[b] : b) * 2 + (bc & 1);
+          int rr = i + g.resid_rot[b];
+          rr = rr >= T ? rr - T : rr;
+          rp = g.resid + (slab * T + rr) * 256 + ccol;
+        } else {
+          rp = g.resid + (long)m * 256 + ccol;
+        }
+        out[rt][r] = out[rt][r] * (rinv[lr] * kWScaleInv) + rp[0];     // undo the row scale of the staged attention row and the weights' 2^8
       }
-      const float inv = rinv[lr] * kWScaleInv;     // undo the row scale of the staged attention row and the weights' 2^8
-      out[0][r] = out[0][r] * inv + rp[0];
-      out[1][r] = out[1][r] * inv + rp[32];
-    }
     store_global(out, g.xmid_out, 256, 0);
-    if constexpr (MODE == 1) {   // A operand of FFN1 = LayerNorm(xmid; ln_ffn)
-      float mean[16], var[16];
-      row_stats(out, mean, var);
-      ln_write(out, mean, var, g.lnf_g, g.lnf_b, sXh, sXl, nullptr);
+    STAMP();   // 2: projection + residual
+    if constexpr (MODE == 1) {   // A operand of FFN1 = LayerNorm(xmid; ln_ffn): parked in sH (the attention rows are consumed), normalised into sX
+      __syncthreads();           // every wave is done reading the attention rows
+      park(out);
+      __syncthreads();
+      f32x4 x[BM / 8];
+      float mean[BM / 8], var[BM / 8], amax[BM / 8];
+      parked_stats(x, mean, var, amax);
+      const f32x4 lg = *(const f32x4*)(g.lnf_g + lane * 4), lb = *(const f32x4*)(g.lnf_b + lane * 4);
+#pragma unroll
+      for (int k = 0; k < BM / 8; ++k) split_row(sXh, sXl, w + 8 * k, (x[k] - mean[k]) * rsqrtf(var[k] + 1e-5f) * lg + lb);
       __syncthreads();
     }
   }
   if constexpr (MODE != 2) {
     // ---- feed-forward: x = xmid + gelu(xn W0^T) W3^T, hidden processed in 3 chunks of 256 ----
-    // hid_scale: static power of two <= 1 from the weights' bound on |gelu(h)| (weights.pack_blob), 1 for every sane checkpoint
+    // hid_scale: static power of two <= 1 from the weights' bound on |gelu(h)| (vapx_create), 1 for every sane checkpoint
     const float hs = g.hid_scale > 0.f ? g.hid_scale : 1.0f;
     zero(out);
     for (int c = 0; c < 3; ++c) {
       f32x16 hacc[2];
       zero(hacc);
       mm(hacc, sXh, sXl, g.w0f + (long)c * 65536, g.w3f + (long)c * 65536);
+      STAMP();   // FFN1 chunk mm
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        hacc[0][r] = gelu_fast(hacc[0][r] * kWScaleInv) * hs;
-        hacc[1][r] = gelu_fast(hacc[1][r] * kWScaleInv) * hs;
-        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-      }
-      __syncthreads();          // every wave is done reading the previous chunk from sH
+      for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        split_store(sHh, sHl, lr * LD16 + ccol, hacc[0][r]);
-        split_store(sHh, sHl, lr * LD16 + ccol + 32, hacc[1][r]);
+        for (int r = 0; r < 16; ++r) hacc[rt][r] = gelu_fast(hacc[rt][r] * kWScaleInv) * hs;
+      __syncthreads();          // every wave is done reading the previous chunk (or the parked tile) from sH
+      {
+        const int b0 = opaque_vgpr(4 * hi) * LD16 + ccol;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) split_store(sHh, sHl, b0 + (rt * 32 + (r & 3) + 8 * (r >> 2)) * LD16, hacc[rt][r]);
       }
       __syncthreads();
+      STAMP();   // gelu + split + h -> LDS
       mm(out, sHh, sHl, g.w3f + (long)c * 65536, c < 2 ? g.w0f + (long)(c + 1) * 65536 : after_ffn);
+      STAMP();   // FFN2 chunk mm
     }
     {
       const float inv = kWScaleInv * __builtin_amdgcn_rcpf(hs);
-      const float* xm = MODE == 0 ? g.xmid : g.xmid_out;   // (mode 1: this lane's own xmid elements, written above)
+      const float* xm = (MODE == 0 ? g.xmid : g.xmid_out) + (long)m0 * 256;   // (mode 1: this lane's own xmid elements, written above)
+      const int h4 = opaque_vgpr(4 * hi);
+      const int last = g.M - 1 - m0 - h4;                      // rows beyond the matrix re-read its last row (their results are not stored)
+      const unsigned o0 = (unsigned)(h4 * 256 + ccol);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        m = m < g.M ? m : g.M - 1;
-        const float* rp = xm + (long)m * 256 + ccol;
-        out[0][r] = out[0][r] * inv + rp[0];
-        out[1][r] = out[1][r] * inv + rp[32];
-      }
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int c = rt * 32 + (r & 3) + 8 * (r >> 2);
+          c = c < last ? c : last;
+          out[rt][r] = out[rt][r] * inv + xm[o0 + (unsigned)(c * 256)];
+        }
     }
     store_global(out, g.xout, 256, 0);
+    STAMP();   // residual + x_out store
   }
   // ---- next layer's projections: cross K,V from the RAW layer output, self Q,K,V from LayerNorm(x) ----
   if (g.wkvxf || nq || g.xn_out) {
-    float mean[16], var[16];
-    row_stats(out, mean, var);   // (also fences the LDS tile: every wave is done with the previous contraction's reads)
-    if constexpr (MODE != 2) {
-      if (g.wkvxf) {
-        // raw rows: |x| <= sqrt(sum x^2) = 16 sqrt(var + mean^2); scaled per row so that the f16 operand stays below 2^14
-        float sinv[16];
+    __syncthreads();            // every wave is done reading sH in the previous contraction
+    park(out);
+    __syncthreads();
+    f32x4 x[BM / 8];
+    float mean[BM / 8], var[BM / 8], amax[BM / 8];
+    parked_stats(x, mean, var, amax);
+    STAMP();   // row statistics
+    __syncthreads();            // the (hi, lo) rows written next alias OTHER waves' fp32 rows: every row is in registers first
+    if (MODE != 2 && g.wkvxf) {
+      // raw rows, each scaled by a power of two so that the f16 operand stays below 2^14 (exact row maximum: the wave holds the row)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float s = pow2_scale_for(16.0f * sqrtf(var[r] + mean[r] * mean[r]) * 1.0001f);
-          sinv[r] = __builtin_amdgcn_rcpf(s) * kWScaleInv;
-          const int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
-          split_store(sHh, sHl, lr * LD16 + ccol, out[0][r] * s);
-          split_store(sHh, sHl, lr * LD16 + ccol + 32, out[1][r] * s);
-        }
-        __syncthreads();
-        for (int nc = 0; nc < 2; ++nc) {
-          f32x16 acc[2];
-          zero(acc);
-          mm(acc, sHh, sHl, g.wkvxf + (long)nc * 65536, nc == 0 ? g.wkvxf + 65536 : (nq ? g.wqkvf : nullptr));
+      for (int k = 0; k < BM / 8; ++k) {
+        const float s = pow2_scale_for(amax[k]);
+        if (lane == 0) rinv[w + 8 * k] = __builtin_amdgcn_rcpf(s);
+        split_row(sHh, sHl, w + 8 * k, x[k] * s);
+      }
+      __syncthreads();
+      for (int nc = 0; nc < 2; ++nc) {
+        f32x16 acc[2];
+        zero(acc);
+        mm(acc, sHh, sHl, g.wkvxf + (long)nc * 65536, nc == 0 ? g.wkvxf + 65536 : (nq ? g.wqkvf : nullptr));
+        const float* ri = rinv + opaque_vgpr(4 * hi);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { acc[0][r] *= sinv[r]; acc[1][r] *= sinv[r]; }
-          store_global(acc, g.kvx, 512, nc * 256);
-        }
-        __syncthreads();        // every wave is done reading the raw rows: the tile becomes the LayerNorm rows
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[rt][r] *= ri[rt * 32 + (r & 3) + 8 * (r >> 2)] * kWScaleInv;
+        store_global(acc, g.kvx, 512, nc * 256);
+        STAMP();   // kvx mm + store
+      }
+      __syncthreads();          // every wave is done reading the raw rows: the tile becomes the LayerNorm rows
+    }
+    {
+      const f32x4 lg = *(const f32x4*)(g.ln_g + lane * 4), lb = *(const f32x4*)(g.ln_b + lane * 4);
+#pragma unroll
+      for (int k = 0; k < BM / 8; ++k) {
+        const f32x4 y = (x[k] - mean[k]) * rsqrtf(var[k] + 1e-5f) * lg + lb;
+        split_row(sHh, sHl, w + 8 * k, y);
+        const int m = m0 + w + 8 * k;
+        if (g.xn_out && m < g.M) *(f32x4*)(g.xn_out + (long)m * 256 + lane * 4) = y;
       }
     }
-    ln_write(out, mean, var, g.ln_g, g.ln_b, sHh, sHl, g.xn_out);
     __syncthreads();
     for (int nc = 0; nc < nq; ++nc) {
       f32x16 acc[2];
       zero(acc);
       mm(acc, sHh, sHl, g.wqkvf + (long)nc * 65536, nc + 1 < nq ? g.wqkvf + (long)(nc + 1) * 65536 : nullptr);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[0][r] *= kWScaleInv; acc[1][r] *= kWScaleInv; }
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rt][r] *= kWScaleInv;
       store_global(acc, g.qkv, nq * 256, nc * 256);
+      STAMP();   // q / k / v mm + store
     }
   }
+#ifdef VAPX_TRACE
+  if (g.trace && tid == 0) { g.trace[(long)blockIdx.x * 32 + 29] = __builtin_amdgcn_s_memrealtime(); g.trace[(long)blockIdx.x * 32 + 30] = (unsigned long long)stamp_k; }
+#endif
 }
 
 }  // namespace
@@ -331,9 +378,8 @@ hipError_t launch_ffn_block_f16x3(const FfnArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)ffn_block_f16x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ffn_block_f16x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  // (64-row tiles halve the weight stream but leave one wave per SIMD: measured 8 % slower at 4096 streams, not built)
-  const size_t lds = (size_t)4 * 32 * LD16 * sizeof(_Float16) + (4 * 32 + 32) * sizeof(float);
-  const dim3 grid((a.M + 31) / 32), block(256);
+  const size_t lds = (size_t)4 * 64 * LD16 * sizeof(_Float16) + 64 * sizeof(float);
+  const dim3 grid((a.M + 63) / 64), block(512);
   if (a.mode == 1 || a.mode == 2) {
     if (!a.att || !a.wprojf || !a.resid || !a.xmid_out) return hipErrorInvalidValue;
     if (a.mode == 1) hipLaunchKernelGGL(ffn_block_f16x3_kernel<1>, grid, block, lds, st, a);

@@ -534,7 +534,10 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
   // acc[mt*2 + ns][r] <-> row i = mt*32 + (r&3) + 8*(r>>2) + 4*hi, column 64w + 32ns + l31.  The projection accumulates ON TOP of the
   // residual rows: their 64 loads per lane are issued here, fly under the barriers and the sAtt stores, and are consumed by the first
   // MFMA of each accumulator — no separate load-wait-add phase after the projection (and 64 registers less at the LayerNorm).
-  const int ccol = w * 64 + l31;
+  // SPLIT: the f16x3 weight fragments interleave the output columns of a wave's two tiles (weights.frag_pack_f16x3: tile ns holds columns
+  // 2 l + ns), so a lane's two accumulators are adjacent columns; fp32 fragments keep tile ns = columns 32 ns + l
+  const int ccol = SPLIT ? w * 64 + 2 * l31 : w * 64 + l31;
+  constexpr int CS = SPLIT ? 1 : 32;   // column distance between acc[2 mt] and acc[2 mt + 1]
   f32x16 acc[4];
   __builtin_amdgcn_sched_barrier(0);   // (the row offsets below must not be hoisted above the attention phase: 32 live registers)
   {
@@ -548,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
         i = i < T ? i : T - 1;
         const unsigned off = (unsigned)prow(i) * 256u + (unsigned)ccol;
         acc[mt * 2][r] = rbase[off];
-        acc[mt * 2 + 1][r] = rbase[off + 32];
+        acc[mt * 2 + 1][r] = rbase[off + CS];
       }
   }
   STAMP();   // 3: residual + weight-ring loads issued
@@ -685,7 +688,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
         const int c = mt * 32 + (r & 3) + 8 * (r >> 2);
         if (c < T4) {
           const unsigned off = o0 + (unsigned)c * 256u;
-          xbase[off] = acc[mt * 2][r]; xbase[off + 32] = acc[mt * 2 + 1][r];
+          xbase[off] = acc[mt * 2][r]; xbase[off + CS] = acc[mt * 2 + 1][r];
         }
       }
     STAMP();   // 7: xmid stores issued
@@ -703,7 +706,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int c = mt * 32 + (r & 3) + 8 * (r >> 2);
-          ps[c * 260] = acc[mt * 2][r]; ps[c * 260 + 32] = acc[mt * 2 + 1][r];
+          ps[c * 260] = acc[mt * 2][r]; ps[c * 260 + CS] = acc[mt * 2 + 1][r];
         }
     }
     __syncthreads();
@@ -762,7 +765,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
         const int c = mt * 32 + (r & 3) + 8 * (r >> 2);
         if (c < T4) {
           const unsigned off = o0 + (unsigned)c * 256u;
-          qbase[off] = acc[mt * 2][r]; qbase[off + 32] = acc[mt * 2 + 1][r];
+          qbase[off] = acc[mt * 2][r]; qbase[off + CS] = acc[mt * 2 + 1][r];
         }
       }
   }

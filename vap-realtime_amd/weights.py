@@ -247,11 +247,15 @@ def blob_entries(K: int, mode: str) -> List[Tuple[str, int]]:
             e.append((f"{p}.wkvxf", 2 * DIM * DIM))  # 2 column chunks [Wk_x;Wv_x]
             e.append((f"{p}.wqxf", DIM * DIM))
             e.append((f"{p}.wprojxf", DIM * DIM))
-        # split-precision (f16 hi/lo) fragment copies for the opt-in f16x3 FFN block, same chunking as the *f entries
-        e.append((f"{p}.w0h", FFN * DIM)); e.append((f"{p}.w3h", DIM * FFN)); e.append((f"{p}.wqkvh", 3 * DIM * DIM))
-        e.append((f"{p}.wprojh", DIM * DIM))
+        # split-precision (f16 hi/lo) fragment copies for the opt-in f16x3 path, same chunking as the *f entries.  *h = 4 waves x 64
+        # interleaved columns (frag_pack_f16x3: the fused short-window attention block), *8 = 8 waves x 32 columns (frag_pack_f16x3_w8:
+        # the 64-row flat-row blocks: FFN, next-layer projections, long-window attention projections)
+        e.append((f"{p}.w0h", FFN * DIM)); e.append((f"{p}.w3h", DIM * FFN)); e.append((f"{p}.wqkvh", 3 * DIM * DIM))   # w8 format
+        e.append((f"{p}.wprojh", DIM * DIM)); e.append((f"{p}.wproj8", DIM * DIM))
         if l > 0:
-            e.append((f"{p}.wkvxh", 2 * DIM * DIM)); e.append((f"{p}.wqxh", DIM * DIM)); e.append((f"{p}.wprojxh", DIM * DIM))
+            e.append((f"{p}.wkvxh", 2 * DIM * DIM))                                                                  # w8 format
+            e.append((f"{p}.wqxh", DIM * DIM)); e.append((f"{p}.wprojxh", DIM * DIM))
+            e.append((f"{p}.wqx8", DIM * DIM)); e.append((f"{p}.wprojx8", DIM * DIM))
     # fused last-row block (csrc/last_block.hip): fourteen 256x256 units of layer 3, 16x16x4-MFMA fragment-major
     # [unit][8 w][16 kc][2 ns][64 lane][4]: Wq, Wk^T per head, Wv, Wproj, Wq_x, Wk_x^T per head, Wv_x, Wproj_x,
     # W0 column chunks 0-2, W3 k-chunks 0-2
@@ -290,16 +294,35 @@ F16X3_WEIGHT_SCALE = 256.0   # weights are split as 2^8 w so that the low part s
 def frag_pack_f16x3(W: np.ndarray, n0: int, k0: int) -> np.ndarray:
     """256x256 sub-matrix -> split-precision B fragments for v_mfma_f32_32x32x16_f16 (csrc/ffn_block_f16x3.hip):
     w' = 2^8 w = hi + lo (both f16), order [4 wave][16 kc][2 ns][2 hi/lo][64 lane][8] with
-    value = w'[n0 + 64w + 32ns + (lane&31)][k0 + 16kc + 8(lane>>5) + i]; returned as a float32 container (65536)."""
+    value = w'[n0 + 64w + 2(lane&31) + ns][k0 + 16kc + 8(lane>>5) + i]; returned as a float32 container (65536).
+    Output columns are INTERLEAVED between the two 32-column MFMA tiles of a wave (tile ns holds columns 2 l + ns): a lane's two
+    accumulators then hold ADJACENT columns, so every epilogue access (global stores / residual loads, f16 (hi, lo) LDS stores) moves
+    two values per instruction."""
     sub = np.ascontiguousarray(W[n0:n0 + 256, k0:k0 + 256], dtype=np.float32) * np.float32(F16X3_WEIGHT_SCALE)
     if np.abs(sub).max() >= 60000.0:
         raise ValueError("weights too large for the split-f16 path (|w| >= 234)")
     hi = sub.astype(np.float16)
     lo = (sub - hi.astype(np.float32)).astype(np.float16)
 
-    def lay(a):   # [n = (w, ns, l31)][k = (kc, kh, i)] -> [w][kc][ns][kh][l31][i]
-        return a.reshape(4, 2, 32, 16, 2, 8).transpose(0, 3, 1, 4, 2, 5)
+    def lay(a):   # [n = (w, l31, ns)][k = (kc, kh, i)] -> [w][kc][ns][kh][l31][i]
+        return a.reshape(4, 32, 2, 16, 2, 8).transpose(0, 3, 2, 4, 1, 5)
     both = np.stack([lay(hi), lay(lo)], axis=3)           # [w][kc][ns][hl][kh][l31][i]
+    return np.ascontiguousarray(both).reshape(-1).view(np.float32)
+
+
+def frag_pack_f16x3_w8(W: np.ndarray, n0: int, k0: int) -> np.ndarray:
+    """256x256 sub-matrix -> split-precision B fragments for the 64-row / 8-wave flat-row blocks (csrc/ffn_block_f16x3.hip): wave w owns
+    the 32 output columns 32 w .. 32 w + 31.  w' = 2^8 w = hi + lo (both f16), order [8 wave][16 kc][2 hi/lo][64 lane][8] with
+    value = w'[n0 + 32w + (lane&31)][k0 + 16kc + 8(lane>>5) + i]; returned as a float32 container (65536)."""
+    sub = np.ascontiguousarray(W[n0:n0 + 256, k0:k0 + 256], dtype=np.float32) * np.float32(F16X3_WEIGHT_SCALE)
+    if np.abs(sub).max() >= 60000.0:
+        raise ValueError("weights too large for the split-f16 path (|w| >= 234)")
+    hi = sub.astype(np.float16)
+    lo = (sub - hi.astype(np.float32)).astype(np.float16)
+
+    def lay(a):   # [n = (w, l31)][k = (kc, kh, i)] -> [w][kc][kh][l31][i]
+        return a.reshape(8, 32, 16, 2, 8).transpose(0, 2, 3, 1, 4)
+    both = np.stack([lay(hi), lay(lo)], axis=2)           # [w][kc][hl][kh][l31][i]
     return np.ascontiguousarray(both).reshape(-1).view(np.float32)
 
 
@@ -391,16 +414,19 @@ def pack_blob(cpc_sd: Dict[str, np.ndarray], vap_sd: Dict[str, np.ndarray], mode
                                A(vap_sd[f"{src}.mha.value.weight"])], axis=0)
         put(f"{p}.wqkvf", np.concatenate([frag_pack(wqkv, c * 256, 0) for c in range(3)]))
         put(f"{p}.wprojf", frag_pack(A(vap_sd[f"{src}.mha.proj.weight"]), 0, 0))
-        put(f"{p}.w0h", np.concatenate([frag_pack_f16x3(w0, c * 256, 0) for c in range(3)]))
-        put(f"{p}.w3h", np.concatenate([frag_pack_f16x3(w3, 0, c * 256) for c in range(3)]))
-        put(f"{p}.wqkvh", np.concatenate([frag_pack_f16x3(wqkv, c * 256, 0) for c in range(3)]))
+        put(f"{p}.w0h", np.concatenate([frag_pack_f16x3_w8(w0, c * 256, 0) for c in range(3)]))
+        put(f"{p}.w3h", np.concatenate([frag_pack_f16x3_w8(w3, 0, c * 256) for c in range(3)]))
+        put(f"{p}.wqkvh", np.concatenate([frag_pack_f16x3_w8(wqkv, c * 256, 0) for c in range(3)]))
         put(f"{p}.wprojh", frag_pack_f16x3(A(vap_sd[f"{src}.mha.proj.weight"]), 0, 0))
+        put(f"{p}.wproj8", frag_pack_f16x3_w8(A(vap_sd[f"{src}.mha.proj.weight"]), 0, 0))
         if l > 0:
             wkvx = np.concatenate([A(vap_sd[f"{src}.mha_cross.key.weight"]), A(vap_sd[f"{src}.mha_cross.value.weight"])], axis=0)
             put(f"{p}.wkvxf", np.concatenate([frag_pack(wkvx, c * 256, 0) for c in range(2)]))
-            put(f"{p}.wkvxh", np.concatenate([frag_pack_f16x3(wkvx, c * 256, 0) for c in range(2)]))
+            put(f"{p}.wkvxh", np.concatenate([frag_pack_f16x3_w8(wkvx, c * 256, 0) for c in range(2)]))
             put(f"{p}.wqxh", frag_pack_f16x3(A(vap_sd[f"{src}.mha_cross.query.weight"]), 0, 0))
             put(f"{p}.wprojxh", frag_pack_f16x3(A(vap_sd[f"{src}.mha_cross.proj.weight"]), 0, 0))
+            put(f"{p}.wqx8", frag_pack_f16x3_w8(A(vap_sd[f"{src}.mha_cross.query.weight"]), 0, 0))
+            put(f"{p}.wprojx8", frag_pack_f16x3_w8(A(vap_sd[f"{src}.mha_cross.proj.weight"]), 0, 0))
             put(f"{p}.wqxf", frag_pack(A(vap_sd[f"{src}.mha_cross.query.weight"]), 0, 0))
             put(f"{p}.wprojxf", frag_pack(A(vap_sd[f"{src}.mha_cross.proj.weight"]), 0, 0))
     s3 = "ar.layers.2"
