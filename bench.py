@@ -379,6 +379,7 @@ def run_workload(name, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=0, split
         wl.eng.join(wl.stream)
     barrier()
     dt = time.perf_counter() - t0
+
     dom_ms, dom_launches = wl.profile_read()[dominant]
     wl.profile_enable([])
     dt = dist_util.max_over_ranks(dist, dt, "cuda")

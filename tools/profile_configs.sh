@@ -18,12 +18,21 @@ rocprofv3 --kernel-trace --stats -f csv -d $RAW/stats -o run -- $BENCH > $OUT/st
 cp $(find $RAW/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
 rm -rf $RAW/stats
 pass() {  # name, counters...
+  # Under --pmc every profiled dispatch is serialised: profiling all 251 window-fill ticks of C3 at 4096 streams takes half an hour per
+  # pass.  For c3 only steady-state dispatches are profiled (--kernel-iteration-range): the window-dependent attention kernel at its last
+  # 26 launches (ticks 254-259, window full), everything else (window-independent work per launch) at launches 250-259 of each kernel.
   local name=$1; shift
-  rocprofv3 --pmc "$@" -f csv -d $RAW/$name -o run -- $BENCH > $OUT/$name.log 2>&1
-  local csv=$(find $RAW/$name -name "*counter_collection.csv" | head -1)
-  if [ -n "$csv" ]; then python $REPO/tools/pmc_summary.py $csv kernel > $OUT/$name.txt; else echo "no counter csv" > $OUT/$name.txt; fi
+  : > $OUT/$name.txt
+  if [ "$WL" = "c3" ]; then
+    rocprofv3 --pmc "$@" --kernel-exclude-regex attention_long2 --kernel-iteration-range "[250-259]" -f csv -d $RAW/${name}_a -o run -- $BENCH > $OUT/$name.log 2>&1
+    rocprofv3 --pmc "$@" --kernel-include-regex attention_long2 --kernel-iteration-range "[1270-1295]" -f csv -d $RAW/${name}_b -o run -- $BENCH >> $OUT/$name.log 2>&1
+  else
+    rocprofv3 --pmc "$@" -f csv -d $RAW/${name}_a -o run -- $BENCH > $OUT/$name.log 2>&1
+  fi
+  for csv in $(find $RAW/${name}_a $RAW/${name}_b -name "*counter_collection.csv" 2>/dev/null); do python $REPO/tools/pmc_summary.py $csv kernel >> $OUT/$name.txt; done
+  [ -s $OUT/$name.txt ] || echo "no counter csv" > $OUT/$name.txt
   tail -3 $OUT/$name.log > $OUT/$name.log.tail; rm -f $OUT/$name.log
-  rm -rf $RAW/$name
+  rm -rf $RAW/${name}_a $RAW/${name}_b
 }
 pass pmc_sq SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE
 pass pmc_mops SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVES

@@ -15,8 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 wls = sys.argv[2:] or ["c2", "s4096_20hz", "c3", "c5"]
 KEY = {"c2": "256x20hz_T50", "s4096_20hz": "4096x20hz_T50", "c3": "4096x50hz_T250", "c5": "4096x20hz_T50_bc+nod"}
-CLASS = [("ffn_block_kernel", "ffn_block"), ("attn_block_kernel", "attention"), ("attention_long_kernel", "attention"),
-         ("attention_mfma_kernel", "attention"), ("conv_tail_kernel", "conv_tail"), ("lstm_kernel", "lstm"), ("last_block_kernel", "last_row"),
+CLASS = [("ffn_block_kernel", "ffn_block"), ("ffn_block_f16x3_kernel", "ffn_block"), ("attn_block_kernel", "attention"),
+         ("attention_long2_kernel", "attention"), ("conv_tail_kernel", "conv_tail"), ("lstm_kernel", "lstm"), ("last_block_kernel", "last_row"),
          ("head_kernel", "head"), ("conv0_kernel", "conv0"), ("gather_ln_kernel", "gather_ln"), ("gemm_f32_kernel<2, 2, 4", "gemm_cn_relu"),
          ("gemm_f32_kernel<4, 1, 4", "gemm_cn_relu")]
 ours = lambda name: ("kernel" in name and "at::" not in name and "rocclr" not in name)
@@ -42,6 +42,9 @@ traffic["_how_r02"] = ("r02 entries: tools/profile_configs.sh (rocprofv3 --pmc F
                        "`bench.py --workload <w> --configs= --steps 4`), means per dispatch by tools/pmc_summary.py; KiB units; "
                        "bytes_per_launch_corrected = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per MI355X_MICROARCH.md (gfx950 tallies 128-B "
                        "read requests at 64 B).")
+traffic["_how_r03"] = ("r03 entries (c2, s4096_20hz, c3, c5 re-measured on the round-3 kernels; C3 at its full 4096 streams, not scaled from 512): same recipe as "
+                       "_how_r02; the class entry of a workload (\"ffn_block\", \"attention\", ...) is the first kernel of that class in name order, i.e. "
+                       "ffn_block_kernel<1, 1> for C3.")
 for wl in wls:
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{wl}")
     if not os.path.isdir(src):
