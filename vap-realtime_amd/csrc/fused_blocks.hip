@@ -34,7 +34,6 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
   constexpr int BM = 32 * MT;
   float* sX = lds;                 // [BM][260] LN_ffn(x) tile (A operand of FFN1)
   float* sH = lds + BM * LDH;      // [BM][260] gelu chunk / raw x / LN_self(x)
-  float* red = sH + BM * LDH;      // [4][BM] row partials
   const int tid = threadIdx.x, lane = tid & 63;
   // wave index as an SGPR: weight-fragment addresses become scalar base + lane offset (SALU pointer
   // bumps, saddr loads) instead of per-lane 64-bit VALU adds — measured 2.8 -> ~1.6 VALU per MFMA
@@ -162,70 +161,50 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
         }
       }
   };
-  auto to_sH = [&](const f32x16(&acc)[MT][2]) {
+
+  auto to_lds = [&](const f32x16(&acc)[MT][2], float* buf) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int lr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        sH[lr * LDH + ccol] = acc[mt][0][r];
-        sH[lr * LDH + ccol + 32] = acc[mt][1][r];
+        buf[lr * LDH + ccol] = acc[mt][0][r];
+        buf[lr * LDH + ccol + 32] = acc[mt][1][r];
       }
   };
-
-  // LayerNorm over the 256 columns of the tile rows held in accumulator layout (two-pass, partials across the 4 waves via
-  // `red`) -> dst (LDS, [BM][260]) and optionally to global rows
-  auto ln_rows = [&](const f32x16(&v)[MT][2], const float* gam, const float* bet, float* dst, float* gout) {
-    float s[MT][16], mean[MT][16];
+  auto to_sH = [&](const f32x16(&acc)[MT][2]) { to_lds(acc, sH); };
+  // LayerNorm of the tile rows, ROW-PER-WAVE and in place on the fp32 tile in the LDS buffer `buf`: wave w owns rows w, w + 4, ..; a lane
+  // holds 4 columns of a whole row, so mean and variance (two-pass) are wave reductions — no cross-wave partial sums through `red`, one
+  // barrier pair instead of four, 16-byte LDS accesses, and the optional global copy leaves as 1 KiB-contiguous rows.  `parked`: the rows
+  // are in `buf` already (the raw x_out tile the cross K,V contractions just read); otherwise the accumulator tile `v` is parked there first.
+  // (Round 2 normalised in accumulator layout: 3.1 us of a 99 us tile alone, and the longest barrier chain of the block.)
+  auto ln_rows = [&](const f32x16(&v)[MT][2], bool parked, float* buf, const float* gam, const float* bet, float* gout) {
+    __syncthreads();          // every wave is done reading `buf` in the previous contraction
+    if (!parked) {
+      to_lds(v, buf);
+      __syncthreads();
+    }
+    const f32x4 lg = *(const f32x4*)(gam + lane * 4), lb = *(const f32x4*)(bet + lane * 4);
+    f32x4 x[BM / 4];
+    float sm[BM / 4];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int k = 0; k < BM / 4; ++k) x[k] = *(const f32x4*)&buf[(w + 4 * k) * LDH + lane * 4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[mt][r] = half_sum(v[mt][0][r] + v[mt][1][r]);
-    __syncthreads();          // also: every wave is done reading dst / red from the previous phase
-    if (l31 == 0)
+    for (int k = 0; k < BM / 4; ++k) sm[k] = wave_sum(x[k][0] + x[k][1] + x[k][2] + x[k][3]);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+    for (int k = 0; k < BM / 4; ++k) {
+      x[k] = x[k] - sm[k] * (1.0f / 256.0f);
+      sm[k] = x[k][0] * x[k][0] + x[k][1] * x[k][1] + x[k][2] * x[k][2] + x[k][3] * x[k][3];
+    }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[w * BM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = s[mt][r];
-    __syncthreads();
+    for (int k = 0; k < BM / 4; ++k) sm[k] = wave_sum(sm[k]);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int lr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        mean[mt][r] = (red[lr] + red[BM + lr] + red[2 * BM + lr] + red[3 * BM + lr]) * (1.0f / 256.0f);
-      }
-    __syncthreads();
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float d0 = v[mt][0][r] - mean[mt][r], d1 = v[mt][1][r] - mean[mt][r];
-        s[mt][r] = half_sum(d0 * d0 + d1 * d1);
-      }
-    if (l31 == 0)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[w * BM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = s[mt][r];
-    __syncthreads();
-    const float g0 = gam[ccol], g1 = gam[ccol + 32], b0 = bet[ccol], b1 = bet[ccol + 32];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int lr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        float var = (red[lr] + red[BM + lr] + red[2 * BM + lr] + red[3 * BM + lr]) * (1.0f / 256.0f);
-        float rstd = rsqrtf(var + 1e-5f);
-        const float y0 = (v[mt][0][r] - mean[mt][r]) * rstd * g0 + b0;
-        const float y1 = (v[mt][1][r] - mean[mt][r]) * rstd * g1 + b1;
-        dst[lr * LDH + ccol] = y0;
-        dst[lr * LDH + ccol + 32] = y1;
-        if (gout && m0 + lr < g.M) {
-          gout[(long)(m0 + lr) * 256 + ccol] = y0;
-          gout[(long)(m0 + lr) * 256 + ccol + 32] = y1;
-        }
-      }
+    for (int k = 0; k < BM / 4; ++k) {
+      const f32x4 y = x[k] * __builtin_amdgcn_rsqf(sm[k] * (1.0f / 256.0f) + 1e-5f) * lg + lb;   // (argument >= 1e-5: never denormal)
+      const int row = w + 4 * k;
+      *(f32x4*)&buf[row * LDH + lane * 4] = y;
+      if (gout && m0 + row < g.M) *(f32x4*)(gout + (long)(m0 + row) * 256 + lane * 4) = y;
+    }
     __syncthreads();
   };
   auto add_rows = [&](f32x16(&v)[MT][2], const float* src) {   // v += src tile (global [M][256] rows)
@@ -267,7 +246,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
     } else
     add_rows(out, g.resid);
     store_global(out, g.xmid_out, 256, 0);
-    if constexpr (MODE == 1) ln_rows(out, g.lnf_g, g.lnf_b, sX, nullptr);   // A operand of FFN1
+    if constexpr (MODE == 1) ln_rows(out, false, sX, g.lnf_g, g.lnf_b, nullptr);   // A operand of FFN1
   }
   if constexpr (MODE != 2) {
   // ---- feed-forward: x = xmid + gelu(xn W0^T) W3^T, hidden processed in 3 chunks of 256 ----
@@ -316,7 +295,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
   }   // MODE != 2
   // ---- next layer's self Q,K,V from LayerNorm(x) (or just the normalised rows) ----
   if (nq || g.xn_out) {
-    ln_rows(out, g.ln_g, g.ln_b, sH, g.xn_out);
+    ln_rows(out, MODE != 2 && g.wkvxf != nullptr, sH, g.ln_g, g.ln_b, g.xn_out);   // (after the cross K,V contractions the raw rows sit in sH already)
     STAMP();   // 21: LN_self rows in LDS
     for (int nc = 0; nc < nq; ++nc) {
       f32x16 acc[MT][2];
@@ -995,7 +974,7 @@ hipError_t launch_ffn_block(const FfnArgs& a, hipStream_t st) {
   attr_set.run([] {
     (void)hipFuncSetAttribute((const void*)ffn_block_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  const size_t lds = (size_t)(2 * 32 * LDH + 4 * 32) * sizeof(float);
+  const size_t lds = (size_t)(2 * 32 * LDH) * sizeof(float);
   if (a.mode == 1 || a.mode == 2) {
     static PerDeviceOnce attr2;
     attr2.run([] {
