@@ -15,6 +15,9 @@ if SPLIT:       # ffn_block_f16x3_kernel<0>: coarser stamps (VAPX_FLAG_SPLIT_F16
     NAMES = ["entry", "tile staged+LN+split", "ffn1.0 mm", "gelu+split->LDS.0", "ffn2.0 mm", "ffn1.1 mm", "gelu+split->LDS.1", "ffn2.1 mm",
              "ffn1.2 mm", "gelu+split->LDS.2", "ffn2.2 mm", "resid + x_out store", "row stats", "kvx0 mm+store", "kvx1 mm+store",
              "LN->LDS + q mm+store", "k mm+store", "v mm+store"]
+    # the debug build carries four extra stamps inside chunk 1's GELU phase and one between kvx1's contraction and its stores
+    NAMES = (NAMES[:6] + ["gelu.1 VALU", "gelu.1 barrier (sH free)", "gelu.1 split + LDS stores", "gelu.1 barrier (sH ready)"] + NAMES[7:14]
+             + ["kvx1 mm", "kvx1 scale + stores issued"] + NAMES[15:])
 NST = len(NAMES)
 t = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 32).astype(np.int64)
 tick_ns = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0

@@ -44,12 +44,6 @@ constexpr float kWScaleInv = 1.0f / 256.0f;   // weights are packed as 2^8 w
 
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void split_store(_Float16* hi, _Float16* lo, int idx, float v) {
-  const _Float16 h = (_Float16)v;
-  hi[idx] = h;
-  lo[idx] = (_Float16)(v - (float)h);
-}
-
 // MODE as FfnArgs::mode (0: xmid from global; 1: attention-output projection + the whole block; 2: projection + LN + wqkvf chunks only)
 template <int MODE>
 __global__ __launch_bounds__(512, 1) void ffn_block_f16x3_kernel(const FfnArgs g) {
@@ -73,8 +67,10 @@ __global__ __launch_bounds__(512, 1) void ffn_block_f16x3_kernel(const FfnArgs g
   };
   STAMP();
   if (g.trace && tid == 0) g.trace[(long)blockIdx.x * 32 + 28] = __builtin_amdgcn_s_memrealtime();
+  auto FINE = [&]() { __builtin_amdgcn_sched_barrier(0); STAMP(); __builtin_amdgcn_sched_barrier(0); };   // (tools/ffn_trace.py --split --fine)
 #else
   auto STAMP = [] {};
+  auto FINE = [] {};
 #endif
 
   // weight fragments of this wave's 32 columns: ring of 8 k-chunks (hi, lo) ahead, running on into the next unit
@@ -132,7 +128,9 @@ __global__ __launch_bounds__(512, 1) void ffn_block_f16x3_kernel(const FfnArgs g
   __syncthreads();
   STAMP();   // 1: tile staged
 
-  // acc[rt] += A[rows 32 rt ..][256 k] (LDS hi / lo) . W^T for this wave's 32 columns
+  // acc[rt] += (A[rows 32 rt ..][256 k] (LDS hi / lo) . W^T for this wave's 32 columns)^T: the WEIGHT fragment is the MFMA's A operand
+  // and the activation rows its B operand (the two operand layouts are the same), so a lane ends up with ONE ROW and 4 x 4 consecutive
+  // columns of it — every epilogue below moves 16 bytes per instruction and needs one row index per lane instead of sixteen
   auto mm = [&](f32x16(&acc)[2], const _Float16* Ah, const _Float16* Al, const float* wfrag, const float* next_wfrag) {
     const _Float16* pah = Ah + l31 * LD16 + hi * 8;
     const _Float16* pal = Al + l31 * LD16 + hi * 8;
@@ -152,12 +150,12 @@ __global__ __launch_bounds__(512, 1) void ffn_block_f16x3_kernel(const FfnArgs g
         n0h = *(const f16x8*)(pah + kn); n0l = *(const f16x8*)(pal + kn);
         n1h = *(const f16x8*)(pah + 32 * LD16 + kn); n1l = *(const f16x8*)(pal + 32 * LD16 + kn);
         const f16x8 bh = __builtin_bit_cast(f16x8, ring[k8 * 2]), bl = __builtin_bit_cast(f16x8, ring[k8 * 2 + 1]);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bh, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, bh, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, bh, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bl, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bl, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, a0h, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, a1h, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, a0l, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, a1l, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, a0h, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, a1h, acc[1], 0, 0, 0);
         ring[k8 * 2] = nx[(k8 * 2) * 64 + lane];
         ring[k8 * 2 + 1] = nx[(k8 * 2 + 1) * 64 + lane];
         // one memory instruction between two MFMAs (4 LDS reads, 2 weight loads per 6 MFMAs)
@@ -176,30 +174,27 @@ __global__ __launch_bounds__(512, 1) void ffn_block_f16x3_kernel(const FfnArgs g
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
   };
-  // accumulator (rt, r) <-> tile row lr = 32 rt + (r&3) + 8 (r>>2) + 4 hi, chunk column 32 w + l31
-  const int ccol = w * 32 + l31;
-  // (row index = compile-time constant C + 4 hi: every phase derives its addresses from ONE fresh per-lane base — opaque_vgpr — plus
-  // constants, so no table of 32 row indices stays live across the phases; without it hipcc spills up to 188 registers here)
+  // accumulator (rt, r) <-> tile row 32 rt + l31, chunk column 32 w + 8 (r >> 2) + 4 hi + (r & 3)
+  const int ccol = w * 32 + 4 * hi;
+  auto quad = [](const f32x16& a, int j) { return f32x4{a[4 * j], a[4 * j + 1], a[4 * j + 2], a[4 * j + 3]}; };
   auto store_global = [&](const f32x16(&acc)[2], float* base, int ld, int col0) {
-    const int h4 = opaque_vgpr(4 * hi);
-    float* bu = base + (long)m0 * ld + col0;                  // workgroup-uniform
-    const unsigned o0 = (unsigned)(h4 * ld + ccol);
-    const int lim = g.M - m0 - h4;                            // row C is inside the matrix iff C < lim
+    float* bu = base + (long)m0 * ld + col0 + ccol;          // (+ per-lane column: 4 hi)
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < 2; ++rt) {
+      const int lr = rt * 32 + l31;
+      if (m0 + lr < g.M) {
+        float* p = bu + (unsigned)(lr * ld);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int c = rt * 32 + (r & 3) + 8 * (r >> 2);
-        if (c < lim) bu[o0 + (unsigned)(c * ld)] = acc[rt][r];
+        for (int j = 0; j < 4; ++j) *(f32x4*)(p + 8 * j) = quad(acc[rt], j);
       }
+    }
   };
   // accumulator tile -> fp32 rows in the sH bytes (row-per-wave statistics follow); callers fence sH before and after
   auto park = [&](const f32x16(&acc)[2]) {
-    float* p = sHf + opaque_vgpr(4 * hi) * LD16 + ccol;
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) p[(rt * 32 + (r & 3) + 8 * (r >> 2)) * LD16] = acc[rt][r];
+      for (int j = 0; j < 4; ++j) *(f32x4*)&sHf[(rt * 32 + l31) * LD16 + ccol + 8 * j] = quad(acc[rt], j);
   };
   // rows w, w + 8, .. of the parked tile: mean, variance (two-pass) and max |x| of each, the rows themselves in registers
   auto parked_stats = [&](f32x4 (&x)[BM / 8], float (&mean)[BM / 8], float (&var)[BM / 8], float (&amax)[BM / 8]) {
@@ -226,27 +221,30 @@ __global__ __launch_bounds__(512, 1) void ffn_block_f16x3_kernel(const FfnArgs g
     // ---- attention output projection + residual: xmid = resid + att . Wproj^T (the separate GEMM of the long-window path) ----
     zero(out);
     mm(out, sHh, sHl, g.wprojf, MODE == 1 ? g.w0f : after_ffn);
-    const int h4p = opaque_vgpr(4 * hi);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int lr = rt * 32 + (r & 3) + 8 * (r >> 2) + h4p;
-        int m = m0 + lr;
-        m = m < g.M ? m : g.M - 1;
-        const float* rp;
-        if (MODE == 1 && g.resid_rot) {   // layer 0: residual rows straight from the embedding ring
-          const int T = g.resid_T;
-          const int bc = m / T, i = m - bc * T, b = bc >> 1;
-          const long slab = (long)(g.resid_ids ? g.resid_ids[b] : b) * 2 + (bc & 1);
-          int rr = i + g.resid_rot[b];
-          rr = rr >= T ? rr - T : rr;
-          rp = g.resid + (slab * T + rr) * 256 + ccol;
-        } else {
-          rp = g.resid + (long)m * 256 + ccol;
-        }
-        out[rt][r] = out[rt][r] * (rinv[lr] * kWScaleInv) + rp[0];     // undo the row scale of the staged attention row and the weights' 2^8
+    for (int rt = 0; rt < 2; ++rt) {
+      const int lr = rt * 32 + l31;
+      int m = m0 + lr;
+      m = m < g.M ? m : g.M - 1;
+      const float* rp;
+      if (MODE == 1 && g.resid_rot) {   // layer 0: residual rows straight from the embedding ring
+        const int T = g.resid_T;
+        const int bc = m / T, i = m - bc * T, b = bc >> 1;
+        const long slab = (long)(g.resid_ids ? g.resid_ids[b] : b) * 2 + (bc & 1);
+        int rr = i + g.resid_rot[b];
+        rr = rr >= T ? rr - T : rr;
+        rp = g.resid + (slab * T + rr) * 256 + ccol;
+      } else {
+        rp = g.resid + (long)m * 256 + ccol;
       }
+      const float sc = rinv[lr] * kWScaleInv;     // undo the row scale of the staged attention row and the weights' 2^8
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 rs = *(const f32x4*)(rp + 8 * j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[rt][4 * j + e] = out[rt][4 * j + e] * sc + rs[e];
+      }
+    }
     store_global(out, g.xmid_out, 256, 0);
     STAMP();   // 2: projection + residual
     if constexpr (MODE == 1) {   // A operand of FFN1 = LayerNorm(xmid; ln_ffn): parked in sH (the attention rows are consumed), normalised into sX
@@ -276,14 +274,20 @@ __global__ __launch_bounds__(512, 1) void ffn_block_f16x3_kernel(const FfnArgs g
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) hacc[rt][r] = gelu_fast(hacc[rt][r] * kWScaleInv) * hs;
+      if (c == 1) FINE();       // gelu VALU done
       __syncthreads();          // every wave is done reading the previous chunk (or the parked tile) from sH
-      {
-        const int b0 = opaque_vgpr(4 * hi) * LD16 + ccol;
+      if (c == 1) FINE();       // barrier passed
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+      for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) split_store(sHh, sHl, b0 + (rt * 32 + (r & 3) + 8 * (r >> 2)) * LD16, hacc[rt][r]);
-      }
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 y = quad(hacc[rt], j);
+          const h16x4 hh = __builtin_convertvector(y, h16x4);
+          const h16x4 ll = __builtin_convertvector(y - __builtin_convertvector(hh, f32x4), h16x4);
+          *(h16x4*)&sHh[(rt * 32 + l31) * LD16 + ccol + 8 * j] = hh;
+          *(h16x4*)&sHl[(rt * 32 + l31) * LD16 + ccol + 8 * j] = ll;
+        }
+      if (c == 1) FINE();       // split + LDS stores issued
       __syncthreads();
       STAMP();   // gelu + split + h -> LDS
       mm(out, sHh, sHl, g.w3f + (long)c * 65536, c < 2 ? g.w0f + (long)(c + 1) * 65536 : after_ffn);
@@ -291,18 +295,19 @@ __global__ __launch_bounds__(512, 1) void ffn_block_f16x3_kernel(const FfnArgs g
     }
     {
       const float inv = kWScaleInv * __builtin_amdgcn_rcpf(hs);
-      const float* xm = (MODE == 0 ? g.xmid : g.xmid_out) + (long)m0 * 256;   // (mode 1: this lane's own xmid elements, written above)
-      const int h4 = opaque_vgpr(4 * hi);
-      const int last = g.M - 1 - m0 - h4;                      // rows beyond the matrix re-read its last row (their results are not stored)
-      const unsigned o0 = (unsigned)(h4 * 256 + ccol);
+      const float* xm = (MODE == 0 ? g.xmid : g.xmid_out) + ccol;   // (mode 1: this lane's own xmid elements, written above)
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
+      for (int rt = 0; rt < 2; ++rt) {
+        int m = m0 + rt * 32 + l31;
+        m = m < g.M ? m : g.M - 1;                               // rows beyond the matrix re-read its last row (their results are not stored)
+        const float* rp = xm + (long)m * 256;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int c = rt * 32 + (r & 3) + 8 * (r >> 2);
-          c = c < last ? c : last;
-          out[rt][r] = out[rt][r] * inv + xm[o0 + (unsigned)(c * 256)];
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 rs = *(const f32x4*)(rp + 8 * j);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) out[rt][4 * j + e] = out[rt][4 * j + e] * inv + rs[e];
         }
+      }
     }
     store_global(out, g.xout, 256, 0);
     STAMP();   // residual + x_out store
@@ -330,11 +335,13 @@ __global__ __launch_bounds__(512, 1) void ffn_block_f16x3_kernel(const FfnArgs g
         f32x16 acc[2];
         zero(acc);
         mm(acc, sHh, sHl, g.wkvxf + (long)nc * 65536, nc == 0 ? g.wkvxf + 65536 : (nq ? g.wqkvf : nullptr));
-        const float* ri = rinv + opaque_vgpr(4 * hi);
+        if (nc == 1) FINE();    // kvx1 mm done (stores follow)
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < 2; ++rt) {
+          const float sc = rinv[rt * 32 + l31] * kWScaleInv;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[rt][r] *= ri[rt * 32 + (r & 3) + 8 * (r >> 2)] * kWScaleInv;
+          for (int r = 0; r < 16; ++r) acc[rt][r] *= sc;
+        }
         store_global(acc, g.kvx, 512, nc * 256);
         STAMP();   // kvx mm + store
       }

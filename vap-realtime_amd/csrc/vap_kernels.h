@@ -63,6 +63,7 @@ struct AttnArgs {
   const int* ring_rot;  // [B] or null.  Non-null (long-window layer 0): q/k/v are the per-stream Q|K|V RINGS (slab = slot*2+channel,
                         // logical row i in ring slot (i + ring_rot[b]) % T) instead of chronological batch buffers
   const int* ids;       // [B] stream slots (null: identity); only used with ring_rot
+  int n_items;          // set by launch_attention_f16x3 (persistent kernel): B * 2 channels * 4 heads
 #ifdef VAPX_TRACE
   unsigned long long* trace;   // debug build: optional [grid][32] s_memtime stamps of workgroup phases (env VAPX_ATTN_TRACE, long windows)
 #endif
@@ -104,6 +105,7 @@ hipError_t launch_lstm(const LstmArgs& a, hipStream_t st);
 hipError_t launch_ring_append(const GatherArgs& a, hipStream_t st);
 hipError_t launch_gather_ln(const GatherArgs& a, hipStream_t st);
 hipError_t launch_attention(const AttnArgs& a, int B, hipStream_t st);
+hipError_t launch_attention_f16x3(const AttnArgs& a, int B, hipStream_t st);   // split-precision variant (attention_f16x3.hip), same arguments
 hipError_t launch_gather_last_ln(const LastRowArgs& a, hipStream_t st);
 hipError_t launch_ln_rows(const float* x, float* y, const float* gamma, const float* beta, int rows, hipStream_t st);
 hipError_t launch_attention_last(const AttnArgs& a, int B, hipStream_t st);
