@@ -10,21 +10,25 @@
 // built around those two:
 //   * K AND V are converted ONCE per (stream, channel, head) item and kept in LDS as MFMA-ready f16 (hi, lo) operands — K row-major
 //     [256 keys][64 features], V TRANSPOSED [64 features][256 key slots] because it is the A operand of O^T = V^T.P^T (lane = feature,
-//     8 keys per lane and k-chunk) — 141 KB, ONE workgroup per CU, eight waves = one 32-query tile each.  (A first version kept the fp32
+//     8 keys per lane and k-chunk) — 141 KB, ONE workgroup per CU, eight waves.  (A first version kept the fp32
 //     kernel's structure — K fragments from global per (query tile, key tile) pair, converted in registers, two workgroups per CU — and
 //     spent its time converting every K tile 4.5 times and waiting for first round trips: 14.1 ms per C3 tick against 17.4 fp32.)
 //   * the kernel is PERSISTENT (one workgroup per CU walks over its items) and the next item's raw K / V rows are in flight — 16 x 16 bytes
 //     per lane, in registers — while the current item computes: no workgroup ever waits for a cold first load except the very first.
-// Wave w takes query tile w (w < 4) or 11 - w: the two waves of a SIMD (w, w + 4) together own 9 causal key tiles, every SIMD the same.
+//   * the MFMA shape is v_mfma_f32_16x16x32_f16: SIXTEEN queries per tile, so the causal triangle splits evenly over the eight waves with
+//     no merging — wave w owns query tiles w and 15 - w, 9 (16 queries x 32 keys) units each, whatever w — and the two tiles of a wave walk
+//     the key tiles together: K and V fragments are fetched once for both, and two independent softmax / MFMA chains interleave.  (With
+//     32-query tiles and one tile per wave the wave with 8 key tiles was the critical path of the item: 11.9 ms per C3 tick.)
 //
 // No operand can overflow f16, whatever the input.  Q, K and V rows are raw projections (the cross-attention K / V of the RAW residual
 // stream), so every operand carries a power-of-two scale from its own maximum: K and V per item (one block reduction each, sharing the
 // barrier that hands the LDS over), Q per 32-query tile (wave-local); P is in [0, 1] and rides as 2^12 P so that its low half stays
 // clear of the f16 denormals.  All scales are undone in fp32 (the score scale inside the softmax's fma, the V and P scales in the final
-// 1 / l), exactly.  Inside each 16-key chunk the key slots of V^T are permuted so that the 8 keys a lane half needs (the keys whose
-// probabilities sit in its 8 accumulator registers of S^T: 16c + 4 hi + {0..3} and 16c + 8 + 4 hi + {0..3}) are one 16-byte read.
-// P never moves: accumulator registers 8c .. 8c+7 of S^T, converted, ARE the B operand of k-chunk c.
+// 1 / l), exactly.  Inside each 32-key tile the key slots of V^T are permuted so that the 8 keys a lane group g = lane >> 4 needs (the keys
+// whose probabilities sit in its 2 x 4 accumulator registers of S^T: 4 g + {0..3} and 16 + 4 g + {0..3}) are one 16-byte read.
+// P never moves: the two score accumulators of a lane, converted, ARE its B operand of O^T = V^T.P^T (one K = 32 MFMA per 16 features).
 #include <algorithm>
+#include <type_traits>
 
 #include "vap_kernels.h"
 
@@ -50,15 +54,14 @@ __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, float s
 __device__ __forceinline__ float max4abs(float mx, const f32x4& v) {
   return fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
 }
-// wave-uniform maximum without the LDS crossbar: four DPP steps make every 16-lane row uniform, v_readlane fetches the four rows
-__device__ __forceinline__ float wave_max_rows(float v) {
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));    // quad_perm [1,0,3,2]
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));    // quad_perm [2,3,0,1]
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));   // row_half_mirror
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));   // row_mirror
-  return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
+// p[idx] for a wave-uniform idx through the SCALAR cache.  Inside the persistent item loop hipcc reads the per-stream metadata (bn, ring_rot,
+// ids) with vector loads — global stores precede them, so it cannot prove the words unclobbered — and waits vmcnt(0) for each: three
+// dependent round trips per item that also sit out every store and prefetch in flight.
+__device__ __forceinline__ int uniform_load(const int* p, int idx) {
+  int v;
+  asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p), "s"(idx * 4) : "memory");
+  return v;
 }
-
 __global__ __launch_bounds__(512, 1) void attention_long_f16x3_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   _Float16* Kh = (_Float16*)lds_raw;          // [256][LDK] K hi
@@ -67,10 +70,10 @@ __global__ __launch_bounds__(512, 1) void attention_long_f16x3_kernel(AttnArgs a
   _Float16* Vl = Vh + 64 * LDV;               // [64][LDV] V^T lo
   float* sred = (float*)(Vl + 64 * LDV);      // [16] max |K|, max |V| per wave
   const int T = a.T;
-  const int n_tiles = (T + 31) >> 5;          // <= 8
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..7
-  const int it = w < 4 ? w : 11 - w;                          // this wave's query tile
+  // this wave's two 16-query tiles: slot 0 = tile w, slot 1 = tile 15 - w (the longer one: key tiles 0 .. (15 - w) / 2)
+  const int qt[2] = {w, 15 - w};
   const bool ringed = a.ring_rot != nullptr;
   const int dq = tid & 15;                                    // feature quad 4 dq .. 4 dq + 3 of the rows this thread stages
 
@@ -79,10 +82,10 @@ __global__ __launch_bounds__(512, 1) void attention_long_f16x3_kernel(AttnArgs a
   f32x4 kr[8], vr[8];
   auto issue_kv = [&](int item) {
     const int h = item & 3, bc = item >> 2, b = bc >> 1;
-    const int n = a.bn[b];
-    const int rot = ringed ? a.ring_rot[b] : 0;
+    const int n = uniform_load(a.bn, b);
+    const int rot = ringed ? uniform_load(a.ring_rot, b) : 0;
     const int kvbc = a.swap_kv ? (bc ^ 1) : bc;
-    const long slab_kv = ringed ? ((long)(a.ids ? a.ids[b] : b) * 2 + (bc & 1)) : (long)kvbc;
+    const long slab_kv = ringed ? ((long)(a.ids ? uniform_load(a.ids, b) : b) * 2 + (bc & 1)) : (long)kvbc;
     const float* kp = a.k + slab_kv * T * a.ldkv + h * 64 + dq * 4;     // item-uniform part + this thread's feature quad
     const float* vp = a.v + slab_kv * T * a.ldkv + h * 64 + dq * 4;
     auto row_off = [&](int j) {                                          // 32-bit offset of logical row j (clamped to the window)
@@ -99,21 +102,32 @@ __global__ __launch_bounds__(512, 1) void attention_long_f16x3_kernel(AttnArgs a
       for (int e = 0; e < 4; ++e) vr[u * 4 + e] = *(const f32x4*)(vp + row_off(4 * (u * 32 + (tid >> 4)) + e));
   };
 
+  // maxima of the rows in kr / vr -> sred (the power-of-two scales of the item they belong to).  Called at the END of the previous item's
+  // compute phase, BEFORE its output stores: vmcnt is one in-order counter, so a wait for these loads issued after the stores would also
+  // sit out the stores' acknowledgements (2.7 us per item when the wait was at the top of the loop)
+  auto take_maxima = [&]() {
+    float mk = 0.f, mv = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { mk = max4abs(mk, kr[u]); mv = max4abs(mv, vr[u]); }
+    mk = wave_max(mk);
+    mv = wave_max(mv);
+    if (lane == 0) { sred[w] = mk; sred[8 + w] = mv; }
+  };
   int item = (int)blockIdx.x;
-  if (item < a.n_items) issue_kv(item);
+  if (item < a.n_items) { issue_kv(item); take_maxima(); }
 #pragma unroll 1
   for (; item < a.n_items; item += (int)gridDim.x) {
     const int h = item & 3, bc = item >> 2, b = bc >> 1;
-    const int n = a.bn[b];
-    const int rot = ringed ? a.ring_rot[b] : 0;
-    const long slab_q = ringed ? ((long)(a.ids ? a.ids[b] : b) * 2 + (bc & 1)) : (long)bc;
+    const int n = uniform_load(a.bn, b);
+    const int rot = ringed ? uniform_load(a.ring_rot, b) : 0;
+    const long slab_q = ringed ? ((long)(a.ids ? uniform_load(a.ids, b) : b) * 2 + (bc & 1)) : (long)bc;
     const int nt_valid = (n + 31) >> 5;
-    const bool act = it < nt_valid;
+    const int n16 = (n + 15) >> 4;                       // 16-query tiles with valid rows
+    const bool act[2] = {qt[0] < n16, qt[1] < n16};
     const float slope = exp2f(-2.0f * (float)(h + 1));  // [1/4, 1/16, 1/64, 1/256]
     // (fresh per item: hipcc otherwise hoists every lane-constant table derived from these — key indices, ALiBi biases, mask bounds, LDS
     // addresses — out of the item loop and keeps them live, i.e. spilled, across it)
-    const int l31 = opaque_vgpr(lane & 31), hi = opaque_vgpr(lane >> 5);
-    const float hi4f = (float)(4 * hi);
+    const int r16 = opaque_vgpr(lane & 15), g = opaque_vgpr(lane >> 4);
 #ifdef VAPX_TRACE
     int stamp_k = 0;
     auto STAMP = [&]() {
@@ -122,31 +136,30 @@ __global__ __launch_bounds__(512, 1) void attention_long_f16x3_kernel(AttnArgs a
     };
     STAMP();   // 0: item start
     if (a.trace && tid == 0 && item < 16384) a.trace[(long)item * 32 + 28] = __builtin_amdgcn_s_memrealtime();
+    auto FINE = [&]() { __builtin_amdgcn_sched_barrier(0); STAMP(); __builtin_amdgcn_sched_barrier(0); };
 #else
     auto STAMP = [] {};
+    auto FINE = [] {};
 #endif
-    // this wave's query rows: raw fragments (row 32 it + l31 clamped; qraw[2c], qraw[2c+1] = features 16c + 8 hi .. + 7, the 8 k-values of this
-    // lane half in the 16-feature chunk c — the same 16 bytes of a row-major K row in LDS below) fly while K / V are converted
-    f32x4 qraw[8];
-    if (act) {
-      int i = it * 32 + l31;
-      i = i < n ? i : n - 1;
-      int r = i + rot;
-      r = r >= T ? r - T : r;
-      const float* qp = a.q + (slab_q * T + r) * a.ldq + h * 64 + hi * 8;
+    // this wave's query rows: raw fragments (row 16 t + r16 clamped; qraw[s][2c], [2c+1] = features 32 c + 8 g .. + 7, the 8 k-values of this lane
+    // in the 32-feature chunk c — the same 16 bytes of a row-major K row in LDS below) fly while K / V are converted
+    // (issued unconditionally — rows beyond the window are clamped anyway — so that hipcc can count them: behind a branch the wait for
+    // the K / V rows below becomes vmcnt(0) and sits out a fresh round trip of these eight loads, 2.7 us per item)
+    f32x4 qraw[2][4];
 #pragma unroll
-      for (int kc = 0; kc < 8; ++kc) qraw[kc] = *(const f32x4*)(qp + (kc >> 1) * 16 + (kc & 1) * 4);
-    }
-    // ---- item maxima -> power-of-two scales of K and V ----
-    {
-      float mk = 0.f, mv = 0.f;
+    for (int s = 0; s < 2; ++s)
+      {
+        int i = qt[s] * 16 + r16;
+        i = i < n ? i : n - 1;
+        int r = i + rot;
+        r = r >= T ? r - T : r;
+        const float* qp = a.q + (slab_q * T + r) * a.ldq + h * 64 + g * 8;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { mk = max4abs(mk, kr[u]); mv = max4abs(mv, vr[u]); }
-      mk = wave_max_rows(mk);
-      mv = wave_max_rows(mv);
-      if (lane == 0) { sred[w] = mk; sred[8 + w] = mv; }
-    }
-    __syncthreads();   // A: maxima visible; every wave is done with the previous item's K / V in LDS
+        for (int c = 0; c < 2; ++c) { qraw[s][2 * c] = *(const f32x4*)(qp + c * 32); qraw[s][2 * c + 1] = *(const f32x4*)(qp + c * 32 + 4); }
+      }
+    FINE();            // 1: Q loads issued
+    __syncthreads();   // A: maxima (taken at the end of the previous item) visible; every wave is done with the previous item's K / V in LDS
+    FINE();            // 2: barrier A passed
     float kinv, vinv;
     {
       float mk = sred[0], mv = sred[8];
@@ -171,7 +184,7 @@ __global__ __launch_bounds__(512, 1) void attention_long_f16x3_kernel(AttnArgs a
       for (int u = 0; u < 2; ++u) {
         const int G = u * 32 + (tid >> 4);                   // keys 4 G .. 4 G + 3
         if (4 * G < nt_valid * 32) {
-          const int slot = (G >> 2) * 16 + (G & 1) * 8 + ((G >> 1) & 1) * 4;   // chunk, lane half that consumes the group, first / second quad
+          const int slot = (G >> 3) * 32 + (G & 3) * 8 + ((G >> 2) & 1) * 4;   // key tile, lane group that consumes the quad, first / second accumulator
 #pragma unroll
           for (int dd = 0; dd < 4; ++dd) {
             f32x4 y;
@@ -185,138 +198,173 @@ __global__ __launch_bounds__(512, 1) void attention_long_f16x3_kernel(AttnArgs a
         }
       }
     }
+    FINE();            // 3: converted, LDS stores issued
     __syncthreads();   // B: K, V^T of this item in LDS
-    STAMP();   // 1: staged
-    if (item + (int)gridDim.x < a.n_items) issue_kv(item + (int)gridDim.x);   // the next item's rows fly under this item's MFMAs
-
-    if (act) {
-      f16x8 qh[4], ql[4];
-      float qinv;
-      {
-        float mx = 0.f;
+    STAMP();   // 4: staged
+    f16x8 qh[2][2], ql[2][2];
+    float qk[2];
+    float m[2] = {-1e30f, -1e30f}, lp[2] = {0.f, 0.f};          // running maximum, PER-LANE partial sum (its own 8 keys per tile)
+    f32x4 o[2][4];
+    if (act[0]) {   // (slot 1 holds the later rows: act[1] implies act[0])
 #pragma unroll
-        for (int kc = 0; kc < 8; ++kc) mx = max4abs(mx, qraw[kc]);
-        const float s = pow2_scale_for(wave_max_rows(mx));
+      for (int s = 0; s < 2; ++s)
+        if (act[s]) {
+          float mx = 0.f;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) split8(qraw[2 * c], qraw[2 * c + 1], s, qh[c], ql[c]);
-        qinv = __builtin_amdgcn_rcpf(s);
-      }
-      const float qk = 0.0625f * qinv * kinv;               // 1 / sqrt(256) x the inverse operand scales
-      float m = -1e30f, l = 0.f;
-      f32x16 o0, o1;
+          for (int k = 0; k < 4; ++k) mx = max4abs(mx, qraw[s][k]);
+          const float sq = pow2_scale_for(wave_max(mx));
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-      const int i = it * 32 + l31;
-#pragma unroll 1
-      for (int jt = 0; jt <= it; ++jt) {
-        // ---- S^T tile = K_tile . Q^T (x s_k s_q): 12 MFMAs into one accumulator ----
-        f32x16 sc;
+          for (int c = 0; c < 2; ++c) split8(qraw[s][2 * c], qraw[s][2 * c + 1], sq, qh[s][c], ql[s][c]);
+          qk[s] = 0.0625f * __builtin_amdgcn_rcpf(sq) * kinv;     // 1 / sqrt(256) x the inverse operand scales
+        }
+    }
+    FINE();            // 5: Q converted
+    // the next item's rows fly under this item's MFMAs (unconditional — the last item re-reads itself — so that hipcc can count the loads)
+    issue_kv(item + (int)gridDim.x < a.n_items ? item + (int)gridDim.x : item);
+    if (act[0]) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) o[s][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int jlast[2] = {qt[0] >> 1, qt[1] >> 1};              // last (diagonal) key tile of each slot
+      // one key tile for the slots S0 .. S1 - 1 ((0, 2): both query tiles, K / V fragments shared; (1, 2): only the longer one; (0, 1): only
+      // the earlier one — the window is still filling and tile 15 - w has no valid row yet)
+      auto step = [&](int jt, auto s0_tag, auto s1_tag) {
+        constexpr int S0 = decltype(s0_tag)::value, S1 = decltype(s1_tag)::value;
+        // ---- S^T = K_tile . Q^T (x s_k s_q): lane (query r16, group g) gets keys 4 g + r (first accumulator) and 16 + 4 g + r ----
+        f32x4 sc[2][2];
         {
-          const _Float16* kph = Kh + (jt * 32 + l31) * LDK + hi * 8;
-          const _Float16* kpl = Kl + (jt * 32 + l31) * LDK + hi * 8;
-          f16x8 kh[4], kl[4];
+          f16x8 kh[2][2], kl[2][2];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) { kh[c] = *(const f16x8*)(kph + c * 16); kl[c] = *(const f16x8*)(kpl + c * 16); }
+          for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[c], qh[c], sc, 0, 0, 0);
-            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[c], qh[c], sc, 0, 0, 0);
-            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[c], ql[c], sc, 0, 0, 0);
+            for (int c = 0; c < 2; ++c) {
+              kh[mt][c] = *(const f16x8*)(Kh + (jt * 32 + mt * 16 + r16) * LDK + c * 32 + g * 8);
+              kl[mt][c] = *(const f16x8*)(Kl + (jt * 32 + mt * 16 + r16) * LDK + c * 32 + g * 8);
+            }
+#pragma unroll
+          for (int s = S0; s < S1; ++s)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) sc[s][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int s = S0; s < S1; ++s)
+#pragma unroll
+              for (int mt = 0; mt < 2; ++mt) {
+                sc[s][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[mt][c], qh[s][c], sc[s][mt], 0, 0, 0);
+                sc[s][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[mt][c], qh[s][c], sc[s][mt], 0, 0, 0);
+                sc[s][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[mt][c], ql[s][c], sc[s][mt], 0, 0, 0);
+              }
+        }
+        // ---- online softmax (as attention_long2_kernel), masked only on the diagonal tile of a slot and the tile with the window end ----
+        f16x8 ph[2], pl[2];
+        const float jb = (float)(jt * 32 + 4 * g);
+#pragma unroll
+        for (int s = S0; s < S1; ++s) {
+          float cm = -1e30f;
+          const bool masked = jt == jlast[s] || (jt + 1) * 32 > n;
+          if (masked) {
+            const int i4 = qt[s] * 16 + r16 - jt * 32 - 4 * g, n4 = n - jt * 32 - 4 * g;     // key C + 4 g is visible iff C <= i4 and C < n4
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int c = mt * 16 + r;
+                float v = fmaf(sc[s][mt][r], qk[s], slope * ((float)c + jb));
+                v = ((c <= i4) && (c < n4)) ? v : -1e30f;
+                sc[s][mt][r] = v;
+                cm = fmaxf(cm, v);
+              }
+          } else {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float v = fmaf(sc[s][mt][r], qk[s], slope * ((float)(mt * 16 + r) + jb));
+                sc[s][mt][r] = v;
+                cm = fmaxf(cm, v);
+              }
+          }
+          cm = fmaxf(cm, __shfl_xor(cm, 16));
+          cm = fmaxf(cm, __shfl_xor(cm, 32));
+          const float mn = fmaxf(m[s], cm);
+          const float alpha = __expf(m[s] - mn);
+          float sum = 0.f;
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float pv = __expf(sc[s][mt][r] - mn);
+              if (masked) pv = sc[s][mt][r] > -1e29f ? pv : 0.f;
+              sc[s][mt][r] = pv;
+              sum += pv;
+            }
+          lp[s] = lp[s] * alpha + sum;
+          m[s] = mn;
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) o[s][mt] *= alpha;
+          split8(sc[s][0], sc[s][1], kPScale, ph[s], pl[s]);
+        }
+        // ---- O^T = alpha O^T + V_tile^T . P^T   (x s_v 2^12): lane (query r16, group g) gets features 16 mt + 4 g + r ----
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const f16x8 vh = *(const f16x8*)(Vh + (mt * 16 + r16) * LDV + jt * 32 + g * 8);
+          const f16x8 vl = *(const f16x8*)(Vl + (mt * 16 + r16) * LDV + jt * 32 + g * 8);
+#pragma unroll
+          for (int s = S0; s < S1; ++s) {
+            o[s][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[s], o[s][mt], 0, 0, 0);
+            o[s][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[s], o[s][mt], 0, 0, 0);
+            o[s][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[s], o[s][mt], 0, 0, 0);
           }
         }
-        // ---- online softmax update for this 32-key tile (as attention_long2_kernel): sc := P.  accumulator r <-> key
-        //      j = 32 jt + C_r + 4 hi with C_r = (r&3) + 8 (r>>2).  MASKED only for the diagonal tile (causal) and the tile with the window end ----
-        float cm = -1e30f;
-        const float jb = (float)(jt * 32) + hi4f;
-        const bool masked = jt == it || (jt + 1) * 32 > n;
-        if (masked) {
-          const int i4 = i - jt * 32 - 4 * hi, n4 = n - jt * 32 - 4 * hi;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int c = (r & 3) + 8 * (r >> 2);
-            float v = fmaf(sc[r], qk, slope * ((float)c + jb));
-            v = ((c <= i4) && (c < n4)) ? v : -1e30f;
-            sc[r] = v;
-            cm = fmaxf(cm, v);
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int c = (r & 3) + 8 * (r >> 2);
-            const float v = fmaf(sc[r], qk, slope * ((float)c + jb));
-            sc[r] = v;
-            cm = fmaxf(cm, v);
-          }
-        }
-        cm = fmaxf(cm, __shfl_xor(cm, 32));
-        const float mn = fmaxf(m, cm);
-        const float alpha = __expf(m - mn);
-        float sum = 0.f;
-        if (masked) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float p = sc[r] > -1e29f ? __expf(sc[r] - mn) : 0.f;
-            sc[r] = p;
-            sum += p;
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float p = __expf(sc[r] - mn);
-            sc[r] = p;
-            sum += p;
-          }
-        }
-        sum += __shfl_xor(sum, 32);
-        l = l * alpha + sum;
-        m = mn;
-        // ---- O^T = alpha O^T + V_tile^T . P^T   (x s_v 2^12) ----
-        const _Float16* vh = Vh + l31 * LDV + jt * 32 + hi * 8;
-        const _Float16* vl = Vl + l31 * LDV + jt * 32 + hi * 8;
-        f16x8 v0h[2], v1h[2], v0l[2], v1l[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          v0h[c] = *(const f16x8*)(vh + c * 16); v1h[c] = *(const f16x8*)(vh + 32 * LDV + c * 16);
-          v0l[c] = *(const f16x8*)(vl + c * 16); v1l[c] = *(const f16x8*)(vl + 32 * LDV + c * 16);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          f16x8 ph, pl;
-          split8(f32x4{sc[8 * c], sc[8 * c + 1], sc[8 * c + 2], sc[8 * c + 3]}, f32x4{sc[8 * c + 4], sc[8 * c + 5], sc[8 * c + 6], sc[8 * c + 7]},
-                 kPScale, ph, pl);
-          o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h[c], ph, o0, 0, 0, 0);
-          o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h[c], ph, o1, 0, 0, 0);
-          o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0l[c], ph, o0, 0, 0, 0);
-          o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1l[c], ph, o1, 0, 0, 0);
-          o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h[c], pl, o0, 0, 0, 0);
-          o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h[c], pl, o1, 0, 0, 0);
-        }
-      }
-      // ---- store: accumulator r of o0 / o1 <-> feature (r&3) + 8 (r>>2) + 4 hi (+ 32) of query row i ----
-      if (i < T) {
-        float* op = a.out + ((long)bc * T + i) * 256 + h * 64;
-        const float scl = i < n ? vinv * (1.0f / kPScale) / l : 0.f;         // rows beyond the valid window: deterministic zeros
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          f32x4 v0 = {o0[rr * 4 + 0], o0[rr * 4 + 1], o0[rr * 4 + 2], o0[rr * 4 + 3]};
-          f32x4 v1 = {o1[rr * 4 + 0], o1[rr * 4 + 1], o1[rr * 4 + 2], o1[rr * 4 + 3]};
-          *(f32x4*)(op + rr * 8 + hi * 4) = v0 * scl;
-          *(f32x4*)(op + 32 + rr * 8 + hi * 4) = v1 * scl;
-        }
-      }
-    } else if (it < n_tiles) {                              // whole tile beyond the valid rows: deterministic zeros
-      const int i = it * 32 + l31;
-      if (i < T) {
-        float* op = a.out + ((long)bc * T + i) * 256 + h * 64;
-#pragma unroll
-        for (int d = 0; d < 8; ++d) *(f32x4*)(op + hi * 32 + d * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      };
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      if (act[1]) {
+#pragma unroll 1
+        for (int jt = 0; jt <= jlast[0]; ++jt) step(jt, I0{}, I2{});
+        FINE();        // 6: key tiles shared by both query tiles done
+#pragma unroll 1
+        for (int jt = jlast[0] + 1; jt <= jlast[1]; ++jt) step(jt, I1{}, I2{});
+        FINE();        // 7: remaining key tiles of the longer query tile done
+      } else {
+#pragma unroll 1
+        for (int jt = 0; jt <= jlast[0]; ++jt) step(jt, I0{}, I1{});
       }
     }
-    STAMP();   // 2: this wave's query tile done
+    take_maxima();     // (next item's rows: issued a whole compute phase ago)
+    FINE();            // 8: next item's rows arrived, maxima taken
+    if (act[0]) {
+      // ---- store: accumulator (mt, r) <-> feature 16 mt + 4 g + r of query row 16 t + r16 ----
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        if (act[s]) {
+          float l = lp[s];
+          l += __shfl_xor(l, 16);
+          l += __shfl_xor(l, 32);
+          const int i = qt[s] * 16 + r16;
+          if (i < T) {
+            float* op = a.out + ((long)bc * T + i) * 256 + h * 64 + g * 4;
+            const float scl = i < n ? vinv * (1.0f / kPScale) / l : 0.f;         // rows beyond the valid window: deterministic zeros
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) *(f32x4*)(op + mt * 16) = o[s][mt] * scl;
+          }
+        }
+    }
+    // whole 16-query tiles beyond the valid rows: deterministic zeros
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      if (!act[s]) {
+        const int i = qt[s] * 16 + r16;
+        if (i < T) {
+          float* op = a.out + ((long)bc * T + i) * 256 + h * 64 + g * 4;
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) *(f32x4*)(op + mt * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    STAMP();   // 9: outputs stored
 #ifdef VAPX_TRACE
     if (a.trace && tid == 0 && item < 16384) { a.trace[(long)item * 32 + 29] = __builtin_amdgcn_s_memrealtime(); a.trace[(long)item * 32 + 30] = (unsigned long long)stamp_k; }
 #endif

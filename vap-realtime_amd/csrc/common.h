@@ -105,11 +105,15 @@ __device__ __forceinline__ float lane_bcast(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
-// 64-lane butterfly all-reduce (max; the sum is below, built on the DPP half_sum)
+// 64-lane all-reduce (max; the sum is below, built on the DPP half_sum) without the LDS crossbar: four DPP steps make every 16-lane row
+// uniform (xor 1 / 2 via quad_perm, then row_half_mirror and row_mirror), v_readlane fetches the four rows.  (Round 2 used six
+// __shfl_xor = ds_bpermute round trips; the row statistics of a 64-row tile call this 8 times per wave.)
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));    // quad_perm [1,0,3,2]
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));    // quad_perm [2,3,0,1]
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));   // row_half_mirror
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));   // row_mirror
+  return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
 }
 // all-reduce inside each 32-lane half (MFMA 32x32 accumulator rows live in one half).
 // __shfl_xor lowers to ds_bpermute (an LDS-crossbar round trip per step); DPP adds are plain VALU:
@@ -126,5 +130,5 @@ __device__ __forceinline__ float half_sum(float v) {
 // 64-lane all-reduce: five DPP / swizzle steps inside each half, one ds_bpermute across the halves
 __device__ __forceinline__ float wave_sum(float v) {
   v = half_sum(v);
-  return v + __shfl_xor(v, 32);
+  return lane_bcast(v, 0) + lane_bcast(v, 32);     // (the same two addends as v + __shfl_xor(v, 32), without the LDS round trip)
 }
