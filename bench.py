@@ -468,7 +468,8 @@ def paced_latency(cpc, sets, hz, ctx_sec, local_rank, seconds, target_ms=10.0, m
     schedule for `seconds`; latency of a sub-tick = its scheduled audio-ready time -> results of EVERY model on the host (pinned
     H2D + kernels + D2H + sync, including any wait behind a late predecessor).  A short calibration picks the largest G x Ssub
     whose sub-tick service time keeps the GPU under `max_util`; if the paced run misses p99 <= target or the utilisation bound it
-    is repeated with ~6 % fewer streams per sub-batch (up to twice), then one group smaller."""
+    is repeated: on time but too busy -> the sub-batch size that meets the bound (busy time is linear in it); late -> ~6 % fewer streams per
+    sub-batch (up to twice), then one group smaller."""
     from vap_realtime_amd import engine
     period = 1.0 / hz
     hop = 16000 // hz
@@ -519,7 +520,7 @@ def paced_latency(cpc, sets, hz, ctx_sec, local_rank, seconds, target_ms=10.0, m
     eng, fol = make_engines(cpc, sets, hz, ctx_sec, G * Ssub, local_rank, groups=2, split_f16=split_f16, max_batch=Ssub)
     import gc
     gc.disable()                                       # a collector pause inside the schedule would be charged to the engine
-    for attempt in range(4):
+    for attempt in range(5):
         for s in range(G * Ssub):                     # every trial starts from clean streams (queued, applied by the next step)
             eng.reset_stream(s)
         idsets = [np.arange(g * Ssub, (g + 1) * Ssub, dtype=np.int32) for g in range(G)]
@@ -551,8 +552,11 @@ def paced_latency(cpc, sets, hz, ctx_sec, local_rank, seconds, target_ms=10.0, m
             out["sustained_streams"] = G * Ssub
             out.update({k: run[k] for k in ("groups", "sub_tick_streams", "p50_ms", "p99_ms", "max_ms", "gpu_busy_fraction")})
             break
-        # too busy or too late: shed ~6 % of the streams of every sub-batch (same schedule) and measure again; then drop a group
-        if attempt < 2 and Ssub >= 64:
+        # on time but over the utilisation bound: the busy fraction is linear in the sub-batch size, so go straight to the size that meets
+        # it (1 % margin, multiples of 8).  Too late: shed ~6 % of every sub-batch (same schedule) and measure again; then drop a group
+        if run["p99_ms"] <= target_ms and attempt < 4 and Ssub >= 64:
+            Ssub = min(Ssub - 8, int(Ssub * max_util / run["gpu_busy_fraction"] * 0.99) // 8 * 8)
+        elif attempt < 2 and Ssub >= 64:
             Ssub -= max(8, (Ssub // 16) // 8 * 8)
         else:
             G -= 1

@@ -72,8 +72,13 @@ extern "C" {
 #define VAPX_FLAG_GROUPS_MASK 0xF     /* bits 0-3: intra-tick overlap groups (0 = default 1 = none, max 8) */
 #define VAPX_FLAG_MATERIALIZE_X0 64   /* copy the context window chronologically each tick ("x0" peekable); default: layer 0 reads
                                          the embedding / Q|K|V rings in place (short and long windows alike) */
-#define VAPX_FLAG_SPLIT_F16 512        /* opt-in: the FFN block's contractions as fp32-accurate 3-term split products on the f16
-                                         matrix cores (x = hi + lo; hi.hi + lo.hi + hi.lo, fp32 accumulate); default: fp32 MFMA */
+#define VAPX_FLAG_SPLIT_F16 512        /* opt-in: every contraction with bounded or scalable operands — the fused flat-row blocks (FFN,
+                                         projections), the attention blocks' projections, the conv / LSTM-input GEMMs, and for windows longer
+                                         than 64 frames the attention itself (Q.K^T and P.V) — as fp32-accurate 3-term split products on the
+                                         f16 matrix cores (x s = hi + lo; hi.hi + lo.hi + hi.lo, fp32 accumulate, power-of-two operand scales
+                                         s from row / tile maxima or static weight bounds: no input can overflow f16); same 1e-4 parity bar,
+                                         same error against float64 as the default fp32-MFMA path.  vapx_create refuses the flag
+                                         (VAPX_E_INVAL) for a checkpoint whose transformer weights break the static bounds (|w| >= 255) */
 #define VAPX_FLAG_UNFUSED_PROJ 1024    /* long windows (T > 64): attention output projections (+ residual + LN, + cross-attention query
                                          projection) as separate GEMM launches instead of riding in the fused blocks; kept for A/B tests */
 #define VAPX_FLAG_UNFUSED_LAST_ROW 256 /* last layer's newest-row path as ten launches (gathers, M = 2B GEMMs, single-query

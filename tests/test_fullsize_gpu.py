@@ -17,12 +17,12 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def _tiled_run(name, S, keys, extra=None, max_frames=None, seed=0):
+def _tiled_run(name, S, keys, extra=None, max_frames=None, seed=0, **engine_kw):
     from vap_realtime_amd import engine, weights as W
     c = Case(name)
     ns = len(c.streams)
     blob = W.pack_blob(c.cpc_sd, c.vap_sd, c.mode)
-    eng = engine.Engine(blob, c.frame_hz, c.ctx_sec, max_streams=S + 7, max_batch=S, mode=c.mode)
+    eng = engine.Engine(blob, c.frame_hz, c.ctx_sec, max_streams=S + 7, max_batch=S, mode=c.mode, **engine_kw)
     rng = np.random.default_rng(seed + S)
     ids = rng.permutation(S + 7)[:S].astype(np.int32)            # shuffled slots, a few left unused
     src = (np.arange(S) % ns).astype(np.int64)                   # batch row k replays golden stream src[k]
@@ -63,6 +63,15 @@ def test_vap50_tiled_over_4096_slots():
     """C3 at its full size: 4096 streams x T = 250 (2 M transformer rows; scratch buffers of 2-6 GB each).  The first
     40 frames (the window is still filling: every frame has a different n) keep the run short."""
     _tiled_run("vap50", 4096, ("p_now", "p_future", "vad", "logits"), max_frames=40)
+
+
+@pytest.mark.parametrize("name,S", [("vap50", 77), ("vap20_10s", 301)])
+def test_long_windows_tiled_on_the_split_precision_path(name, S):
+    """The split-precision long-window chain (VAPX_FLAG_SPLIT_F16: attention_long_f16x3_kernel is PERSISTENT — one workgroup per CU walks
+    over (stream, channel, head) items with the next item's rows prefetched — and ffn_block_f16x3 modes 1 / 2) at batch sizes the 1-stream
+    goldens never reach: 77 x 8 = 616 and 301 x 8 = 2408 items on 256 workgroups (several items per workgroup, a ragged last round),
+    shuffled slots (ring addressing through `ids`), every frame from the empty window to the sliding one, T = 250 and T = 200."""
+    _tiled_run(name, S, ("p_now", "p_future", "vad", "logits"), split_f16=True)
 
 
 def _bc_extra(c, f, o, src, worst):

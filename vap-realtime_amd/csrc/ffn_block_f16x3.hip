@@ -245,7 +245,9 @@ __global__ __launch_bounds__(512, 1) void ffn_block_f16x3_kernel(const FfnArgs g
         for (int e = 0; e < 4; ++e) out[rt][4 * j + e] = out[rt][4 * j + e] * sc + rs[e];
       }
     }
-    store_global(out, g.xmid_out, 256, 0);
+    // mode 2 hands xmid to the next block through HBM; in mode 1 its only consumer is this workgroup (the residual of the FFN), so it
+    // stays in the accumulators the FFN2 products are added to (below) and never travels
+    if constexpr (MODE == 2) store_global(out, g.xmid_out, 256, 0);
     STAMP();   // 2: projection + residual
     if constexpr (MODE == 1) {   // A operand of FFN1 = LayerNorm(xmid; ln_ffn): parked in sH (the attention rows are consumed), normalised into sX
       __syncthreads();           // every wave is done reading the attention rows
@@ -264,7 +266,15 @@ __global__ __launch_bounds__(512, 1) void ffn_block_f16x3_kernel(const FfnArgs g
     // ---- feed-forward: x = xmid + gelu(xn W0^T) W3^T, hidden processed in 3 chunks of 256 ----
     // hid_scale: static power of two <= 1 from the weights' bound on |gelu(h)| (vapx_create), 1 for every sane checkpoint
     const float hs = g.hid_scale > 0.f ? g.hid_scale : 1.0f;
-    zero(out);
+    if constexpr (MODE == 0) {
+      zero(out);
+    } else {   // the accumulators start from xmid, in the products' units (2^8 from the weights, hs from the hidden row: exact)
+      const float up = 256.0f * hs;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[rt][r] *= up;
+    }
     for (int c = 0; c < 3; ++c) {
       f32x16 hacc[2];
       zero(hacc);
@@ -295,18 +305,25 @@ __global__ __launch_bounds__(512, 1) void ffn_block_f16x3_kernel(const FfnArgs g
     }
     {
       const float inv = kWScaleInv * __builtin_amdgcn_rcpf(hs);
-      const float* xm = (MODE == 0 ? g.xmid : g.xmid_out) + ccol;   // (mode 1: this lane's own xmid elements, written above)
+      if constexpr (MODE == 0) {
+        const float* xm = g.xmid + ccol;
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        int m = m0 + rt * 32 + l31;
-        m = m < g.M ? m : g.M - 1;                               // rows beyond the matrix re-read its last row (their results are not stored)
-        const float* rp = xm + (long)m * 256;
+        for (int rt = 0; rt < 2; ++rt) {
+          int m = m0 + rt * 32 + l31;
+          m = m < g.M ? m : g.M - 1;                             // rows beyond the matrix re-read its last row (their results are not stored)
+          const float* rp = xm + (long)m * 256;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const f32x4 rs = *(const f32x4*)(rp + 8 * j);
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 rs = *(const f32x4*)(rp + 8 * j);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) out[rt][4 * j + e] = out[rt][4 * j + e] * inv + rs[e];
+            for (int e = 0; e < 4; ++e) out[rt][4 * j + e] = out[rt][4 * j + e] * inv + rs[e];
+          }
         }
+      } else {   // xmid is in the sum already
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) out[rt][r] *= inv;
       }
     }
     store_global(out, g.xout, 256, 0);

@@ -24,7 +24,8 @@ struct FfnArgs {
   unsigned long long* trace;   // debug build: optional [grid][32] s_memtime stamps of workgroup phases (env VAPX_FFN_TRACE)
 #endif
   // Long-window path (T > 64): the attention output projection rides in front of the block instead of a separate GEMM:
-  //   xmid = resid + att . Wproj^T   (-> xmid_out, the residual stream), then LayerNorm as usual.
+  //   xmid = resid + att . Wproj^T   (the residual stream), then LayerNorm as usual.  Mode 2 writes it to xmid_out (the next block's
+  //   `resid`); in mode 1 its only consumer is the block itself, so it stays in the accumulators and xmid_out is NOT written.
   // mode 0: xmid is read from global (fused attention block wrote it).  mode 1: pre-projection + the whole block.
   // mode 2: pre-projection + LN(ln_g, ln_b) + the n_qkv_chunks contractions of wqkvf -> qkv only (self-attention half of a
   //         stereo layer: LN_src + cross-attention query projection), no FFN.
@@ -32,7 +33,7 @@ struct FfnArgs {
   const float* att;    // [M][256] attention output (heads merged)
   const float* wprojf; // output projection, fragment-major
   const float* resid;  // [M][256]
-  float* xmid_out;     // [M][256]
+  float* xmid_out;     // [M][256] (mode 2)
   // mode 1 on layer 0 of a long window: `resid` is the per-stream embedding RING (slab = slot*2+channel, logical row i of the
   // window in ring slot (i + resid_rot[b]) % resid_T) instead of a chronological [M][256] buffer
   const int* resid_rot; // [B] or null

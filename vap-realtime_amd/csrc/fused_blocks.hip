@@ -245,12 +245,14 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
         }
     } else
     add_rows(out, g.resid);
-    store_global(out, g.xmid_out, 256, 0);
+    // mode 2 hands xmid to the next block through HBM; in mode 1 its only consumer is this workgroup (the residual of the FFN), so it
+    // stays where it is — in the accumulators the FFN2 products are added to — and never travels (2 x 2.1 GB per launch at C3)
+    if constexpr (MODE == 2) store_global(out, g.xmid_out, 256, 0);
     if constexpr (MODE == 1) ln_rows(out, false, sX, g.lnf_g, g.lnf_b, nullptr);   // A operand of FFN1
   }
   if constexpr (MODE != 2) {
   // ---- feed-forward: x = xmid + gelu(xn W0^T) W3^T, hidden processed in 3 chunks of 256 ----
-  zero(out);
+  if constexpr (MODE == 0) zero(out);   // (mode 1: the accumulators start from xmid)
   for (int c = 0; c < 3; ++c) {
     f32x16 hacc[MT][2];
     zero(hacc);
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
     mm(out, sH, g.w3f + (long)c * 65536, c < 2 ? g.w0f + (long)(c + 1) * 65536 : after_ffn);
     STAMP();   // 5 + 4c: FFN2 chunk MFMAs done
   }
-  add_rows(out, MODE == 0 ? g.xmid : g.xmid_out);   // (mode 1: this workgroup's own xmid rows, written above)
+  if constexpr (MODE == 0) add_rows(out, g.xmid);
   STAMP();   // 14: residual added
   store_global(out, g.xout, 256, 0);
   STAMP();   // 15: x_out stored
