@@ -400,7 +400,7 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
 #ifdef VAPX_TRACE
       if (h->attn_trace && l == 1) { aa.trace = h->attn_trace; h->attn_trace_wgs = std::min<size_t>(16384, (size_t)B * 8); }
 #endif
-      { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, split ? launch_attention_f16x3(aa, B, st) : launch_attention_long(aa, B, st)); }
+      { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, split ? launch_attention_f16x3(aa, B, st) : launch_attention(aa, B, st)); }
       pre_att = sc.att; pre_w = split ? Lw.wproj8 : Lw.wprojf; pre_resid = ring0 ? rv->ring : xin;
       pre_ring = ring0;
       if (l > 0) {
@@ -411,13 +411,13 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
         fp.ln_g = Lw.ln_src_g; fp.ln_b = Lw.ln_src_b; fp.wqkvf = split ? Lw.wqx8 : Lw.wqxf; fp.n_qkv_chunks = 1; fp.qkv = sc.qx;
         { ProfScope ps(h, CLS_FFN, st); HIPCHK(h, split ? launch_ffn_block_f16x3(fp, st) : launch_ffn_block(fp, st)); }
         AttnArgs ax{sc.qx, sc.kvx, sc.kvx + 256, sc.att, sc.bn, T, 256, 512, 1};
-        { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, split ? launch_attention_f16x3(ax, B, st) : launch_attention_long(ax, B, st)); }
+        { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, split ? launch_attention_f16x3(ax, B, st) : launch_attention(ax, B, st)); }
         pre_w = split ? Lw.wprojx8 : Lw.wprojxf; pre_resid = sc.xmid;
       }
     } else {
     // self attention
       AttnArgs aa{sc.qkv, sc.qkv + 256, sc.qkv + 512, sc.att, sc.bn, T, 768, 768, 0};
-      { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, split ? launch_attention_f16x3(aa, B, st) : launch_attention_long(aa, B, st)); }
+      { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, split ? launch_attention_f16x3(aa, B, st) : launch_attention(aa, B, st)); }
       g = gemm_args(sc.att, r256, Lw.wproj, M, 256, 256, sc.xmid, r256);
       g.resid = xin; g.C2 = sc.xn;
       if (l == 0) { g.gamma = Lw.ln_ffn_g; g.beta = Lw.ln_ffn_b; }
@@ -428,7 +428,7 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
         g = gemm_args(sc.xn, r256, Lw.wq_x, M, 256, 256, sc.qx, r256);
         HIPCHK(h, gemm(h, g, EPI_STORE, st));
         AttnArgs ax{sc.qx, sc.kvx, sc.kvx + 256, sc.att, sc.bn, T, 256, 512, 1};
-        { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, split ? launch_attention_f16x3(ax, B, st) : launch_attention_long(ax, B, st)); }
+        { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, split ? launch_attention_f16x3(ax, B, st) : launch_attention(ax, B, st)); }
         g = gemm_args(sc.att, r256, Lw.wproj_x, M, 256, 256, sc.xmid, r256);
         g.resid = sc.xmid; g.C2 = sc.xn; g.gamma = Lw.ln_ffn_g; g.beta = Lw.ln_ffn_b;
         HIPCHK(h, gemm(h, g, EPI_RESID_LN, st, /*bounded_A=*/false));
