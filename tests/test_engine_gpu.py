@@ -506,11 +506,13 @@ def test_long_window_fused_projections_equal_the_gemm_chain():
     fused.close(); plain.close()
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["fp32", "split_f16"])
 @pytest.mark.parametrize("hz,ctx", [(20, 5.0), (20, 7.5), (10, 10.0)])
-def test_mid_length_windows_against_the_oracle(hz, ctx):
+def test_mid_length_windows_against_the_oracle(hz, ctx, split):
     """Windows between the fused-block limit (64) and 256 rows — the reference's published bc (20 Hz / 5 s, T = 100) and nod
     (10 Hz / 10 s, T = 100) settings, and T = 150 (5 key tiles: a partly used second chunk of the online softmax) — run the
-    long-window attention kernel + flat-row projection blocks; window filling, full, and sliding."""
+    long-window attention kernel + flat-row projection blocks; window filling, full, and sliding.  On the split-precision path
+    the same windows leave some of the persistent attention kernel's waves without a valid query tile (7 or 10 of its 16)."""
     from oracle.vap_oracle import ServerFramer, VapOracle
     from vap_realtime_amd import engine, synth, weights as W
     cpc, vap = W.synthetic_weights(13, hz, "vap")
@@ -519,7 +521,7 @@ def test_mid_length_windows_against_the_oracle(hz, ctx):
     S, F_ = 2, T + 5
     audio = synth.dialogue_batch([70, 71], hop * F_)
     st, fr = o.new_state(S), ServerFramer(S, hop)
-    eng = engine.Engine(W.pack_blob(cpc, vap), hz, ctx, max_streams=S)
+    eng = engine.Engine(W.pack_blob(cpc, vap), hz, ctx, max_streams=S, split_f16=split)
     assert eng.T == T
     worst = 0.0
     for f in range(F_):
