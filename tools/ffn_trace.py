@@ -12,12 +12,9 @@ NAMES = ["entry", "tile staged+LN", "ffn1.0 mm", "gelu.0", "h->LDS.0", "ffn2.0 m
 SPLIT = "--split" in sys.argv
 if SPLIT:       # ffn_block_f16x3_kernel<0>: coarser stamps (VAPX_FLAG_SPLIT_F16 engine, bench.py --split-f16)
     sys.argv.remove("--split")
-    NAMES = ["entry", "tile staged+LN+split", "ffn1.0 mm", "gelu+split->LDS.0", "ffn2.0 mm", "ffn1.1 mm", "gelu+split->LDS.1", "ffn2.1 mm",
-             "ffn1.2 mm", "gelu+split->LDS.2", "ffn2.2 mm", "resid + x_out store", "row stats", "kvx0 mm+store", "kvx1 mm+store",
+    NAMES = ["entry", "tile staged+LN+split", "ffn1.0 mm", "gelu.0 -> sH under ffn1.1 mm", "ffn2.0 mm", "gelu.1 -> sH under ffn1.2 mm", "ffn2.1 mm",
+             "gelu.2 -> sH", "ffn2.2 mm", "resid + x_out store", "row stats", "kvx0 mm+store", "kvx1 mm", "kvx1 scale + stores issued",
              "LN->LDS + q mm+store", "k mm+store", "v mm+store"]
-    # the debug build carries four extra stamps inside chunk 1's GELU phase and one between kvx1's contraction and its stores
-    NAMES = (NAMES[:6] + ["gelu.1 VALU", "gelu.1 barrier (sH free)", "gelu.1 split + LDS stores", "gelu.1 barrier (sH ready)"] + NAMES[7:14]
-             + ["kvx1 mm", "kvx1 scale + stores issued"] + NAMES[15:])
 NST = len(NAMES)
 t = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 32).astype(np.int64)
 tick_ns = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0

@@ -36,6 +36,10 @@
 // immaterial.
 #include "fused_blocks.h"
 
+#ifndef VAPX_F16X3_RING
+#define VAPX_F16X3_RING 4      // k-chunks of weight fragments in flight per wave (4: 1.5 k cycles of cover, as fast as 8 and 32 registers cheaper)
+#endif
+
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -73,13 +77,14 @@ __global__ __launch_bounds__(512, 1) void ffn_block_f16x3_kernel(const FfnArgs g
   auto FINE = [] {};
 #endif
 
-  // weight fragments of this wave's 32 columns: ring of 8 k-chunks (hi, lo) ahead, running on into the next unit
-  f32x4 ring[16];
+  // weight fragments of this wave's 32 columns: ring of RD k-chunks (hi, lo) ahead, running on into the next unit
+  constexpr int RD = VAPX_F16X3_RING;
+  f32x4 ring[2 * RD];
   auto wbase = [&](const float* wfrag) { return (const f32x4*)wfrag + (long)w * 16 * 2 * 64; };   // wave-uniform
   auto fetch = [&](const float* wfrag) {
     const f32x4* wf = wbase(wfrag);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) ring[i] = wf[i * 64 + lane];
+    for (int i = 0; i < 2 * RD; ++i) ring[i] = wf[i * 64 + lane];
   };
   fetch(MODE == 0 ? g.w0f : g.wprojf);   // the first weight fragments fly while the tile is staged
 
@@ -131,44 +136,83 @@ __global__ __launch_bounds__(512, 1) void ffn_block_f16x3_kernel(const FfnArgs g
   // acc[rt] += (A[rows 32 rt ..][256 k] (LDS hi / lo) . W^T for this wave's 32 columns)^T: the WEIGHT fragment is the MFMA's A operand
   // and the activation rows its B operand (the two operand layouts are the same), so a lane ends up with ONE ROW and 4 x 4 consecutive
   // columns of it — every epilogue below moves 16 bytes per instruction and needs one row index per lane instead of sixteen
+  // one k-chunk: 6 MFMAs on the A fragments fetched a step ago, the next step's A fragments from LDS, two ring refills from `nx`
+  f16x8 n0h, n0l, n1h, n1l;   // A fragments ping-pong one k-chunk ahead of their use
+  auto kstep_body = [&](f32x16(&acc)[2], const _Float16* pah, const _Float16* pal, const f32x4* nx, int k8, int kn) {
+    const f16x8 a0h = n0h, a0l = n0l, a1h = n1h, a1l = n1l;
+    n0h = *(const f16x8*)(pah + kn); n0l = *(const f16x8*)(pal + kn);
+    n1h = *(const f16x8*)(pah + 32 * LD16 + kn); n1l = *(const f16x8*)(pal + 32 * LD16 + kn);
+    const f16x8 bh = __builtin_bit_cast(f16x8, ring[k8 * 2]), bl = __builtin_bit_cast(f16x8, ring[k8 * 2 + 1]);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, a0h, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, a1h, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, a0l, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, a1l, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, a0h, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, a1h, acc[1], 0, 0, 0);
+    ring[k8 * 2] = nx[(k8 * 2) * 64 + lane];
+    ring[k8 * 2 + 1] = nx[(k8 * 2 + 1) * 64 + lane];
+  };
+  auto kstep = [&](f32x16(&acc)[2], const _Float16* pah, const _Float16* pal, const f32x4* nx, int k8, int kn) {
+    kstep_body(acc, pah, pal, nx, k8, kn);
+    // one memory instruction between two MFMAs (4 LDS reads, 2 weight loads per 6 MFMAs)
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    __builtin_amdgcn_sched_barrier(0);   // keep the refills of this chunk behind its MFMAs
+  };
   auto mm = [&](f32x16(&acc)[2], const _Float16* Ah, const _Float16* Al, const float* wfrag, const float* next_wfrag) {
     const _Float16* pah = Ah + l31 * LD16 + hi * 8;
     const _Float16* pal = Al + l31 * LD16 + hi * 8;
     const f32x4* wf = wbase(wfrag);
     const f32x4* wnext = next_wfrag ? wbase(next_wfrag) : wf;
     __builtin_amdgcn_s_setprio(1);
-    // A fragments ping-pong one k-chunk ahead of their use
-    f16x8 n0h = *(const f16x8*)(pah), n0l = *(const f16x8*)(pal);
-    f16x8 n1h = *(const f16x8*)(pah + 32 * LD16), n1l = *(const f16x8*)(pal + 32 * LD16);
+    n0h = *(const f16x8*)(pah); n0l = *(const f16x8*)(pal);
+    n1h = *(const f16x8*)(pah + 32 * LD16); n1l = *(const f16x8*)(pal + 32 * LD16);
 #pragma unroll 1
-    for (int blk = 0; blk < 2; ++blk) {
-      const f32x4* nx = blk < 1 ? wf + 16 * 64 : wnext;
+    for (int blk = 0; blk < 16 / RD; ++blk) {
+      const f32x4* nx = blk < 16 / RD - 1 ? wf + (blk + 1) * RD * 2 * 64 : wnext;
 #pragma unroll
-      for (int k8 = 0; k8 < 8; ++k8) {
-        const int kn = ((blk * 8 + k8 + 1) & 15) * 16;
-        const f16x8 a0h = n0h, a0l = n0l, a1h = n1h, a1l = n1l;
-        n0h = *(const f16x8*)(pah + kn); n0l = *(const f16x8*)(pal + kn);
-        n1h = *(const f16x8*)(pah + 32 * LD16 + kn); n1l = *(const f16x8*)(pal + 32 * LD16 + kn);
-        const f16x8 bh = __builtin_bit_cast(f16x8, ring[k8 * 2]), bl = __builtin_bit_cast(f16x8, ring[k8 * 2 + 1]);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, a0h, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, a1h, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, a0l, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, a1l, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, a0h, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, a1h, acc[1], 0, 0, 0);
-        ring[k8 * 2] = nx[(k8 * 2) * 64 + lane];
-        ring[k8 * 2 + 1] = nx[(k8 * 2 + 1) * 64 + lane];
-        // one memory instruction between two MFMAs (4 LDS reads, 2 weight loads per 6 MFMAs)
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        __builtin_amdgcn_sched_barrier(0);   // keep the refills of this chunk behind its MFMAs
-      }
+      for (int k8 = 0; k8 < RD; ++k8) kstep(acc, pah, pal, nx, k8, ((blk * RD + k8 + 1) & 15) * 16);
     }
     __builtin_amdgcn_s_setprio(0);
+  };
+  // the same contraction, fully unrolled, with `side(q)` — a slice of VALU / LDS-store work that does not depend on it: one of the eight
+  // 4-value groups of the PREVIOUS hidden chunk's GELU — woven into every pair of k-chunks: behind each of the 12 MFMAs come five VALU
+  // instructions, one transcendental and one memory instruction (sched_group_barrier), which is what fits in an MFMA's shadow with two
+  // waves on the SIMD.  (As a block BEHIND the MFMAs the slice gains nothing: the SIMD's two waves run in lockstep, so both sit in their
+  // VALU blocks at the same time and the matrix pipe idles — measured: 7.4 us for the pair, exactly the sum of its parts.)
+  auto mm_side = [&](f32x16(&acc)[2], const _Float16* Ah, const _Float16* Al, const float* wfrag, const float* next_wfrag, auto&& side) {
+    const _Float16* pah = Ah + l31 * LD16 + hi * 8;
+    const _Float16* pal = Al + l31 * LD16 + hi * 8;
+    const f32x4* wf = wbase(wfrag);
+    const f32x4* wnext = next_wfrag ? wbase(next_wfrag) : wf;
+    n0h = *(const f16x8*)(pah); n0l = *(const f16x8*)(pal);
+    n1h = *(const f16x8*)(pah + 32 * LD16); n1l = *(const f16x8*)(pal + 32 * LD16);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int blk = ks / RD, k8 = ks % RD;
+      kstep_body(acc, pah, pal, blk < 16 / RD - 1 ? wf + (blk + 1) * RD * 2 * 64 : wnext, k8, ((ks + 1) & 15) * 16);
+      if (ks & 1) {
+        side(ks >> 1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);     // GELU arithmetic
+          __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);     // its exp / rcp
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // an A-fragment LDS read
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // a weight refill
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
   };
   auto zero = [](f32x16(&acc)[2]) {
 #pragma unroll
@@ -275,33 +319,36 @@ __global__ __launch_bounds__(512, 1) void ffn_block_f16x3_kernel(const FfnArgs g
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[rt][r] *= up;
     }
+    // gelu + f16 split of one 4-value group (q = 4 rt + j) of a hidden chunk's accumulators -> sH
+    auto gelu_group = [&](const f32x16(&h)[2], int q) {
+      const int rt = q >> 2, j = q & 3;
+      f32x4 y;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = gelu_fast(h[rt][4 * j + e] * kWScaleInv) * hs;
+      const h16x4 hh = __builtin_convertvector(y, h16x4);
+      const h16x4 ll = __builtin_convertvector(y - __builtin_convertvector(hh, f32x4), h16x4);
+      *(h16x4*)&sHh[(rt * 32 + l31) * LD16 + ccol + 8 * j] = hh;
+      *(h16x4*)&sHl[(rt * 32 + l31) * LD16 + ccol + 8 * j] = ll;
+    };
+    // weight order: W0.0, W0.1, W3.0, W0.2, W3.1, W3.2 — the GELU of chunk c rides in the FFN1 contraction of chunk c + 1 (mm_side)
+    f32x16 hacc[2][2];
+    zero(hacc[0]);
+    mm(hacc[0], sXh, sXl, g.w0f, g.w0f + 65536);
+    STAMP();   // FFN1 chunk 0
+#pragma unroll
     for (int c = 0; c < 3; ++c) {
-      f32x16 hacc[2];
-      zero(hacc);
-      mm(hacc, sXh, sXl, g.w0f + (long)c * 65536, g.w3f + (long)c * 65536);
-      STAMP();   // FFN1 chunk mm
+      if (c > 0) __syncthreads();   // every wave is done reading the previous chunk from sH
+      if (c < 2) {
+        zero(hacc[(c + 1) & 1]);
+        mm_side(hacc[(c + 1) & 1], sXh, sXl, g.w0f + (long)(c + 1) * 65536, g.w3f + (long)c * 65536, [&](int q) { gelu_group(hacc[c & 1], q); });
+      } else {
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hacc[rt][r] = gelu_fast(hacc[rt][r] * kWScaleInv) * hs;
-      if (c == 1) FINE();       // gelu VALU done
-      __syncthreads();          // every wave is done reading the previous chunk (or the parked tile) from sH
-      if (c == 1) FINE();       // barrier passed
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const f32x4 y = quad(hacc[rt], j);
-          const h16x4 hh = __builtin_convertvector(y, h16x4);
-          const h16x4 ll = __builtin_convertvector(y - __builtin_convertvector(hh, f32x4), h16x4);
-          *(h16x4*)&sHh[(rt * 32 + l31) * LD16 + ccol + 8 * j] = hh;
-          *(h16x4*)&sHl[(rt * 32 + l31) * LD16 + ccol + 8 * j] = ll;
-        }
-      if (c == 1) FINE();       // split + LDS stores issued
+        for (int q = 0; q < 8; ++q) gelu_group(hacc[c & 1], q);
+      }
       __syncthreads();
-      STAMP();   // gelu + split + h -> LDS
-      mm(out, sHh, sHl, g.w3f + (long)c * 65536, c < 2 ? g.w0f + (long)(c + 1) * 65536 : after_ffn);
-      STAMP();   // FFN2 chunk mm
+      STAMP();   // gelu(c) -> sH  (+ FFN1 chunk c + 1)
+      mm(out, sHh, sHl, g.w3f + (long)c * 65536, c == 0 ? g.w0f + 2 * 65536 : (c == 1 ? g.w3f + 2 * 65536 : after_ffn));
+      STAMP();   // FFN2 chunk c
     }
     {
       const float inv = kWScaleInv * __builtin_amdgcn_rcpf(hs);
