@@ -2,7 +2,8 @@
 """Soak run on the GPU: the same audio through three engines (default, two free-running overlap groups, split-precision)
 for many ticks with random resets; the first two must stay bit-identical while both batch sizes select the same kernel
 variants (<= 512 streams; beyond that tile heuristics differ and only the tolerance applies), the third within tolerance,
-nothing may go non-finite.  Usage: tools/soak.py [streams] [ticks]"""
+nothing may go non-finite.  Usage: tools/soak.py [streams] [ticks] [frame_hz] [context_sec]   (default 20 Hz / 2.5 s; 50 5 runs the
+long-window chain: attention_long2_kernel / attention_long_f16x3_kernel + the flat-row projection blocks)"""
 import os
 import sys
 
@@ -14,16 +15,22 @@ from vap_realtime_amd import engine, synth, weights as W  # noqa: E402
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 TICKS = int(sys.argv[2]) if len(sys.argv) > 2 else 600
-cpc, vap = W.synthetic_weights(3, 20)
+HZ = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+CTX = float(sys.argv[4]) if len(sys.argv) > 4 else 2.5
+HOP = 16000 // HZ
+cpc, vap = W.synthetic_weights(3, HZ)
 blob = W.pack_blob(cpc, vap)
-a = engine.Engine(blob, 20, 2.5, max_streams=S)
-b = engine.Engine(blob, 20, 2.5, max_streams=S, groups=2)
-c = engine.Engine(blob, 20, 2.5, max_streams=S, split_f16=True)
+a = engine.Engine(blob, HZ, CTX, max_streams=S)
+b = engine.Engine(blob, HZ, CTX, max_streams=S, groups=2)
+c = engine.Engine(blob, HZ, CTX, max_streams=S, split_f16=True)
 NF = 16
-audio = torch.from_numpy(np.concatenate([synth.dialogue_batch(list(range(64)), 800 * NF)] * ((S + 63) // 64))[:S]).cuda()
+# bit-identity of the overlap-group engine holds while both batch sizes select the same kernel variants: up to 512 streams x 50 rows x 2
+# channels of transformer rows (measured); beyond that the GEMM tile heuristics differ between S and S / 2 and only the tolerance applies
+STRICT = S * 2 * a.T <= 512 * 2 * 50
+audio = torch.from_numpy(np.concatenate([synth.dialogue_batch(list(range(64)), HOP * NF)] * ((S + 63) // 64))[:S]).cuda()
 # one resident tensor per frame: with VAPX_DEFER_JOIN the group streams of engine b may still be reading a tick's audio when the
 # next tick is enqueued, so the inputs must not be temporaries the caching allocator recycles under them
-frames = [audio[:, :, k * 800:(k + 1) * 800].contiguous() for k in range(NF)]
+frames = [audio[:, :, k * HOP:(k + 1) * HOP].contiguous() for k in range(NF)]
 oa, ob, oc = (torch.zeros(S, engine.OUT_STRIDE, device="cuda") for _ in range(3))
 rng = np.random.default_rng(0)
 st = torch.cuda.current_stream().cuda_stream
@@ -35,18 +42,18 @@ for t in range(TICKS):
         for sid in rng.integers(0, S, 3):
             for e in (a, b, c):
                 e.reset_stream(int(sid))
-    a.step_device(S, x.data_ptr(), 800, oa.data_ptr(), stream=st)
-    b.step_device(S, x.data_ptr(), 800, ob.data_ptr(), stream=st, defer_join=not os.environ.get("SOAK_NO_DEFER"))
-    c.step_device(S, x.data_ptr(), 800, oc.data_ptr(), stream=st)
+    a.step_device(S, x.data_ptr(), HOP, oa.data_ptr(), stream=st)
+    b.step_device(S, x.data_ptr(), HOP, ob.data_ptr(), stream=st, defer_join=not os.environ.get("SOAK_NO_DEFER"))
+    c.step_device(S, x.data_ptr(), HOP, oc.data_ptr(), stream=st)
     if t % 25 == 24 or t == TICKS - 1:
         b.join(st)
         torch.cuda.synchronize()
         assert torch.isfinite(oa).all() and torch.isfinite(oc).all(), f"non-finite output at tick {t}"
-        if S <= 512:
+        if STRICT:
             assert torch.equal(oa, ob), f"overlap groups diverged from the single-stream path at tick {t} (max |diff| {float((oa - ob).abs().max()):.3e})"
         dg = float((oa[:, :272] - ob[:, :272]).abs().max())
         assert dg < 2e-5, f"overlap groups off by {dg} at tick {t}"
         d = float((oa[:, :272] - oc[:, :272]).abs().max())
         worst = max(worst, d)
         assert d < 1e-4, f"split path off by {d} at tick {t}"
-print(f"soak ok: {S} streams x {TICKS} ticks; overlap groups " + ("bit-identical" if S <= 512 else "within 2e-5") + f"; max |split - fp32| = {worst:.2e}")
+print(f"soak ok: {S} streams x {TICKS} ticks at {HZ} Hz / {CTX} s; overlap groups " + ("bit-identical" if STRICT else "within 2e-5") + f"; max |split - fp32| = {worst:.2e}")
