@@ -323,6 +323,35 @@ def test_poisoned_sample_behaves_like_the_reference():
     eng.close()
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["fp32", "split_f16"])
+def test_poisoned_sample_in_a_long_window_stays_in_its_stream(split):
+    """The same contract at 50 Hz / 5 s (long-window chain: flat-row blocks over rows of SEVERAL streams, attention items of several
+    streams per workgroup on the split path) with per-tile / per-item operand scales taken from maxima: one NaN sample in stream 1 must
+    flag stream 1 only and leave streams 0 and 2 BIT-identical to a run that never saw it; a reset brings stream 1 back."""
+    from vap_realtime_amd import engine, synth, weights as W
+    cpc, vap = W.synthetic_weights(23, 50, "vap")
+    blob = W.pack_blob(cpc, vap)
+    S, hop, F_ = 3, 320, 12
+    audio = synth.dialogue_batch([90, 91, 92], hop * F_)
+    bad = audio.copy()
+    bad[1, 0, 3 * hop + 17] = np.nan
+    clean_eng = engine.Engine(blob, 50, 5.0, max_streams=S, split_f16=split)
+    eng = engine.Engine(blob, 50, 5.0, max_streams=S, split_f16=split)
+    for f in range(F_):
+        sl = slice(f * hop, (f + 1) * hop)
+        want = clean_eng.step(np.ascontiguousarray(audio[:, :, sl]))
+        if f == 8:
+            eng.reset_stream(1)
+        src = bad if f < 8 else audio
+        got = eng.step(np.ascontiguousarray(src[:, :, sl]), on_numeric="status")
+        o = engine.split_outputs(got)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2]), f      # the neighbours never notice
+        poisoned = 3 <= f < 8
+        assert o["status"].tolist() == [0, int(poisoned), 0], (f, o["status"])
+        assert np.isfinite(o["logits"][1]).all() != poisoned
+    clean_eng.close(); eng.close()
+
+
 def test_reset_is_stream_ordered_and_leaves_the_other_streams_alone():
     """vapx_reset_stream only queues the request; the next step applies it on its own HIP stream.  Resetting one stream of
     a 1024-stream engine mid-run: every other stream's outputs are bit-identical to an engine that saw no reset, the reset
