@@ -47,10 +47,10 @@ def _tiled_run(name, S, keys, extra=None, max_frames=None, seed=0, **engine_kw):
         assert v <= TOL, (name, S, k, v)
 
 
-@pytest.mark.parametrize("S", [1100, 4096])
-def test_multi3_tiled_over_full_size_batches(S):
-    """C2 / C4 shape (20 Hz, T = 50) at 1100 and 4096 streams per engine."""
-    _tiled_run("multi3", S, ("p_now", "p_future", "vad", "logits"))
+@pytest.mark.parametrize("S,split", [(1100, False), (4096, False), (4096, True)], ids=["1100", "4096", "4096-split_f16"])
+def test_multi3_tiled_over_full_size_batches(S, split):
+    """C2 / C4 shape (20 Hz, T = 50) at 1100 and 4096 streams per engine (4096 also on the split-precision path)."""
+    _tiled_run("multi3", S, ("p_now", "p_future", "vad", "logits"), split_f16=split)
 
 
 def test_vap50_tiled_over_1100_slots():
@@ -89,7 +89,8 @@ def _nod_extra(c, f, o, src, worst):
     worst["p_bc"] = max(worst.get("p_bc", 0.0), float(np.abs(o["logits"][:, :n] - want).max()))
 
 
-def test_bc_and_nod_heads_at_4096_streams():
+@pytest.mark.parametrize("split", [False, True], ids=["fp32", "split_f16"])
+def test_bc_and_nod_heads_at_4096_streams(split):
     """C5 shape: the bc and nod variants at 4096 streams (nod runs the full last layer + the all-rows p_bc)."""
-    _tiled_run("bc20", 4096, ("e",), extra=_bc_extra)       # (the bc / nod programs never fill result_vad: no golden for it)
-    _tiled_run("nod20", 4096, ("e",), extra=_nod_extra)
+    _tiled_run("bc20", 4096, ("e",), extra=_bc_extra, split_f16=split)       # (the bc / nod programs never fill result_vad: no golden for it)
+    _tiled_run("nod20", 4096, ("e",), extra=_nod_extra, split_f16=split)

@@ -2,7 +2,8 @@
 random subsets of the streams in random batch order (what ragged ticks of the TCP front-end look like), stream resets, carry-only
 resets (reconnects), state export / import into another slot, host and device paths, overlap groups — runs against the engine while
 one oracle instance per dialogue follows the same program on the CPU.  Every stepped stream must agree with its oracle (<= 1e-4)
-at every tick, through window fill and slide.  Complements the fixed scenarios of test_engine_gpu.py."""
+at every tick, through window fill and slide — on the default fp32 path and on the split-precision path (VAPX_FLAG_SPLIT_F16).  Complements
+the fixed scenarios of test_engine_gpu.py."""
 import numpy as np
 import pytest
 
@@ -42,9 +43,10 @@ def _compare(mode, got, i, want):
     return max(float(np.abs(np.asarray(a, np.float64).reshape(-1) - np.asarray(b, np.float64).reshape(-1)).max()) for a, b in pairs)
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["fp32", "split_f16"])
 @pytest.mark.parametrize("seed,hz,ctx,groups,mode", [(1, 20, 2.5, 0, "vap"), (2, 20, 1.0, 2, "vap"), (3, 50, 1.3, 2, "vap"), (4, 10, 2.5, 2, "vap"),
                                                      (5, 20, 2.5, 0, "nod"), (6, 10, 5.0, 2, "bc"), (7, 5, 10.0, 0, "vap"), (8, 50, 5.0, 0, "vap")])
-def test_random_program_against_per_stream_oracles(seed, hz, ctx, groups, mode):
+def test_random_program_against_per_stream_oracles(seed, hz, ctx, groups, mode, split):
     import torch
     from oracle.vap_oracle import VapOracle
     from vap_realtime_amd import engine, synth, weights as W
@@ -54,7 +56,7 @@ def test_random_program_against_per_stream_oracles(seed, hz, ctx, groups, mode):
     hop = 16000 // hz
     S, slots, ticks = 5, 9, int(ctx * hz) + 14          # 5 dialogues living in 9 engine slots
     audio = synth.dialogue_batch([70 + i for i in range(S)], hop * ticks)
-    eng = engine.Engine(W.pack_blob(cpc, vap, mode), hz, ctx, max_streams=slots, max_batch=slots, groups=groups, mode=mode)
+    eng = engine.Engine(W.pack_blob(cpc, vap, mode), hz, ctx, max_streams=slots, max_batch=slots, groups=groups, mode=mode, split_f16=split)
     dia = [Dialogue(oracle, hop) for _ in range(S)]
     slot_of = list(rng.permutation(slots)[:S])            # dialogue k lives in engine slot slot_of[k]
     pos = [0] * S                                         # next audio frame of each dialogue
