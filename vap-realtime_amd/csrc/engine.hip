@@ -297,6 +297,7 @@ int run_encoder(vapx_engine* h, const Scratch& sc, const StateView& sv, int B, c
     RowMap cm{(long)(c.Pout + 2 * c.guard_out) * 256, 256, c.Pout};
     snprintf(nm, sizeof nm, "conv%s.w", c.idx);
     GemmArgs g = gemm_args(c.in, am, h->W(nm), B * 2 * c.Pout, 256, c.k * 256, c.out + c.guard_out * 256, cm);
+    snprintf(nm, sizeof nm, "conv%s.w16", c.idx); g.W16 = h->W(nm);
     snprintf(nm, sizeof nm, "conv%s.b", c.idx); g.bias = h->W(nm);
     snprintf(nm, sizeof nm, "cn%s.g", c.idx); g.gamma = h->W(nm);
     snprintf(nm, sizeof nm, "cn%s.b", c.idx); g.beta = h->W(nm);
@@ -314,11 +315,13 @@ int run_encoder(vapx_engine* h, const Scratch& sc, const StateView& sv, int B, c
   } else {  // conv4: only positions 1..P4-2 survive z[:, 1:-1] (encoder.py:76)
     RowMap am{(long)(P[3] + 2) * 256, 2 * 256, h->ncpc};
     GemmArgs g = gemm_args(sc.h3 + 2 * 256, am, h->W("conv4.w"), B * 2 * h->ncpc, 256, 4 * 256, sc.z, contiguous_rows(256));
+    g.W16 = h->W("conv4.w16");
     g.bias = h->W("conv4.b"); g.gamma = h->W("cn4.g"); g.beta = h->W("cn4.b");
     HIPCHK(h, gemm(h, g, EPI_CN_RELU, st));
   }
   {  // LSTM input projection for all n_cpc steps at once: gx = z.W_ih^T + (b_ih + b_hh)
     GemmArgs g = gemm_args(sc.z, contiguous_rows(256), h->W("lstm.wih"), B * 2 * h->ncpc, 1024, 256, sc.gx, contiguous_rows(1024));
+    g.W16 = h->W("lstm.wih16");
     g.bias = h->W("lstm.b");
     HIPCHK(h, gemm(h, g, EPI_STORE, st));
   }
@@ -704,6 +707,7 @@ int step_group(vapx_engine* h, const Scratch& sc_own, int nb, int b0, const int*
   {  // layer-0 Q|K|V of the NEW row only: they are per-row functions of the embedding, so the other
      // rows' values are cached next to the ring (exact; saves the [rows x 768] GEMM every tick)
     GemmArgs g = gemm_args(sc.en, contiguous_rows(256), h->layer[0].wqkv, nb * 2, 768, 256, sc.qkv_new, contiguous_rows(768));
+    g.W16 = h->W("L0.wqkv16");
     HIPCHK(h, gemm(h, g, EPI_STORE, st));
   }
   GatherArgs ga;
@@ -864,6 +868,17 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
     //  * every weight w satisfies |2^8 w| < 65504 (its f16 hi part is finite);
     //  * the GELU hidden row h = LN_ffn(x) . W0^T obeys |h_j| <= sum_k |W0[j][k]| (16 |gamma_k| + |beta_k|) because a LayerNorm output is
     //    bounded by 16 |gamma| + |beta|: a layer whose bound reaches 2^15 gets a power-of-two down-scale of the hidden operand.
+    // every weight that reaches the split-precision GEMM (gemm(): conv1-4, LSTM input projection, downsample, Combinator) is stored /
+    // converted as 2^8 w in f16 as well
+    for (const char* nm : {"conv1.w", "conv2.w", "conv3.w", "conv4.w", "lstm.wih", "down.w", "comb.wa", "comb.wb"})
+      for (size_t i = 0; i < h->lay_n; ++i)
+        if (!strcmp(h->lay[i].name, nm))
+          for (size_t k = 0; k < h->lay[i].n; ++k)
+            if (!(fabsf(blob[h->lay[i].off + k]) < 255.0f)) {
+              int rc = fail(nullptr, VAPX_E_INVAL, "VAPX_FLAG_SPLIT_F16: a weight of %s has |w| >= 255 (or is not finite); use the fp32 path", nm);
+              vapx_destroy(h);
+              return rc;
+            }
     for (int l = 0; l < 4; ++l) {
       Layer& Lw = h->layer[l];
       auto host = [&](const float* dev) { return blob + (dev - h->w); };

@@ -26,6 +26,8 @@ struct GemmArgs {
   float* C2;
   RowMap c2m;
   int split;   // 1: fp32-accurate 3-term split products on the f16 matrix cores (operands split while staged), see gemm_f32.hip
+  const float* W16;   // split only, optional: pre-split copy of W (weights.split16_pack: same [N][K] addressing, 16 bytes = 4 hi + 4 lo halves
+                      // of 2^8 w) — staged as it is instead of converting W in every k-tile of every workgroup; null: convert on the fly
 };
 
 // tile_rows: 0 = choose from M, else 32 / 64 / 128 rows per workgroup.

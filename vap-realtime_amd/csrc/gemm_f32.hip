@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256, (WM == 4 ? 2 : 2)) void gemm_f32_kernel(const 
     m = m < g.M ? m : g.M - 1;
     aptr[i] = g.A + row_off(g.am, m) + skq;
   }
-  const float* bptr = g.W + (long)(n0 + srow) * g.K + skq;
+  const bool pre16 = SPLIT && g.W16 != nullptr;           // weights arrive pre-split: same addressing, no conversion
+  const float* bptr = (pre16 ? g.W16 : g.W) + (long)(n0 + srow) * g.K + skq;
   const long bstep = (long)32 * g.K;
 
   f32x4 ra[WM], rb[8];
@@ -77,13 +78,22 @@ __global__ __launch_bounds__(256, (WM == 4 ? 2 : 2)) void gemm_f32_kernel(const 
         *(f16x4*)&sAh[(i * 32 + srow) * LDT16 + skq] = hi;
         *(f16x4*)&sAl[(i * 32 + srow) * LDT16 + skq] = lo;
       }
+      if (pre16) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const f32x4 wv = rb[i] * 256.0f;
-        const f16x4 hi = __builtin_convertvector(wv, f16x4);
-        const f16x4 lo = __builtin_convertvector(wv - __builtin_convertvector(hi, f32x4), f16x4);
-        *(f16x4*)&sBh[(i * 32 + srow) * LDT16 + skq] = hi;
-        *(f16x4*)&sBl[(i * 32 + srow) * LDT16 + skq] = lo;
+        for (int i = 0; i < 8; ++i) {
+          const f16x8 hl = __builtin_bit_cast(f16x8, rb[i]);     // [hi x 4 | lo x 4]
+          *(f16x4*)&sBh[(i * 32 + srow) * LDT16 + skq] = __builtin_shufflevector(hl, hl, 0, 1, 2, 3);
+          *(f16x4*)&sBl[(i * 32 + srow) * LDT16 + skq] = __builtin_shufflevector(hl, hl, 4, 5, 6, 7);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const f32x4 wv = rb[i] * 256.0f;
+          const f16x4 hi = __builtin_convertvector(wv, f16x4);
+          const f16x4 lo = __builtin_convertvector(wv - __builtin_convertvector(hi, f32x4), f16x4);
+          *(f16x4*)&sBh[(i * 32 + srow) * LDT16 + skq] = hi;
+          *(f16x4*)&sBl[(i * 32 + srow) * LDT16 + skq] = lo;
+        }
       }
     } else {
 #pragma unroll

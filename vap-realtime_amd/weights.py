@@ -214,11 +214,13 @@ def blob_entries(K: int, mode: str) -> List[Tuple[str, int]]:
     e.append(("cn0.g", DIM)); e.append(("cn0.b", DIM))
     for i, k in zip((1, 2, 3, 4), (8, 4, 4, 4)):
         e.append((f"conv{i}.w", DIM * k * DIM))  # [cout][tap*256+cin]
+        e.append((f"conv{i}.w16", DIM * k * DIM))  # split16_pack copy (opt-in split-precision GEMMs)
         e.append((f"conv{i}.b", DIM))
         e.append((f"cn{i}.g", DIM)); e.append((f"cn{i}.b", DIM))
     for i in (2, 3, 4):
         e.append((f"conv{i}.wf", 4 * DIM * DIM))  # fused conv tail: 4 taps x fragment-major 256x256 block
     e.append(("lstm.wih", LSTM_GATES * DIM))     # [perm row][256]  (plain GEMM operand)
+    e.append(("lstm.wih16", LSTM_GATES * DIM))   # split16_pack copy
     e.append(("lstm.whh", LSTM_GATES * DIM))     # 16x16x4-MFMA fragment-major [8 w][16 kc][8 ns][64 lane][4]
     e.append(("lstm.b", LSTM_GATES))             # b_ih + b_hh, permuted
     e.append(("down.w", DIM * K * DIM))          # [cout][k*256+cin]
@@ -228,6 +230,8 @@ def blob_entries(K: int, mode: str) -> List[Tuple[str, int]]:
         p = f"L{l}"
         e.append((f"{p}.ln_self.g", DIM)); e.append((f"{p}.ln_self.b", DIM))
         e.append((f"{p}.wqkv", 3 * DIM * DIM))     # [Wq;Wk;Wv]  [768][256]
+        if l == 0:
+            e.append((f"{p}.wqkv16", 3 * DIM * DIM))   # split16_pack copy (layer 0: the new row's Q|K|V every tick)
         e.append((f"{p}.wproj", DIM * DIM))
         if l > 0:
             e.append((f"{p}.ln_src.g", DIM)); e.append((f"{p}.ln_src.b", DIM))
@@ -326,6 +330,19 @@ def frag_pack_f16x3_w8(W: np.ndarray, n0: int, k0: int) -> np.ndarray:
     return np.ascontiguousarray(both).reshape(-1).view(np.float32)
 
 
+def split16_pack(W: np.ndarray) -> np.ndarray:
+    """[N][K] GEMM weight (K contiguous) -> its pre-split copy for the split-precision GEMM (csrc/gemm_f32.hip, GemmArgs::W16): w' = 2^8 w =
+    hi + lo (both f16), the SAME [N][K] addressing in 16-byte units — float offset n K + 4 q holds the four hi halves of k = 4 q .. 4 q + 3
+    followed by their four lo halves — so the kernel stages it with the loads it uses for the fp32 matrix and no conversion.  Values
+    beyond the f16 range saturate here; vapx_create refuses VAPX_FLAG_SPLIT_F16 for such a checkpoint (|w| >= 255)."""
+    sub = np.clip(np.ascontiguousarray(W, dtype=np.float32) * np.float32(F16X3_WEIGHT_SCALE), -60000.0, 60000.0)
+    N, K = sub.shape
+    hi = sub.astype(np.float16)
+    lo = (sub - hi.astype(np.float32)).astype(np.float16)
+    both = np.stack([hi.reshape(N, K // 4, 4), lo.reshape(N, K // 4, 4)], axis=2)      # [N][K/4][hi|lo][4]
+    return np.ascontiguousarray(both).reshape(-1).view(np.float32)
+
+
 def frag_pack16(W: np.ndarray) -> np.ndarray:
     """256x256 block [out][in] -> v_mfma_f32_16x16x4_f32 B fragments for 8 waves x 32 output columns:
     out = w*32 + ns*16 + l15, in = kc*16 + kq*4 + u  ->  [w][kc][ns][lane = kq*16 + l15][u]."""
@@ -364,6 +381,7 @@ def pack_blob(cpc_sd: Dict[str, np.ndarray], vap_sd: Dict[str, np.ndarray], mode
     for i in (1, 2, 3, 4):
         w = A(cpc_sd[f"gEncoder.conv{i}.weight"])       # [cout, cin, k]
         put(f"conv{i}.w", w.transpose(0, 2, 1))          # [cout][k][cin]
+        put(f"conv{i}.w16", split16_pack(w.transpose(0, 2, 1).reshape(w.shape[0], -1)))
         if i >= 2:
             put(f"conv{i}.wf", np.concatenate([frag_pack(np.ascontiguousarray(w[:, :, t]), 0, 0) for t in range(4)]))
         put(f"conv{i}.b", A(cpc_sd[f"gEncoder.conv{i}.bias"]))
@@ -373,6 +391,7 @@ def pack_blob(cpc_sd: Dict[str, np.ndarray], vap_sd: Dict[str, np.ndarray], mode
     wih = A(cpc_sd["gAR.baseNet.weight_ih_l0"])[perm]
     whh = A(cpc_sd["gAR.baseNet.weight_hh_l0"])[perm]
     put("lstm.wih", wih)
+    put("lstm.wih16", split16_pack(wih))
     # row = w*128 + ns*16 + l15 ; k = kc*16 + kq*4 + u  ->  [w][kc][ns][lane = kq*16 + l15][u]
     put("lstm.whh", whh.reshape(8, 8, 16, 16, 4, 4).transpose(0, 3, 1, 4, 2, 5))
     put("lstm.b", (A(cpc_sd["gAR.baseNet.bias_ih_l0"]) + A(cpc_sd["gAR.baseNet.bias_hh_l0"]))[perm])
@@ -395,6 +414,9 @@ def pack_blob(cpc_sd: Dict[str, np.ndarray], vap_sd: Dict[str, np.ndarray], mode
         put(f"{p}.wqkv", np.concatenate([A(vap_sd[f"{src}.mha.query.weight"]),
                                           A(vap_sd[f"{src}.mha.key.weight"]),
                                           A(vap_sd[f"{src}.mha.value.weight"])], axis=0))
+        if l == 0:
+            put(f"{p}.wqkv16", split16_pack(np.concatenate([A(vap_sd[f"{src}.mha.query.weight"]), A(vap_sd[f"{src}.mha.key.weight"]),
+                                                             A(vap_sd[f"{src}.mha.value.weight"])], axis=0)))
         put(f"{p}.wproj", A(vap_sd[f"{src}.mha.proj.weight"]))
         if l > 0:
             put(f"{p}.ln_src.g", A(vap_sd[f"{src}.ln_src_attn.weight"]))
