@@ -495,21 +495,25 @@ def paced_latency(cpc, sets, hz, ctx_sec, local_rank, seconds, target_ms=10.0, m
     for Ssub in Ssub_opts:
         ids = np.arange(Ssub, dtype=np.int32)
         ts = []
-        for i in range(16):
+        for i in range(20):
             t1 = time.perf_counter()
             sub_tick(eng, fol, pin_in[i % NF][:Ssub], ids)
             ts.append(time.perf_counter() - t1)
-        sv = float(np.percentile(ts[4:], 95))
+        # upper quartile, not the tail: one host hiccup in a dozen samples must not end the calibration (a box with a noisy host once reported
+        # "0 streams" for C5 because the FIRST candidate's p95 crossed the cut-off); the paced run itself measures the tail
+        sv = float(np.percentile(ts[4:], 75))
         calib[Ssub] = sv * 1e3
         if sv * 1e3 > 0.8 * target_ms:
             break
-        G = min(Gmax, int(max_util * period / sv))
+        # (the paced schedule adds host work the isolated calibration does not see: first runs landed at 0.86-0.95 busy when this aimed
+        # at the bound itself, and every repeat costs `seconds` of wall time; a larger margin under-reports configurations that would have fit)
+        G = min(Gmax, int(0.97 * max_util * period / sv))
         if G >= 1 and (best is None or G * Ssub > best[0] * best[1]):
             best = (G, Ssub)
     for f in fol:
         f.close()
     eng.close()
-    out = {"calibration_subtick_p95_ms": calib, "frame_period_ms": period * 1e3, "target_p99_ms": target_ms, "max_utilisation": max_util,
+    out = {"calibration_subtick_p75_ms": calib, "frame_period_ms": period * 1e3, "target_p99_ms": target_ms, "max_utilisation": max_util,
            "models": [m for m, _ in sets], "gemm_arithmetic": "f16x3 split products" if split_f16 else "fp32 MFMA",
            "method": "one engine, G phase-staggered sub-batches of DISTINCT streams per frame period, wall-clock schedule; latency = "
                      "scheduled audio-ready -> results of every model on host (pinned staging both ways)", "runs": []}
@@ -517,7 +521,9 @@ def paced_latency(cpc, sets, hz, ctx_sec, local_rank, seconds, target_ms=10.0, m
         out["sustained_streams"] = 0
         return out
     G, Ssub = best
-    eng, fol = make_engines(cpc, sets, hz, ctx_sec, G * Ssub, local_rank, groups=2, split_f16=split_f16, max_batch=Ssub)
+    cap = min(max(Ssub_opts), (int(Ssub * 1.12) + 7) // 8 * 8)   # head-room for ONE upward step when the first run leaves slack (coarse calibration grid)
+    eng, fol = make_engines(cpc, sets, hz, ctx_sec, G * cap, local_rank, groups=2, split_f16=split_f16, max_batch=cap)
+    accepted, tried_up = None, False
     import gc
     gc.disable()                                       # a collector pause inside the schedule would be charged to the engine
     for attempt in range(5):
@@ -549,19 +555,35 @@ def paced_latency(cpc, sets, hz, ctx_sec, local_rank, seconds, target_ms=10.0, m
                "gpu_busy_fraction": busy / wall, "late_fraction": float((lat > target_ms).mean())}
         out["runs"].append(run)
         if run["p99_ms"] <= target_ms and run["gpu_busy_fraction"] <= max_util:
-            out["sustained_streams"] = G * Ssub
-            out.update({k: run[k] for k in ("groups", "sub_tick_streams", "p50_ms", "p99_ms", "max_ms", "gpu_busy_fraction")})
+            accepted = run
+            up = min(cap, int(Ssub * 0.99 * max_util / run["gpu_busy_fraction"]) // 8 * 8)
+            if run["gpu_busy_fraction"] < max_util - 0.025 and not tried_up and up > Ssub and attempt < 4:
+                tried_up, Ssub = True, up                # slack: one larger run; whichever of the two meets the bounds is reported
+                continue
+            break
+        if accepted is not None:                         # the upward step overshot: the accepted run stands
             break
         # on time but over the utilisation bound: the busy fraction is linear in the sub-batch size, so go straight to the size that meets
         # it (1 % margin, multiples of 8).  Too late: shed ~6 % of every sub-batch (same schedule) and measure again; then drop a group
         if run["p99_ms"] <= target_ms and attempt < 4 and Ssub >= 64:
-            Ssub = min(Ssub - 8, int(Ssub * max_util / run["gpu_busy_fraction"] * 0.99) // 8 * 8)
+            prev = [r for r in out["runs"][:-1] if r["groups"] == G and r["p99_ms"] <= target_ms]
+            if prev and abs(prev[-1]["gpu_busy_fraction"] - run["gpu_busy_fraction"]) > 1e-3:
+                # two on-time points: the busy fraction is affine in the sub-batch size (a fixed cost per sub-tick + a slope)
+                p0 = prev[-1]
+                slope = (run["gpu_busy_fraction"] - p0["gpu_busy_fraction"]) / (run["sub_tick_streams"] - p0["sub_tick_streams"])
+                est = run["sub_tick_streams"] + (0.99 * max_util - run["gpu_busy_fraction"]) / slope if slope > 0 else Ssub - 8
+            else:
+                est = Ssub * (max_util / run["gpu_busy_fraction"]) ** 1.4 * 0.99
+            Ssub = max(8, min(Ssub - 8, int(est) // 8 * 8))
         elif attempt < 2 and Ssub >= 64:
             Ssub -= max(8, (Ssub // 16) // 8 * 8)
         else:
             G -= 1
         if G < 1:
             break
+    if accepted is not None:
+        out["sustained_streams"] = accepted["streams"]
+        out.update({k: accepted[k] for k in ("groups", "sub_tick_streams", "p50_ms", "p99_ms", "max_ms", "gpu_busy_fraction")})
     out.setdefault("sustained_streams", 0)
     gc.enable()
     for f in fol:
@@ -619,12 +641,12 @@ def main():
     ap.add_argument("--mode", default=None, choices=["vap", "bc", "nod", "bc+nod", "vap+bc+nod"],
                     help="override: model variant; a+b = weight sets served on one shared CPC trunk (one stream-frame = one audio "
                          "frame through the shared encoder and every listed model)")
-    ap.add_argument("--cpu-baseline-sec", type=float, default=8.0, help="timed oracle seconds per distinct record shape")
+    ap.add_argument("--cpu-baseline-sec", type=float, default=6.0, help="timed oracle seconds per distinct record shape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=-1,
                     help="processes of the multi-core CPU leg at the headline shape (-1 = every physical core, 0 = skip)")
     ap.add_argument("--no-latency", action="store_true", help="skip the latency legs, the split-precision side records and the front-end record")
-    ap.add_argument("--paced-sec", type=float, default=12.0, help="duration of each paced many-stream latency run (0 = skip)")
+    ap.add_argument("--paced-sec", type=float, default=10.0, help="duration of each paced many-stream latency run (0 = skip)")
     ap.add_argument("--front-end-streams", type=int, default=4096, help="real-time TCP clients of the front-end record (0 = skip)")
     ap.add_argument("--groups", type=int, default=0, help="intra-tick overlap groups (0 = engine default)")
     ap.add_argument("--split-f16", action="store_true",
