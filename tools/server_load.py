@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--groups", type=int, default=2, help="intra-tick overlap groups of the engine (what vap_realtime_amd.serve uses: 2)")
     ap.add_argument("--repeat", type=int, default=1, help="run the load generator this many times against the SAME server (slot reuse, resets at scale)")
     ap.add_argument("--python", action="store_true", help="serve with the Python front-end instead of the native one")
+    ap.add_argument("--shards", type=int, default=1, help="N engines (all on this GPU: a one-GPU box) behind ONE front door (vapx_frontdoor_*), "
+                    "--streams / N slots each: what `python -m vap_realtime_amd.serve --gpus N --share-gpu` runs")
     ap.add_argument("--fake", action="store_true", help="native front-end over a trivial step function (plumbing only, no GPU)")
     args = ap.parse_args()
     loadgen = os.path.join(ROOT, "tools", "loadgen")
@@ -64,6 +66,32 @@ def main():
             vap = realtime.ManyStreamVAP(cpc, vap_sd, args.hz, args.ctx_sec, n_streams=S, max_batch=args.max_batch or None)
             srv = ManyStreamServer(vap, port_in=0, port_out=0, max_wait_s=args.max_wait_ms * 1e-3).start()
             kind = "Python front-end (server.ManyStreamServer)"
+        elif args.shards > 1:
+            N = args.shards
+            blob = W.pack_blob(cpc, vap_sd)
+            engs = [engine.Engine(blob, args.hz, args.ctx_sec, max_streams=(S + N - 1) // N, max_batch=args.max_batch or None, groups=args.groups) for _ in range(N)]
+            shards = [ingest.NativeServer(e, port_in=-1, port_out=-1, max_wait_s=args.max_wait_ms * 1e-3, min_batch=args.min_batch,
+                                          rx_threads=args.rx_threads, tx_threads=args.tx_threads, target_util=args.target_util) for e in engs]
+            door = ingest.FrontDoor(shards, 0, 0)
+
+            class _Srv:                                   # the load generator's view: one port pair; statistics summed over the shards
+                port_in, port_out = door.port_in, door.port_out
+
+                @staticmethod
+                def stats(reset_latency_window=False):
+                    per = door.stats(reset_latency_window)
+                    tot = {k: sum(p[k] for p in per) for k in ("frames_done", "ticks", "overruns", "dropped_listeners", "numeric_resets")}
+                    tot["per_shard"] = per
+                    tot["front_door"] = door.counts()
+                    return tot
+
+                @staticmethod
+                def stop():
+                    door.close()
+                    for e in engs:
+                        e.close()
+            srv = _Srv
+            kind = f"ONE front door (vapx_frontdoor_*) + {N} passive native front-ends + {N} engines sharing this GPU"
         else:
             eng = engine.Engine(W.pack_blob(cpc, vap_sd), args.hz, args.ctx_sec, max_streams=S, max_batch=args.max_batch or None, groups=args.groups)
             srv = ingest.NativeServer(eng, port_in=0, port_out=0, max_wait_s=args.max_wait_ms * 1e-3, min_batch=args.min_batch,
