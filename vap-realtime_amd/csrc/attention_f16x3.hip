@@ -15,18 +15,21 @@
 //     spent its time converting every K tile 4.5 times and waiting for first round trips: 14.1 ms per C3 tick against 17.4 fp32.)
 //   * the kernel is PERSISTENT (one workgroup per CU walks over its items) and the next item's raw K / V rows are in flight — 16 x 16 bytes
 //     per lane, in registers — while the current item computes: no workgroup ever waits for a cold first load except the very first.
-//   * the MFMA shape is v_mfma_f32_16x16x32_f16: SIXTEEN queries per tile, so the causal triangle splits evenly over the eight waves with
-//     no merging — wave w owns query tiles w and 15 - w, 9 (16 queries x 32 keys) units each, whatever w — and the two tiles of a wave walk
-//     the key tiles together: K and V fragments are fetched once for both, and two independent softmax / MFMA chains interleave.  (With
-//     32-query tiles and one tile per wave the wave with 8 key tiles was the critical path of the item: 11.9 ms per C3 tick.)
+//   * eight waves = one 32-query tile each (v_mfma_f32_32x32x16_f16); wave w takes query tile w (w < 4) or 11 - w, so the two waves of a SIMD
+//     (w, w + 4) together own 9 causal key tiles, every SIMD the same.  (Tried and dropped: SIXTEEN-query tiles on v_mfma_f32_16x16x32_f16,
+//     two per wave — tiles w and 15 - w, 9 units per wave whatever w, K / V fragments shared where both tiles need the same key tile.  Perfectly
+//     balanced, but a 16 x 32 unit costs a wave as long as a 32 x 32 pair does — 0.82 us against 0.81: the step is bound by its fixed VALU /
+//     latency chain, not by the tile area — so the balanced waves were as slow as this kernel's critical one: 11.2 ms per C3 tick against
+//     10.7; git history has it.)
 //
 // No operand can overflow f16, whatever the input.  Q, K and V rows are raw projections (the cross-attention K / V of the RAW residual
 // stream), so every operand carries a power-of-two scale from its own maximum: K and V per item (one block reduction each, sharing the
 // barrier that hands the LDS over), Q per 32-query tile (wave-local); P is in [0, 1] and rides as 2^12 P so that its low half stays
 // clear of the f16 denormals.  All scales are undone in fp32 (the score scale inside the softmax's fma, the V and P scales in the final
-// 1 / l), exactly.  Inside each 32-key tile the key slots of V^T are permuted so that the 8 keys a lane group g = lane >> 4 needs (the keys
-// whose probabilities sit in its 2 x 4 accumulator registers of S^T: 4 g + {0..3} and 16 + 4 g + {0..3}) are one 16-byte read.
-// P never moves: the two score accumulators of a lane, converted, ARE its B operand of O^T = V^T.P^T (one K = 32 MFMA per 16 features).
+// 1 / l), exactly.  Inside each 16-key chunk the key slots of V^T are permuted so that the 8 keys a lane half needs (the keys whose
+// probabilities sit in its 8 accumulator registers of S^T: 16c + 4 hi + {0..3} and 16c + 8 + 4 hi + {0..3}) are one 16-byte read.
+// P never moves: accumulator registers 8c .. 8c+7 of S^T, converted, ARE the B operand of k-chunk c.  The row sum is kept PER LANE and the
+// two lane halves of a query are added once per item.
 #include <algorithm>
 #include <type_traits>
 
@@ -72,8 +75,7 @@ __global__ __launch_bounds__(512, 1) void attention_long_f16x3_kernel(AttnArgs a
   const int T = a.T;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..7
-  // this wave's two 16-query tiles: slot 0 = tile w, slot 1 = tile 15 - w (the longer one: key tiles 0 .. (15 - w) / 2)
-  const int qt[2] = {w, 15 - w};
+  const int it = w < 4 ? w : 11 - w;                          // this wave's 32-query tile: the two waves of a SIMD (w, w + 4) own 9 key tiles together
   const bool ringed = a.ring_rot != nullptr;
   const int dq = tid & 15;                                    // feature quad 4 dq .. 4 dq + 3 of the rows this thread stages
 
@@ -122,12 +124,12 @@ __global__ __launch_bounds__(512, 1) void attention_long_f16x3_kernel(AttnArgs a
     const int rot = ringed ? uniform_load(a.ring_rot, b) : 0;
     const long slab_q = ringed ? ((long)(a.ids ? uniform_load(a.ids, b) : b) * 2 + (bc & 1)) : (long)bc;
     const int nt_valid = (n + 31) >> 5;
-    const int n16 = (n + 15) >> 4;                       // 16-query tiles with valid rows
-    const bool act[2] = {qt[0] < n16, qt[1] < n16};
+    const bool act = it < nt_valid;
     const float slope = exp2f(-2.0f * (float)(h + 1));  // [1/4, 1/16, 1/64, 1/256]
     // (fresh per item: hipcc otherwise hoists every lane-constant table derived from these — key indices, ALiBi biases, mask bounds, LDS
     // addresses — out of the item loop and keeps them live, i.e. spilled, across it)
-    const int r16 = opaque_vgpr(lane & 15), g = opaque_vgpr(lane >> 4);
+    const int l31 = opaque_vgpr(lane & 31), hi = opaque_vgpr(lane >> 5);
+    const float hi4f = (float)(4 * hi);
 #ifdef VAPX_TRACE
     int stamp_k = 0;
     auto STAMP = [&]() {
@@ -141,22 +143,20 @@ __global__ __launch_bounds__(512, 1) void attention_long_f16x3_kernel(AttnArgs a
     auto STAMP = [] {};
     auto FINE = [] {};
 #endif
-    // this wave's query rows: raw fragments (row 16 t + r16 clamped; qraw[s][2c], [2c+1] = features 32 c + 8 g .. + 7, the 8 k-values of this lane
-    // in the 32-feature chunk c — the same 16 bytes of a row-major K row in LDS below) fly while K / V are converted
+    // this wave's query rows: raw fragments (row 32 it + l31 clamped; qraw[2c], qraw[2c+1] = features 16 c + 8 hi .. + 7, the 8 k-values of this
+    // lane half in the 16-feature chunk c — the same 16 bytes of a row-major K row in LDS below) fly while K / V are converted
     // (issued unconditionally — rows beyond the window are clamped anyway — so that hipcc can count them: behind a branch the wait for
     // the K / V rows below becomes vmcnt(0) and sits out a fresh round trip of these eight loads, 2.7 us per item)
-    f32x4 qraw[2][4];
+    f32x4 qraw[8];
+    {
+      int i = it * 32 + l31;
+      i = i < n ? i : n - 1;
+      int r = i + rot;
+      r = r >= T ? r - T : r;
+      const float* qp = a.q + (slab_q * T + r) * a.ldq + h * 64 + hi * 8;
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-      {
-        int i = qt[s] * 16 + r16;
-        i = i < n ? i : n - 1;
-        int r = i + rot;
-        r = r >= T ? r - T : r;
-        const float* qp = a.q + (slab_q * T + r) * a.ldq + h * 64 + g * 8;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) { qraw[s][2 * c] = *(const f32x4*)(qp + c * 32); qraw[s][2 * c + 1] = *(const f32x4*)(qp + c * 32 + 4); }
-      }
+      for (int kc = 0; kc < 8; ++kc) qraw[kc] = *(const f32x4*)(qp + (kc >> 1) * 16 + (kc & 1) * 4);
+    }
     FINE();            // 1: Q loads issued
     __syncthreads();   // A: maxima (taken at the end of the previous item) visible; every wave is done with the previous item's K / V in LDS
     FINE();            // 2: barrier A passed
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(512, 1) void attention_long_f16x3_kernel(AttnArgs a
       for (int u = 0; u < 2; ++u) {
         const int G = u * 32 + (tid >> 4);                   // keys 4 G .. 4 G + 3
         if (4 * G < nt_valid * 32) {
-          const int slot = (G >> 3) * 32 + (G & 3) * 8 + ((G >> 2) & 1) * 4;   // key tile, lane group that consumes the quad, first / second accumulator
+          const int slot = (G >> 2) * 16 + (G & 1) * 8 + ((G >> 1) & 1) * 4;   // 16-key chunk, lane half that consumes the quad, first / second quad
 #pragma unroll
           for (int dd = 0; dd < 4; ++dd) {
             f32x4 y;
@@ -201,169 +201,132 @@ __global__ __launch_bounds__(512, 1) void attention_long_f16x3_kernel(AttnArgs a
     FINE();            // 3: converted, LDS stores issued
     __syncthreads();   // B: K, V^T of this item in LDS
     STAMP();   // 4: staged
-    f16x8 qh[2][2], ql[2][2];
-    float qk[2];
-    float m[2] = {-1e30f, -1e30f}, lp[2] = {0.f, 0.f};          // running maximum, PER-LANE partial sum (its own 8 keys per tile)
-    f32x4 o[2][4];
-    if (act[0]) {   // (slot 1 holds the later rows: act[1] implies act[0])
+    f16x8 qh[4], ql[4];
+    float qk = 0.f;
+    if (act) {
+      float mx = 0.f;
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
-        if (act[s]) {
-          float mx = 0.f;
+      for (int kc = 0; kc < 8; ++kc) mx = max4abs(mx, qraw[kc]);
+      const float sq = pow2_scale_for(wave_max(mx));
 #pragma unroll
-          for (int k = 0; k < 4; ++k) mx = max4abs(mx, qraw[s][k]);
-          const float sq = pow2_scale_for(wave_max(mx));
-#pragma unroll
-          for (int c = 0; c < 2; ++c) split8(qraw[s][2 * c], qraw[s][2 * c + 1], sq, qh[s][c], ql[s][c]);
-          qk[s] = 0.0625f * __builtin_amdgcn_rcpf(sq) * kinv;     // 1 / sqrt(256) x the inverse operand scales
-        }
+      for (int c = 0; c < 4; ++c) split8(qraw[2 * c], qraw[2 * c + 1], sq, qh[c], ql[c]);
+      qk = 0.0625f * __builtin_amdgcn_rcpf(sq) * kinv;       // 1 / sqrt(256) x the inverse operand scales
     }
     FINE();            // 5: Q converted
     // the next item's rows fly under this item's MFMAs (unconditional — the last item re-reads itself — so that hipcc can count the loads)
     issue_kv(item + (int)gridDim.x < a.n_items ? item + (int)gridDim.x : item);
-    if (act[0]) {
+    float m = -1e30f, lp = 0.f;                              // running maximum, PER-LANE partial sum (its own 16 keys per tile)
+    f32x16 o0, o1;
+    const int i = it * 32 + l31;
+    if (act) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+      for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+      FINE();          // 6
+#pragma unroll 1
+      for (int jt = 0; jt <= it; ++jt) {
+        // ---- S^T tile = K_tile . Q^T (x s_k s_q): 12 MFMAs into one accumulator ----
+        f32x16 sc;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) o[s][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int jlast[2] = {qt[0] >> 1, qt[1] >> 1};              // last (diagonal) key tile of each slot
-      // one key tile for the slots S0 .. S1 - 1 ((0, 2): both query tiles, K / V fragments shared; (1, 2): only the longer one; (0, 1): only
-      // the earlier one — the window is still filling and tile 15 - w has no valid row yet)
-      auto step = [&](int jt, auto s0_tag, auto s1_tag) {
-        constexpr int S0 = decltype(s0_tag)::value, S1 = decltype(s1_tag)::value;
-        // ---- S^T = K_tile . Q^T (x s_k s_q): lane (query r16, group g) gets keys 4 g + r (first accumulator) and 16 + 4 g + r ----
-        f32x4 sc[2][2];
+        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
         {
-          f16x8 kh[2][2], kl[2][2];
+          const _Float16* kph = Kh + (jt * 32 + l31) * LDK + hi * 8;
+          const _Float16* kpl = Kl + (jt * 32 + l31) * LDK + hi * 8;
+          f16x8 kh[4], kl[4];
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
+          for (int c = 0; c < 4; ++c) { kh[c] = *(const f16x8*)(kph + c * 16); kl[c] = *(const f16x8*)(kpl + c * 16); }
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-              kh[mt][c] = *(const f16x8*)(Kh + (jt * 32 + mt * 16 + r16) * LDK + c * 32 + g * 8);
-              kl[mt][c] = *(const f16x8*)(Kl + (jt * 32 + mt * 16 + r16) * LDK + c * 32 + g * 8);
-            }
-#pragma unroll
-          for (int s = S0; s < S1; ++s)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) sc[s][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int s = S0; s < S1; ++s)
-#pragma unroll
-              for (int mt = 0; mt < 2; ++mt) {
-                sc[s][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[mt][c], qh[s][c], sc[s][mt], 0, 0, 0);
-                sc[s][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[mt][c], qh[s][c], sc[s][mt], 0, 0, 0);
-                sc[s][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[mt][c], ql[s][c], sc[s][mt], 0, 0, 0);
-              }
-        }
-        // ---- online softmax (as attention_long2_kernel), masked only on the diagonal tile of a slot and the tile with the window end ----
-        f16x8 ph[2], pl[2];
-        const float jb = (float)(jt * 32 + 4 * g);
-#pragma unroll
-        for (int s = S0; s < S1; ++s) {
-          float cm = -1e30f;
-          const bool masked = jt == jlast[s] || (jt + 1) * 32 > n;
-          if (masked) {
-            const int i4 = qt[s] * 16 + r16 - jt * 32 - 4 * g, n4 = n - jt * 32 - 4 * g;     // key C + 4 g is visible iff C <= i4 and C < n4
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int c = mt * 16 + r;
-                float v = fmaf(sc[s][mt][r], qk[s], slope * ((float)c + jb));
-                v = ((c <= i4) && (c < n4)) ? v : -1e30f;
-                sc[s][mt][r] = v;
-                cm = fmaxf(cm, v);
-              }
-          } else {
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float v = fmaf(sc[s][mt][r], qk[s], slope * ((float)(mt * 16 + r) + jb));
-                sc[s][mt][r] = v;
-                cm = fmaxf(cm, v);
-              }
-          }
-          cm = fmaxf(cm, __shfl_xor(cm, 16));
-          cm = fmaxf(cm, __shfl_xor(cm, 32));
-          const float mn = fmaxf(m[s], cm);
-          const float alpha = __expf(m[s] - mn);
-          float sum = 0.f;
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float pv = __expf(sc[s][mt][r] - mn);
-              if (masked) pv = sc[s][mt][r] > -1e29f ? pv : 0.f;
-              sc[s][mt][r] = pv;
-              sum += pv;
-            }
-          lp[s] = lp[s] * alpha + sum;
-          m[s] = mn;
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt) o[s][mt] *= alpha;
-          split8(sc[s][0], sc[s][1], kPScale, ph[s], pl[s]);
-        }
-        // ---- O^T = alpha O^T + V_tile^T . P^T   (x s_v 2^12): lane (query r16, group g) gets features 16 mt + 4 g + r ----
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          const f16x8 vh = *(const f16x8*)(Vh + (mt * 16 + r16) * LDV + jt * 32 + g * 8);
-          const f16x8 vl = *(const f16x8*)(Vl + (mt * 16 + r16) * LDV + jt * 32 + g * 8);
-#pragma unroll
-          for (int s = S0; s < S1; ++s) {
-            o[s][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[s], o[s][mt], 0, 0, 0);
-            o[s][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[s], o[s][mt], 0, 0, 0);
-            o[s][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[s], o[s][mt], 0, 0, 0);
+          for (int c = 0; c < 4; ++c) {
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[c], qh[c], sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[c], qh[c], sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[c], ql[c], sc, 0, 0, 0);
           }
         }
-      };
-      using I0 = std::integral_constant<int, 0>;
-      using I1 = std::integral_constant<int, 1>;
-      using I2 = std::integral_constant<int, 2>;
-      if (act[1]) {
-#pragma unroll 1
-        for (int jt = 0; jt <= jlast[0]; ++jt) step(jt, I0{}, I2{});
-        FINE();        // 6: key tiles shared by both query tiles done
-#pragma unroll 1
-        for (int jt = jlast[0] + 1; jt <= jlast[1]; ++jt) step(jt, I1{}, I2{});
-        FINE();        // 7: remaining key tiles of the longer query tile done
-      } else {
-#pragma unroll 1
-        for (int jt = 0; jt <= jlast[0]; ++jt) step(jt, I0{}, I1{});
+        // ---- online softmax update for this 32-key tile (as attention_long2_kernel): sc := P.  accumulator r <-> key
+        //      j = 32 jt + C_r + 4 hi with C_r = (r&3) + 8 (r>>2).  MASKED only for the diagonal tile (causal) and the tile with the window end ----
+        float cm = -1e30f;
+        const float jb = (float)(jt * 32) + hi4f;
+        const bool masked = jt == it || (jt + 1) * 32 > n;
+        if (masked) {
+          const int i4 = i - jt * 32 - 4 * hi, n4 = n - jt * 32 - 4 * hi;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = (r & 3) + 8 * (r >> 2);
+            float v = fmaf(sc[r], qk, slope * ((float)c + jb));
+            v = ((c <= i4) && (c < n4)) ? v : -1e30f;
+            sc[r] = v;
+            cm = fmaxf(cm, v);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = (r & 3) + 8 * (r >> 2);
+            const float v = fmaf(sc[r], qk, slope * ((float)c + jb));
+            sc[r] = v;
+            cm = fmaxf(cm, v);
+          }
+        }
+        cm = fmaxf(cm, __shfl_xor(cm, 32));
+        const float mn = fmaxf(m, cm);
+        const float alpha = __expf(m - mn);
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float p = __expf(sc[r] - mn);
+          if (masked) p = sc[r] > -1e29f ? p : 0.f;
+          sc[r] = p;
+          sum += p;
+        }
+        lp = lp * alpha + sum;
+        m = mn;
+        // ---- O^T = alpha O^T + V_tile^T . P^T   (x s_v 2^12) ----
+        const _Float16* vh = Vh + l31 * LDV + jt * 32 + hi * 8;
+        const _Float16* vl = Vl + l31 * LDV + jt * 32 + hi * 8;
+        f16x8 v0h[2], v1h[2], v0l[2], v1l[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          v0h[c] = *(const f16x8*)(vh + c * 16); v1h[c] = *(const f16x8*)(vh + 32 * LDV + c * 16);
+          v0l[c] = *(const f16x8*)(vl + c * 16); v1l[c] = *(const f16x8*)(vl + 32 * LDV + c * 16);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          f16x8 ph, pl;
+          split8(f32x4{sc[8 * c], sc[8 * c + 1], sc[8 * c + 2], sc[8 * c + 3]}, f32x4{sc[8 * c + 4], sc[8 * c + 5], sc[8 * c + 6], sc[8 * c + 7]},
+                 kPScale, ph, pl);
+          o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h[c], ph, o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h[c], ph, o1, 0, 0, 0);
+          o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0l[c], ph, o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1l[c], ph, o1, 0, 0, 0);
+          o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h[c], pl, o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h[c], pl, o1, 0, 0, 0);
+        }
       }
+      FINE();          // 7: key tiles done
     }
     take_maxima();     // (next item's rows: issued a whole compute phase ago)
     FINE();            // 8: next item's rows arrived, maxima taken
-    if (act[0]) {
-      // ---- store: accumulator (mt, r) <-> feature 16 mt + 4 g + r of query row 16 t + r16 ----
+    if (act) {
+      // ---- store: accumulator r of o0 / o1 <-> feature (r&3) + 8 (r>>2) + 4 hi (+ 32) of query row i ----
+      const float l = lp + __shfl_xor(lp, 32);
+      if (i < T) {
+        float* op = a.out + ((long)bc * T + i) * 256 + h * 64;
+        const float scl = i < n ? vinv * (1.0f / kPScale) / l : 0.f;         // rows beyond the valid window: deterministic zeros
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
-        if (act[s]) {
-          float l = lp[s];
-          l += __shfl_xor(l, 16);
-          l += __shfl_xor(l, 32);
-          const int i = qt[s] * 16 + r16;
-          if (i < T) {
-            float* op = a.out + ((long)bc * T + i) * 256 + h * 64 + g * 4;
-            const float scl = i < n ? vinv * (1.0f / kPScale) / l : 0.f;         // rows beyond the valid window: deterministic zeros
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) *(f32x4*)(op + mt * 16) = o[s][mt] * scl;
-          }
-        }
-    }
-    // whole 16-query tiles beyond the valid rows: deterministic zeros
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-      if (!act[s]) {
-        const int i = qt[s] * 16 + r16;
-        if (i < T) {
-          float* op = a.out + ((long)bc * T + i) * 256 + h * 64 + g * 4;
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt) *(f32x4*)(op + mt * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int rr = 0; rr < 4; ++rr) {
+          f32x4 v0 = {o0[rr * 4 + 0], o0[rr * 4 + 1], o0[rr * 4 + 2], o0[rr * 4 + 3]};
+          f32x4 v1 = {o1[rr * 4 + 0], o1[rr * 4 + 1], o1[rr * 4 + 2], o1[rr * 4 + 3]};
+          *(f32x4*)(op + rr * 8 + hi * 4) = v0 * scl;
+          *(f32x4*)(op + 32 + rr * 8 + hi * 4) = v1 * scl;
         }
       }
+    } else if (it * 32 < T) {                               // whole tile beyond the valid rows: deterministic zeros
+      if (i < T) {
+        float* op = a.out + ((long)bc * T + i) * 256 + h * 64;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) *(f32x4*)(op + hi * 32 + d * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
     STAMP();   // 9: outputs stored
 #ifdef VAPX_TRACE
     if (a.trace && tid == 0 && item < 16384) { a.trace[(long)item * 32 + 29] = __builtin_amdgcn_s_memrealtime(); a.trace[(long)item * 32 + 30] = (unsigned long long)stamp_k; }
