@@ -82,6 +82,18 @@ struct PerDeviceOnce {
   }
 };
 
+// compute units of the current device (cached per device): grid size of the persistent kernels
+inline int device_cu_count() {
+  static std::mutex mu;
+  static int cus[64] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(mu);
+  int& c = cus[dev & 63];
+  if (c == 0 && (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0)) c = 256;
+  return c;
+}
+
 // The same value as a NEW SSA definition the optimiser cannot look through: index expressions derived from it are not commoned with
 // the ones of an earlier kernel phase, so they die with their phase instead of occupying registers across the whole kernel
 // (hipcc otherwise keeps e.g. the 32 accumulator-row indices of a 64-row tile live from the softmax to the final stores and spills).
