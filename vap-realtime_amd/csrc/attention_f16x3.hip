@@ -334,21 +334,6 @@ __global__ __launch_bounds__(512, 1) void attention_long_f16x3_kernel(AttnArgs a
   }
 }
 
-struct DeviceCUs {
-  std::mutex mu;
-  int cus[64] = {0};
-  int get() {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lk(mu);
-    int& c = cus[dev & 63];
-    if (c == 0) {
-      if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
-    }
-    return c;
-  }
-};
-
 }  // namespace
 
 hipError_t launch_attention_f16x3(const AttnArgs& a, int B, hipStream_t st) {
@@ -358,10 +343,9 @@ hipError_t launch_attention_f16x3(const AttnArgs& a, int B, hipStream_t st) {
   const size_t lds = (size_t)2 * 256 * LDK * sizeof(_Float16) + (size_t)2 * 64 * LDV * sizeof(_Float16) + 16 * sizeof(float);
   static PerDeviceOnce attr_set;
   attr_set.run([] { (void)hipFuncSetAttribute((const void*)attention_long_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-  static DeviceCUs cus;
   AttnArgs b = a;
   b.n_items = B * 8;                                       // (stream, channel, head)
-  const int grid = std::min(b.n_items, cus.get());         // persistent: one workgroup per CU
+  const int grid = std::min(b.n_items, device_cu_count());         // persistent: one workgroup per CU
   hipLaunchKernelGGL(attention_long_f16x3_kernel, dim3(grid), dim3(512), lds, st, b);
   return hipGetLastError();
 }
