@@ -377,11 +377,14 @@ def run_workload(name, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=0, split
         wl.step(i, defer_join=defer_join)
     if defer_join:
         wl.eng.join(wl.stream)
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0                              # this rank's own K steps (reported per rank; `value` uses the max below)
     barrier()
     dt = time.perf_counter() - t0
 
     dom_ms, dom_launches = wl.profile_read()[dominant]
     wl.profile_enable([])
+    dt_rank = dist_util.gather_floats(dist, [dt_own])                 # every rank's own time for its K steps
     dt = dist_util.max_over_ranks(dist, dt, "cuda")
     for o in [wl.d_out] + wl.d_out_f:
         assert torch.isfinite(o[:, :6]).all(), "non-finite outputs"
@@ -433,6 +436,7 @@ def run_workload(name, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=0, split
                    "gemm_arithmetic": ("f16x3 split products, fp32 accumulate" if split_f16 else "fp32 MFMA"),
                    "parallelism": f"stream-sharded x{world}, no collective"},
         "parity_gate": gate,
+        "per_rank": ({"value_min": S * steps / max(t[0] for t in dt_rank), "value_max": S * steps / min(t[0] for t in dt_rank)} if world > 1 else None),
         "realtime_streams_sustained": value / hz,
         "executed_gflop_per_stream_frame": exec_gflop, "executed_gflop_per_stream_frame_causal_attention": exec_gflop_causal,
         "executed_tflops": value * exec_gflop / 1e3,
@@ -462,14 +466,15 @@ def cpu_baseline_record(twin: OracleTwin, wl_cfg, seconds: float):
             "ms_per_frame": cdt / n * 1e3}
 
 
-def paced_latency(cpc, sets, hz, ctx_sec, local_rank, seconds, target_ms=10.0, max_util=0.85, split_f16=False):
+def paced_latency(cpc, sets, hz, ctx_sec, local_rank, seconds, target_ms=10.0, max_util=0.85, split_f16=False, accept_ms=9.0):
     """The north-star latency target measured, not extrapolated: ONE engine (plus trunk followers for bc+nod) holding G x Ssub
     DISTINCT streams, its G sub-batches phase-staggered over the frame period (50 ms at 20 Hz, 20 ms at 50 Hz) on a wall-clock
     schedule for `seconds`; latency of a sub-tick = its scheduled audio-ready time -> results of EVERY model on the host (pinned
     H2D + kernels + D2H + sync, including any wait behind a late predecessor).  A short calibration picks the largest G x Ssub
     whose sub-tick service time keeps the GPU under `max_util`; if the paced run misses p99 <= target or the utilisation bound it
     is repeated: on time but too busy -> the sub-batch size that meets the bound (busy time is linear in it); late -> ~6 % fewer streams per
-    sub-batch (up to twice), then one group smaller."""
+    sub-batch (up to twice), then one group smaller.  A run is ACCEPTED only at p99 <= `accept_ms` (9 ms): a point 0.1 ms under the
+    10 ms limit is an edge, not a sustained figure (round-3 verdict: C3 at p99 9.90 ms); the next point down is reported instead."""
     from vap_realtime_amd import engine
     period = 1.0 / hz
     hop = 16000 // hz
@@ -513,7 +518,7 @@ def paced_latency(cpc, sets, hz, ctx_sec, local_rank, seconds, target_ms=10.0, m
     for f in fol:
         f.close()
     eng.close()
-    out = {"calibration_subtick_p75_ms": calib, "frame_period_ms": period * 1e3, "target_p99_ms": target_ms, "max_utilisation": max_util,
+    out = {"calibration_subtick_p75_ms": calib, "frame_period_ms": period * 1e3, "target_p99_ms": target_ms, "accept_p99_ms": accept_ms, "max_utilisation": max_util,
            "models": [m for m, _ in sets], "gemm_arithmetic": "f16x3 split products" if split_f16 else "fp32 MFMA",
            "method": "one engine, G phase-staggered sub-batches of DISTINCT streams per frame period, wall-clock schedule; latency = "
                      "scheduled audio-ready -> results of every model on host (pinned staging both ways)", "runs": []}
@@ -554,7 +559,7 @@ def paced_latency(cpc, sets, hz, ctx_sec, local_rank, seconds, target_ms=10.0, m
                "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)), "max_ms": float(lat.max()),
                "gpu_busy_fraction": busy / wall, "late_fraction": float((lat > target_ms).mean())}
         out["runs"].append(run)
-        if run["p99_ms"] <= target_ms and run["gpu_busy_fraction"] <= max_util:
+        if run["p99_ms"] <= accept_ms and run["gpu_busy_fraction"] <= max_util:
             accepted = run
             up = min(cap, int(Ssub * 0.99 * max_util / run["gpu_busy_fraction"]) // 8 * 8)
             if run["gpu_busy_fraction"] < max_util - 0.025 and not tried_up and up > Ssub and attempt < 4:
@@ -565,8 +570,8 @@ def paced_latency(cpc, sets, hz, ctx_sec, local_rank, seconds, target_ms=10.0, m
             break
         # on time but over the utilisation bound: the busy fraction is linear in the sub-batch size, so go straight to the size that meets
         # it (1 % margin, multiples of 8).  Too late: shed ~6 % of every sub-batch (same schedule) and measure again; then drop a group
-        if run["p99_ms"] <= target_ms and attempt < 4 and Ssub >= 64:
-            prev = [r for r in out["runs"][:-1] if r["groups"] == G and r["p99_ms"] <= target_ms]
+        if run["p99_ms"] <= accept_ms and attempt < 4 and Ssub >= 64:
+            prev = [r for r in out["runs"][:-1] if r["groups"] == G and r["p99_ms"] <= accept_ms]
             if prev and abs(prev[-1]["gpu_busy_fraction"] - run["gpu_busy_fraction"]) > 1e-3:
                 # two on-time points: the busy fraction is affine in the sub-batch size (a fixed cost per sub-tick + a slope)
                 p0 = prev[-1]
@@ -608,12 +613,22 @@ def gather_paced(dist, rank, world, rec):
     return rec
 
 
-def front_end_record(streams: int, seconds: float):
+def front_end_record(streams: int, seconds: float, devices=None):
     """The native TCP front-end (vapx_ingest_*) + one engine under tools/loadgen: `streams` real-time dialogue clients sending the
-    reference's 10 ms packets (2560 B, vap_main.py:373-391), every result packet (12 880 B at 20 Hz) read back and timed."""
+    reference's 10 ms packets (2560 B, vap_main.py:373-391), every result packet (12 880 B at 20 Hz) read back and timed.
+    `devices` (multi-GPU job): one engine per listed GPU behind ONE port pair (vapx_frontdoor_*, what `serve --gpus N` runs; the
+    reference's single port pair, vap_main.py:338-366), `streams` clients in total."""
     cmd = [sys.executable, os.path.join(ROOT, "tools", "server_load.py"), "--streams", str(streams), "--seconds", str(seconds), "--warm", "4"]
+    if devices and len(devices) > 1:
+        cmd += ["--shards", str(len(devices)), "--devices", ",".join(str(d) for d in devices)]
+
+    def unpin():                                                       # the server of ALL shards must not inherit rank 0's core pinning
+        try:
+            os.sched_setaffinity(0, range(os.cpu_count() or 1))
+        except Exception:
+            pass
     try:
-        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=seconds + 240)
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=seconds + 240, preexec_fn=unpin)
         line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]
         r = json.loads(line)
         keep = ("streams", "frames_sent", "frames_answered", "stream_frames_per_s", "realtime_streams_served", "lat_p50_ms", "lat_p99_ms",
@@ -621,10 +636,121 @@ def front_end_record(streams: int, seconds: float):
         rec = {k: r[k] for k in keep if k in r}
         st = r.get("server_stats", {})
         rec["server_latency_ms"] = {k: st[k] for k in st if k.startswith("lat_")}
+        if devices and len(devices) > 1:
+            rec["shards"] = len(devices)
+            rec["front_door"] = st.get("front_door")
+            rec["frames_done_per_shard"] = [p_.get("frames_done") for p_ in st.get("per_shard", [])]
         rec["how"] = "tools/server_load.py: native front-end + engine on this GPU, tools/loadgen on the same host (loopback TCP), reference wire format"
         return rec
     except Exception as e:                                        # noqa: BLE001 - a side record must not cost the headline
         return {"error": f"{type(e).__name__}: {e}"}
+
+COMPACT_LIMIT = 4096          # bytes: the driver keeps an 8 KB tail of stdout; round 3's 30.8 KB line could not be parsed
+
+
+def _r(x, sig=5):
+    """Round a float to `sig` significant digits (ints, None, bools pass through) — keeps the compact line short."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    x = float(x)
+    if not np.isfinite(x):
+        return None
+    return float(f"{x:.{sig}g}")
+
+
+def _sub_summary(rec):
+    """One-number-per-question summary of a sub-record (c2 / s4096_20hz / c5): fp32 and split."""
+    if not isinstance(rec, dict) or "value" not in rec:
+        return {"error": str(rec.get("error", "no record"))[:80]} if isinstance(rec, dict) else {"error": "no record"}
+    out = {"value": _r(rec["value"]), "ms_per_step": _r(rec["ms_per_step"], 4), "frac": _r(rec["roofline"]["frac"], 3),
+           "kernel": rec["roofline"]["kernel"], "parity_worst_abs": _r(rec["parity_gate"]["worst_abs"], 3)}
+    if "concurrent_streams_at_10ms" in rec:
+        out["streams_at_10ms"] = rec["concurrent_streams_at_10ms"]
+        out["p99_ms"] = _r(rec.get("paced_latency", {}).get("p99_ms"), 3)
+    sp = rec.get("split_f16")
+    if isinstance(sp, dict) and "value" in sp:
+        out["split"] = {"value": _r(sp["value"]), "frac": _r(sp["roofline"]["frac"], 3)}
+        if "concurrent_streams_at_10ms" in sp:
+            out["split"]["streams_at_10ms"] = sp["concurrent_streams_at_10ms"]
+            out["split"]["p99_ms"] = _r(sp.get("paced_latency", {}).get("p99_ms"), 3)
+    elif isinstance(sp, dict) and "error" in sp:
+        out["split"] = {"error": sp["error"][:80]}
+    if "cpu_baseline" in rec:
+        out["cpu_frames_per_s"] = _r(rec["cpu_baseline"]["value"], 4)
+    return out
+
+
+def compact_line(result: dict, full_path: str = "") -> str:
+    """The LAST stdout line of bench.py: the contract keys of the task prompt + one-number summaries of the sub-records, strict JSON
+    (no NaN / Infinity), < COMPACT_LIMIT bytes.  The complete record (every sub-record's breakdown, paced runs, gates) goes to a file
+    (`full_path`), never to stdout.  tests/test_bench_line.py holds this against a canned round-3 record."""
+    roof = result["roofline"]
+    cfg = result["config"]
+    line = {
+        "metric": result["metric"], "value": _r(result["value"], 7), "unit": result["unit"], "n_gpus": result["n_gpus"], "steps": result["steps"],
+        "warmup": result["warmup"], "ms_per_step": _r(result["ms_per_step"], 6), "timed_seconds": _r(result.get("timed_seconds"), 5),
+        "higher_is_better": True, "scaling": result.get("scaling", "weak"), "vs_baseline": result.get("vs_baseline"), "dtype": result["dtype"],
+        "data": "synthetic (seeded dialogue audio + seeded random weights)",
+        "config": {"workload": cfg["workload"], "streams_per_gpu": cfg["streams_per_gpu"], "streams_total": cfg["streams_total"],
+                   "frame_hz": cfg["frame_hz"], "ctx_frames": cfg["ctx_frames"], "mode": cfg["mode"], "parallelism": cfg["parallelism"]},
+        "parity_gate": {"ok": result["parity_gate"]["ok"], "worst_abs": _r(result["parity_gate"]["worst_abs"], 3),
+                        "tolerance_abs": result["parity_gate"]["tolerance_abs"]},
+        "roofline": {"bound": roof["bound"], "kernel": roof["kernel"], "achieved": _r(roof["achieved"]), "peak": _r(roof["peak"]),
+                     "unit": roof["unit"], "frac": _r(roof["frac"], 4), "traffic": _r(roof.get("traffic")), "avg_launch_us": _r(roof["avg_launch_us"]),
+                     "launches_per_step": _r(roof["launches_per_step"], 3)},
+    }
+    if "executed_frac_of_fp32_mfma_peak" in result:
+        line["executed_tflops"] = _r(result["executed_tflops"], 4)
+    cb = result.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": _r(cb["value"], 4), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "sample": cb["sample"][:150], "ms_per_frame": _r(cb.get("ms_per_frame"), 4)}
+    cm = result.get("cpu_baseline_multiprocess")
+    if cm:
+        line["cpu_all_cores"] = {"value": _r(cm["value"], 4), "cores": cm["cores"]}
+    if "concurrent_streams_at_10ms" in result:
+        line["concurrent_streams_at_10ms"] = result["concurrent_streams_at_10ms"]
+        line["paced_p99_ms"] = _r(result.get("paced_latency", {}).get("p99_ms"), 3)
+    sp = result.get("split_f16")
+    if isinstance(sp, dict) and "value" in sp:
+        line["split_f16"] = {"value": _r(sp["value"]), "ms_per_step": _r(sp["ms_per_step"], 4), "frac": _r(sp["roofline"]["frac"], 3),
+                             "kernel": sp["roofline"]["kernel"], "parity_worst_abs": _r(sp["parity_gate"]["worst_abs"], 3)}
+        if "concurrent_streams_at_10ms" in sp:
+            line["split_f16"]["streams_at_10ms"] = sp["concurrent_streams_at_10ms"]
+    elif isinstance(sp, dict) and "error" in sp:
+        line["split_f16"] = {"error": sp["error"][:80]}
+    if result.get("per_rank"):
+        line["per_rank"] = result["per_rank"]
+    if result.get("configs"):
+        line["configs"] = {k: _sub_summary(v) for k, v in result["configs"].items()}
+    fe = result.get("front_end")
+    if isinstance(fe, dict):
+        line["front_end"] = ({"error": str(fe["error"])[:80]} if "error" in fe else
+                             {k: _r(fe.get(k)) for k in ("streams", "shards", "frames_sent", "frames_answered", "lat_p50_ms", "lat_p99_ms", "lat_max_ms", "late_over_10ms")
+                              if fe.get(k) is not None})
+    if full_path:
+        line["full_record"] = full_path
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    for drop in ("cpu_all_cores", "front_end", "configs", "split_f16"):      # never reached with today's records; the contract keys always survive
+        if len(text) < COMPACT_LIMIT:
+            break
+        line.pop(drop, None)
+        text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    assert len(text) < COMPACT_LIMIT, len(text)
+    return text
+
+
+def _jsonable(o):
+    """The full record as strict JSON: non-finite floats -> None."""
+    if isinstance(o, dict):
+        return {str(k): _jsonable(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_jsonable(v) for v in o]
+    if isinstance(o, (float, np.floating)):
+        return float(o) if np.isfinite(o) else None
+    if isinstance(o, np.integer):
+        return int(o)
+    return o
 
 
 def main():
@@ -655,6 +781,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--share-gpu", action="store_true",
                     help="plumbing check on a 1-GPU box: every rank uses device 0 (combine with --backend gloo; RCCL cannot put two ranks on one device)")
+    ap.add_argument("--full-record", default="bench_full.json", help="file name of the complete record (written under gpurun_out/, else the repo root)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="multi-rank plumbing check without a GPU: spawn, rendezvous, shard the streams, barrier, print the ranks")
     args = ap.parse_args()
@@ -670,7 +797,7 @@ def main():
     from vap_realtime_amd.sharding import shard_streams
     rank, local_rank, world = dist_util.env_rank()
     dev_index = 0 if args.share_gpu else local_rank
-    pinned = dist_util.pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), device_index=dev_index)
+    pinned = dist_util.pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), device_index=dev_index, shared=args.share_gpu)
 
     if args.rendezvous_only:
         dist = dist_util.init("gloo")
@@ -813,8 +940,13 @@ def main():
         rec, _ = full_record(name, cS, chz, cctx, cmode, csteps, cwarm)
         result["configs"][name] = rec
 
-    if rank == 0 and world == 1 and side and args.front_end_streams > 0:
-        result["front_end"] = front_end_record(args.front_end_streams, 10.0)
+    if side and args.front_end_streams > 0:
+        # every rank's engines are closed by now; rank 0 serves `front_end_streams` real-time TCP clients — one engine per GPU of the
+        # job behind ONE port pair when world > 1 — while the other ranks wait in a CPU (gloo) rendezvous, their GPUs idle
+        if rank == 0:
+            devs = [0] * world if args.share_gpu else list(range(world))
+            result["front_end"] = front_end_record(args.front_end_streams, 10.0, devices=devs if world > 1 else None)
+        dist_util.gather_ints(dist, [rank])
 
     if rank == 0 and not args.no_cpu_baseline and mode == "vap":
         P = args.cpu_procs if args.cpu_procs >= 0 else physical_cores()
@@ -838,7 +970,21 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        # the complete record goes to a file; stdout carries exactly ONE line: the compact record (< 4 KB, strict JSON)
+        result = _jsonable(result)
+        full_path = ""
+        for d in (os.path.join(ROOT, "gpurun_out"), ROOT, "/tmp"):
+            try:
+                os.makedirs(d, exist_ok=True)
+                fp = os.path.join(d, args.full_record)
+                with open(fp, "w") as f:
+                    json.dump(result, f, allow_nan=False)
+                full_path = os.path.relpath(fp, ROOT) if fp.startswith(ROOT) else fp
+                break
+            except OSError:
+                continue
+        sys.stdout.flush()
+        print(compact_line(result, full_path), flush=True)
 
 
 if __name__ == "__main__":

@@ -382,3 +382,40 @@ def test_one_front_door_routes_dialogues_over_two_back_ends_and_reconnects_stick
         assert door.counts() == {"accepted_in": 5, "accepted_out": 4, "refused": 1}
     finally:
         door.close()
+
+
+def test_front_door_over_single_slot_shards_spreads_the_output_connections():
+    """serve.py's default is --streams 1: every per-GPU front-end is then in BROADCAST mode (all its output connections hear its one
+    dialogue, as the reference's single-client server does).  Behind the front door the k-th output connection must still hear dialogue k,
+    i.e. GPU k mod N — round 3 skipped broadcast shards in the routing loop and every listener landed on shard 0 (advisor finding)."""
+    hop = 800
+    models = [TaggedModel(10.0), TaggedModel(20.0)]
+    shards = [ingest.NativeServer.over_function(m.step, 1, 20, reset=m.reset, max_wait_s=0.05, port_in=-1, port_out=-1) for m in models]
+    door = ingest.FrontDoor(shards, port_in=0, port_out=0)
+    try:
+        ins, outs = [], []
+        for k in range(2):
+            ins.append(socket.create_connection(("127.0.0.1", door.port_in)))
+            _wait(lambda: door.counts()["accepted_in"] == k + 1)
+        for k in range(4):                                                  # two listeners per dialogue
+            outs.append(socket.create_connection(("127.0.0.1", door.port_out)))
+            _wait(lambda: door.counts()["accepted_out"] == k + 1)
+        assert [s.stats()["out_connections"] for s in shards] == [2, 2]
+        x = np.random.default_rng(3).standard_normal((2, 2, hop)) * np.array([0.2, 1.5])[:, None, None]
+        for k in range(2):
+            ins[k].sendall(wire.encode_input(x[k, 0], x[k, 1]))
+        for j in range(4):                                                  # output connection j hears dialogue j mod 2 (GPU j mod 2)
+            _, r = _read_result(outs[j])
+            np.testing.assert_array_equal(r["x1"], x[j % 2, 0])
+            assert r["vad"][0] == models[j % 2].tag
+    finally:
+        door.close()
+        for s_ in ins + outs:
+            s_.close()
+
+
+def test_a_half_passive_front_end_is_a_configuration_error():
+    m = TaggedModel(1.0)
+    for pin, pout in ((-1, 0), (0, -1)):
+        with pytest.raises(Exception):
+            ingest.NativeServer.over_function(m.step, 2, 20, port_in=pin, port_out=pout)

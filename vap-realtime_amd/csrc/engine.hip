@@ -226,8 +226,11 @@ void geometry(int hz, int* hop, int* L, int P[5], int* ncpc) {
   *ncpc = P[4] - 2;
 }
 
-// kernel classes for profiling: 0..5 = GEMM by epilogue, then the rest
-enum { CLS_CONVTAIL = 5, CLS_FFN = 6, CLS_LASTROW = 7, CLS_CONV0 = 8, CLS_LSTM = 9, CLS_GATHER = 10, CLS_ATTN = 11, CLS_HEAD = 12, CLS_COUNT = 13 };
+// kernel classes for profiling: 0..4 = GEMM by epilogue (EPI_STORE .. EPI_CN_RELU), then the rest; EPI_BIAS_LN_GELU (= 5 as an epilogue id)
+// is booked as class 13 — 5 is the fused conv tail (round 3 booked both under 5: a follower's downsample GEMM was priced as conv_tail)
+enum { CLS_CONVTAIL = 5, CLS_FFN = 6, CLS_LASTROW = 7, CLS_CONV0 = 8, CLS_LSTM = 9, CLS_GATHER = 10, CLS_ATTN = 11, CLS_HEAD = 12,
+       CLS_GEMM_BIAS_LN_GELU = 13, CLS_COUNT = 14 };
+static inline int gemm_class(int epi) { return epi == EPI_BIAS_LN_GELU ? CLS_GEMM_BIAS_LN_GELU : epi; }
 
 struct ProfScope {
   vapx_engine* h; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; int cls;
@@ -252,7 +255,7 @@ struct ProfScope {
 // bounded_A: the A operand is bounded by construction (a LayerNorm / ChannelNorm+ReLU output, LSTM outputs): only then may the opt-in
 // split-precision product run (f16 operands overflow at 65504); GEMMs on RAW residual-stream / attention rows stay on the fp32 MFMA
 hipError_t gemm(vapx_engine* h, const GemmArgs& g, int epi, hipStream_t st, bool bounded_A = true) {
-  ProfScope ps(h, epi, st);
+  ProfScope ps(h, gemm_class(epi), st);
   if ((h->cfg.flags & VAPX_FLAG_SPLIT_F16) && bounded_A) {
     GemmArgs gs = g;
     gs.split = 1;

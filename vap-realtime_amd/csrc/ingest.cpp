@@ -565,16 +565,18 @@ void tx_main(vapx_ingest* g) {
   std::vector<uint8_t> tail(64 + 8 * 256);
   const int hop = g->hop;
   while (true) {
-    // claim a chunk of rows of the oldest job that still has some (claims and completions are serialised by job_mu: a
-    // few thousand lock operations per second, and a recycled Job can never be touched through a stale index)
+    // claim a chunk of rows of the OLDEST job (claims and completions are serialised by job_mu: a few thousand lock operations per
+    // second).  Jobs are sent strictly one after the other: a job leaves the queue when its last row has been SENT, not when its last row
+    // has been claimed — otherwise a thread could send stream s's frame of tick k + 1 while another thread is still working through the
+    // chunk of tick k that holds s's previous frame, and a listener would see the two packets in the wrong order (round 4: found by
+    // tests/test_ingest.py::test_random_segmentation...: frames 1 and 2 of one stream swapped in 1 of 3 runs).
     int j = -1, k0 = 0, k1 = 0;
     {
       std::unique_lock<std::mutex> lk(g->job_mu);
       for (;;) {
-        while (!g->job_queue.empty() && g->jobs[g->job_queue.front()].claimed >= g->jobs[g->job_queue.front()].n) g->job_queue.pop_front();
-        if (!g->job_queue.empty()) break;
+        if (!g->job_queue.empty() && g->jobs[g->job_queue.front()].claimed < g->jobs[g->job_queue.front()].n) break;
         if (g->stop.load()) return;
-        g->job_cv.wait(lk);
+        g->job_cv.wait(lk);                  // nothing queued, or the front job is fully claimed and its last chunks are still being sent
       }
       j = g->job_queue.front();
       Job& job = g->jobs[j];
@@ -622,7 +624,12 @@ void tx_main(vapx_ingest* g) {
     {
       std::lock_guard<std::mutex> lk(g->job_mu);
       job.finished += k1 - k0;
-      if (job.finished >= job.n) { job.busy = false; g->job_done_cv.notify_all(); }
+      if (job.finished >= job.n) {           // every packet of this tick is out: the next tick's rows may go (and the Job may be reused)
+        if (!g->job_queue.empty() && g->job_queue.front() == j) g->job_queue.pop_front();
+        job.busy = false;
+        g->job_done_cv.notify_all();
+        g->job_cv.notify_all();
+      }
     }
   }
 }
@@ -772,6 +779,7 @@ int open_common(vapx_ingest* g, const vapx_ingest_config* cfg) {
   if (!g->stage || !g->batch_audio || !g->jobs[0].out || !g->jobs[1].out) return VAPX_E_NOMEM;
   // port_in < 0: a PASSIVE shard of a multi-GPU front door (vapx_frontdoor_open): it listens on nothing, connections are handed to it
   const bool passive = cfg->port_in < 0;
+  if (passive != (cfg->port_out < 0)) return VAPX_E_INVAL;   // a shard is passive on BOTH ports or on none (-1 / >= 0 mixed is a configuration error)
   if (!passive) {
     g->lin = listen_on(cfg->port_in, cfg->bind_any != 0, &g->port_in);
     g->lout = listen_on(cfg->port_out, cfg->bind_any != 0, &g->port_out);
@@ -940,7 +948,12 @@ void frontdoor_main(vapx_frontdoor* d) {
       const uint64_t kind = evs[i].data.u64 & ~0xffffffffull;
       for (;;) {
         int fd = accept4(kind == K_LISTEN_IN ? d->lin : d->lout, nullptr, nullptr, SOCK_NONBLOCK);
-        if (fd < 0) break;
+        if (fd < 0) {
+          // out of descriptors: the listen socket stays readable (level-triggered), so epoll_wait would return at once and this thread
+          // would spin at 100 % — back off until a connection closes
+          if (errno == EMFILE || errno == ENFILE || errno == ENOBUFS || errno == ENOMEM) std::this_thread::sleep_for(std::chrono::milliseconds(20));
+          break;
+        }
         if (kind == K_LISTEN_IN) {
           bool placed = false;
           for (int attempt = 0; attempt < N && !placed; ++attempt) {      // (a shard can fill up between the query and the adoption)
@@ -959,8 +972,11 @@ void frontdoor_main(vapx_frontdoor* d) {
         } else {
           int who = 0; long bestc = -1, bestg = -1;
           for (int k = 0; k < N; ++k) {
-            if (d->shards[k]->broadcast) continue;
-            const auto c = next_listener_slot(d->shards[k]);
+            // a broadcast shard (one dialogue slot: serve.py's default --streams 1) is ONE candidate: (its listener count, slot 0) — so the
+            // k-th output connection hears GPU k mod N's dialogue instead of every listener piling up on shard 0
+            std::pair<int, int> c;
+            if (d->shards[k]->broadcast) { std::lock_guard<std::mutex> lk(d->shards[k]->slots_mu); c = {(int)d->shards[k]->out_all.size(), 0}; }
+            else c = next_listener_slot(d->shards[k]);
             const long gslot = (long)c.second * N + k;
             if (bestc < 0 || c.first < bestc || (c.first == bestc && gslot < bestg)) { bestc = c.first; bestg = gslot; who = k; }
           }
@@ -980,7 +996,7 @@ int vapx_frontdoor_open(vapx_ingest_handle* shards, int32_t n_shards, int32_t po
                         vapx_frontdoor_handle* out) {
   if (!shards || n_shards < 1 || !out || port_in < 0 || port_out < 0) return VAPX_E_INVAL;
   for (int k = 0; k < n_shards; ++k) {
-    if (!shards[k] || shards[k]->lin >= 0) return VAPX_E_INVAL;      // shards must be passive (vapx_ingest_config.port_in = -1)
+    if (!shards[k] || shards[k]->lin >= 0 || shards[k]->lout >= 0) return VAPX_E_INVAL;   // shards must be passive (port_in = port_out = -1)
     if (shards[k]->hz != shards[0]->hz || shards[k]->mode != shards[0]->mode) return VAPX_E_INVAL;
   }
   vapx_frontdoor* d = new vapx_frontdoor();

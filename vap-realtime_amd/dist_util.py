@@ -51,12 +51,13 @@ def _parse_cpulist(txt: str):
     return cpus
 
 
-def pin_rank_to_cores(local_rank: int, local_world: int, device_index=None):
+def pin_rank_to_cores(local_rank: int, local_world: int, device_index=None, shared: bool = False):
     """Pin this process to host cores near its GPU: the NUMA node of the GPU's PCI function when sysfs exposes it
     (shared evenly by the ranks of that node), else an even split of the visible cores.  The host side of a shard (audio
-    staging, result fan-out) then stays off the other ranks' cores.  ``device_index`` = the torch device this rank really uses
-    when it is not ``local_rank`` (``--share-gpu``, a remapped CUDA_VISIBLE_DEVICES); ranks on one device share its node's cores
-    evenly.  Returns the core list or None (single rank / no affinity support)."""
+    staging, result fan-out) then stays off the other ranks' cores.  ``shared`` = every rank uses device ``device_index``
+    (``--share-gpu``: said explicitly, so that all ranks — rank 0 included, whose device index equals its rank — compute the SAME
+    rank -> NUMA-node table and their core splits cannot overlap); otherwise rank r uses device r (clamped to the visible devices).
+    Ranks on one node share its cores evenly.  Returns the core list or None (single rank / no affinity support)."""
     if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
         return None
     try:
@@ -68,9 +69,7 @@ def pin_rank_to_cores(local_rank: int, local_world: int, device_index=None):
                 nodes = []
                 ndev = torch.cuda.device_count()
                 for r in range(local_world):
-                    # device of rank r: everyone on `device_index` when it was given and differs from the rank (shared GPU),
-                    # else rank r -> device r (clamped to the visible devices)
-                    d = device_index if (device_index is not None and device_index != local_rank) else min(r, ndev - 1)
+                    d = int(device_index or 0) if shared else min(r, ndev - 1)
                     p = torch.cuda.get_device_properties(d)
                     bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
                     with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
@@ -138,6 +137,19 @@ def gather_ints(dist, values, device: Optional[str] = None):
     if device and device != "cpu" and "nccl" not in str(dist.get_backend()):
         device = "cpu"
     t = torch.tensor(list(values), dtype=torch.int64, device=device or "cpu")
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [o.tolist() for o in out]
+
+
+def gather_floats(dist, values, device: Optional[str] = None):
+    """all_gather of equal-length float lists: one list per rank (the bench's per-rank rates next to the max-over-ranks time)."""
+    if dist is None:
+        return [list(values)]
+    import torch
+    if device and device != "cpu" and "nccl" not in str(dist.get_backend()):
+        device = "cpu"
+    t = torch.tensor(list(values), dtype=torch.float64, device=device or "cpu")
     out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
     return [o.tolist() for o in out]

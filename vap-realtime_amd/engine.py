@@ -32,7 +32,8 @@ EXPORTS = ("vapx_abi_version", "vapx_blob_floats", "vapx_create", "vapx_destroy"
            "vapx_wire_decode_input", "vapx_wire_encode_result", "vapx_vap_head", "vapx_va_classifier", "vapx_softmax256",
            "vapx_aggregate", "vapx_frontdoor_open", "vapx_frontdoor_ports", "vapx_frontdoor_counts", "vapx_frontdoor_close")
 PROF_CLASSES = {0: "gemm_store", 1: "gemm_gelu", 2: "gemm_resid", 3: "gemm_resid_ln", 4: "gemm_cn_relu",
-                5: "conv_tail", 6: "ffn_block", 7: "last_row", 8: "conv0", 9: "lstm", 10: "gather_ln", 11: "attention", 12: "head"}
+                5: "conv_tail", 6: "ffn_block", 7: "last_row", 8: "conv0", 9: "lstm", 10: "gather_ln", 11: "attention", 12: "head",
+                13: "gemm_bias_ln_gelu"}
 
 
 class VapxError(RuntimeError):
@@ -312,9 +313,10 @@ class Engine:
 
     def profile_read(self) -> dict:
         """{class_name: (total_ms, launches)} since the last read (synchronises the device)."""
-        ms = (C.c_double * 13)()
-        cnt = (C.c_int64 * 13)()
-        self._check(self.lib.vapx_profile_read(self._h, ms, cnt, 13), "vapx_profile_read")
+        n = len(PROF_CLASSES)
+        ms = (C.c_double * n)()
+        cnt = (C.c_int64 * n)()
+        self._check(self.lib.vapx_profile_read(self._h, ms, cnt, n), "vapx_profile_read")
         return {PROF_CLASSES[i]: (ms[i], cnt[i]) for i in PROF_CLASSES if cnt[i]}
 
     def peek(self, name: str, shape) -> np.ndarray:
@@ -342,11 +344,11 @@ class TrunkGroup:
     entry leads (runs the encoder), the others follow.  ``step`` returns ``{mode: out[n, OUT_STRIDE]}``."""
 
     def __init__(self, blobs: dict, frame_hz: int = 20, context_len_sec: float = 2.5, max_streams: int = 1,
-                 max_batch: Optional[int] = None, device_id: int = 0):
+                 max_batch: Optional[int] = None, device_id: int = 0, **engine_kw):
         self.modes = list(blobs)
         self.engines = {}
-        for m in self.modes:
-            self.engines[m] = Engine(blobs[m], frame_hz, context_len_sec, max_streams, max_batch, m, device_id)
+        for m in self.modes:                                   # engine_kw: groups / split_f16 / ... — the same for every weight set
+            self.engines[m] = Engine(blobs[m], frame_hz, context_len_sec, max_streams, max_batch, m, device_id, **engine_kw)
         self.leader = self.engines[self.modes[0]]
         for m in self.modes[1:]:
             self.engines[m].attach_trunk(self.leader)
