@@ -312,12 +312,13 @@ def test_library_twin_vap_class_with_microphone_sources(tmp_path):
     vap._stop_worker = True
 
 
-@pytest.mark.parametrize("gpus", [1, 2])
-def test_serve_program_end_to_end(gpus):
+@pytest.mark.parametrize("gpus,precision", [(1, "fp32"), (2, "fp32"), (1, "split")], ids=["1", "2", "1-split"])
+def test_serve_program_end_to_end(gpus, precision):
     """``python -m vap_realtime_amd.serve`` — the twin of ``python vap_main.py --vap_model ... --port_num_in ... --gpu`` (vap_main.py:461-530)
     for many dialogues: started as a subprocess with the reference's argument names, fed the golden audio over TCP, answers compared
     with the golden of the imported reference; SIGTERM stops it.  gpus = 2: two engines (both on this box's one GPU, ``--share-gpu``)
-    behind ONE port pair — the front door sends dialogue k to engine k mod 2, every dialogue still gets its own golden numbers."""
+    behind ONE port pair — the front door sends dialogue k to engine k mod 2, every dialogue still gets its own golden numbers.
+    ``--precision split``: the served engine runs the opt-in split-precision path (dedicated GPU), same golden, same tolerance."""
     import os
     import re
     import signal
@@ -329,7 +330,7 @@ def test_serve_program_end_to_end(gpus):
     proc = subprocess.Popen([sys.executable, "-u", "-m", "vap_realtime_amd.serve", "--synthetic-weights", str(c.seed), "--streams", "4",
                              "--port_num_in", "0", "--port_num_out", "0", "--vap_process_rate", str(c.frame_hz),
                              "--context_len_sec", str(c.ctx_sec), "--gpu", "--stats_sec", "0"]
-                            + (["--gpus", str(gpus), "--share-gpu"] if gpus > 1 else []),
+                            + (["--gpus", str(gpus), "--share-gpu"] if gpus > 1 else []) + ["--precision", precision],
                             cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     try:
         line = ""

@@ -67,3 +67,30 @@ def test_offline_driver_matches_reference_offline_golden():
         np.testing.assert_allclose(r["p_future"], c.z["p_future"][f][0], rtol=0, atol=1e-4)
     for f, r in enumerate(res[1]):     # the shorter copy of the same dialogue gives the same prefix
         np.testing.assert_allclose(r["p_now"], res[0][f]["p_now"], rtol=0, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_offline_poisoned_recording_fails_by_default_and_follows_the_reference_on_request():
+    """A NaN sample in one recording: the reference's vap_offline.py keeps writing nan rows for that file (no check, vap_offline.py:62-73);
+    here that is `on_numeric="reference"` (nan rows for the poisoned dialogue only, the other dialogue bit-identical to a clean run), and
+    the default fails loudly."""
+    from golden_util import Case
+    from vap_realtime_amd.engine import VapxError
+    from vap_realtime_amd.realtime import ManyStreamVAP
+    c = Case("offline20")
+    n = c.hop * 12 + 320
+    clean = (c.audio[0, 0, :n].copy(), c.audio[0, 1, :n].copy())
+    bad = (clean[0].copy(), clean[1].copy())
+    bad[0][c.hop * 5 + 400] = np.nan                                   # inside frame 5's new samples
+    vap = ManyStreamVAP(c.cpc_sd, c.vap_sd, c.frame_hz, c.ctx_sec, n_streams=2)
+    ref = offline.run_offline(vap, [clean, clean])
+    for s in (0, 1):
+        vap.reset(s)
+    with pytest.raises(VapxError):
+        offline.run_offline(vap, [clean, bad])
+    for s in (0, 1):
+        vap.reset(s)
+    res = offline.run_offline(vap, [clean, bad], on_numeric="reference")
+    assert [r["p_now"] for r in res[0]] == [r["p_now"] for r in ref[0]]            # the healthy dialogue is untouched
+    assert all(np.isfinite(r["p_now"]).all() for r in res[1][:5])
+    assert all(np.isnan(r["p_now"]).all() and np.isnan(r["p_future"]).all() for r in res[1][5:]) and len(res[1]) == 12

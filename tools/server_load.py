@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--shards", type=int, default=1, help="N engines (all on this GPU: a one-GPU box) behind ONE front door (vapx_frontdoor_*), "
                     "--streams / N slots each: what `python -m vap_realtime_amd.serve --gpus N --share-gpu` runs")
     ap.add_argument("--devices", default="", help="with --shards N: comma list of N device ids, one engine per listed GPU (default: all on device 0)")
+    ap.add_argument("--split-f16", action="store_true", help="engines on the opt-in split-precision path (serve --precision split)")
+    ap.add_argument("--mode", default="vap", choices=["vap", "bc", "nod"])
     ap.add_argument("--fake", action="store_true", help="native front-end over a trivial step function (plumbing only, no GPU)")
     args = ap.parse_args()
     loadgen = os.path.join(ROOT, "tools", "loadgen")
@@ -61,7 +63,7 @@ def main():
         kind = "native front-end over a trivial step function"
     else:
         from vap_realtime_amd import realtime, weights as W
-        cpc, vap_sd = W.synthetic_weights(0, args.hz)
+        cpc, vap_sd = W.synthetic_weights(0, args.hz, args.mode)
         if args.python:
             from vap_realtime_amd.server import ManyStreamServer
             vap = realtime.ManyStreamVAP(cpc, vap_sd, args.hz, args.ctx_sec, n_streams=S, max_batch=args.max_batch or None)
@@ -69,11 +71,11 @@ def main():
             kind = "Python front-end (server.ManyStreamServer)"
         elif args.shards > 1:
             N = args.shards
-            blob = W.pack_blob(cpc, vap_sd)
+            blob = W.pack_blob(cpc, vap_sd, args.mode)
             devs = [int(d) for d in args.devices.split(",") if d != ""] or [0] * N
             assert len(devs) == N, "--devices needs one id per shard"
             engs = [engine.Engine(blob, args.hz, args.ctx_sec, max_streams=(S + N - 1) // N, max_batch=args.max_batch or None, groups=args.groups,
-                                  device_id=devs[k]) for k in range(N)]
+                                  device_id=devs[k], mode=args.mode, split_f16=args.split_f16) for k in range(N)]
             shards = [ingest.NativeServer(e, port_in=-1, port_out=-1, max_wait_s=args.max_wait_ms * 1e-3, min_batch=args.min_batch,
                                           rx_threads=args.rx_threads, tx_threads=args.tx_threads, target_util=args.target_util) for e in engs]
             door = ingest.FrontDoor(shards, 0, 0)
@@ -97,7 +99,8 @@ def main():
             srv = _Srv
             kind = f"ONE front door (vapx_frontdoor_*) + {N} passive native front-ends + {N} engines on devices {devs}"
         else:
-            eng = engine.Engine(W.pack_blob(cpc, vap_sd), args.hz, args.ctx_sec, max_streams=S, max_batch=args.max_batch or None, groups=args.groups)
+            eng = engine.Engine(W.pack_blob(cpc, vap_sd, args.mode), args.hz, args.ctx_sec, max_streams=S, max_batch=args.max_batch or None, groups=args.groups,
+                                mode=args.mode, split_f16=args.split_f16)
             srv = ingest.NativeServer(eng, port_in=0, port_out=0, max_wait_s=args.max_wait_ms * 1e-3, min_batch=args.min_batch,
                                       rx_threads=args.rx_threads, tx_threads=args.tx_threads, target_util=args.target_util)
             kind = "native front-end (vapx_ingest_*) + engine"

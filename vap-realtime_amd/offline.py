@@ -42,10 +42,17 @@ def frame_starts(n_samples: int, frame: int) -> range:
     return range(0, last + 1, shift) if last >= 0 else range(0)
 
 
-def run_offline(vap, dialogues: Sequence[Tuple[np.ndarray, np.ndarray]]) -> List[List[Dict]]:
+def run_offline(vap, dialogues: Sequence[Tuple[np.ndarray, np.ndarray]], on_numeric: str = "raise") -> List[List[Dict]]:
     """``vap``: object with ``.hop`` and ``.process(frames[n,2,hop+320], stream_ids) -> dict`` (``ManyStreamVAP``).
     ``dialogues``: (left, right) float32 arrays.  Returns per dialogue the list of
-    ``{"t", "p_now", "p_future"}`` rows."""
+    ``{"t", "p_now", "p_future"}`` rows.
+
+    ``on_numeric``: a recording with a NaN / Inf sample poisons its LSTM state for good.  The reference keeps going and writes
+    ``nan`` rows for the rest of that file (``vap_offline.py:62-73`` has no check); the default here is to FAIL (``"raise"``: a batch
+    job should not fill files with ``nan`` silently).  ``"reference"`` reproduces the reference: the poisoned dialogue's rows are
+    ``nan`` from that frame on, every other dialogue of the batch is unaffected (streams are independent)."""
+    if on_numeric not in ("raise", "reference"):
+        raise ValueError("on_numeric must be 'raise' or 'reference'")
     frame = vap.hop + 320
     starts = [frame_starts(min(len(l), len(r)), frame) for l, r in dialogues]
     n_frames = [len(s) for s in starts]
@@ -57,7 +64,8 @@ def run_offline(vap, dialogues: Sequence[Tuple[np.ndarray, np.ndarray]]) -> List
             i = starts[d][f]
             batch[k, 0] = dialogues[d][0][i:i + frame]
             batch[k, 1] = dialogues[d][1][i:i + frame]
-        out = vap.process(batch, np.asarray(ids, np.int32))
+        out = (vap.process(batch, np.asarray(ids, np.int32)) if on_numeric == "raise"
+               else vap.process(batch, np.asarray(ids, np.int32), on_numeric="status"))
         for k, d in enumerate(ids):
             results[d].append({"t": float(starts[d][f] + frame) / SR,
                                "p_now": [float(v) for v in out["p_now"][k]],
@@ -84,12 +92,14 @@ def main(argv=None):
     ap.add_argument("--pairs", nargs="+", required=True, help="left.wav:right.wav[:out.txt] ...")
     ap.add_argument("--vap_process_rate", type=int, default=20)
     ap.add_argument("--context_len_sec", type=float, default=5)
+    ap.add_argument("--on_numeric", choices=["raise", "reference"], default="raise",
+                    help="a NaN / Inf sample: fail (default) or, like the reference, keep writing nan rows for that file")
     args = ap.parse_args(argv)
     cpc_sd, vap_sd = realtime._load_state_dicts(args.vap_model, args.cpc_model)
     specs = [p.split(":") for p in args.pairs]
     dialogues = [(read_wav_mono(s[0]), read_wav_mono(s[1])) for s in specs]
     vap = realtime.ManyStreamVAP(cpc_sd, vap_sd, args.vap_process_rate, args.context_len_sec, n_streams=len(dialogues))
-    for k, rows in enumerate(run_offline(vap, dialogues)):
+    for k, rows in enumerate(run_offline(vap, dialogues, on_numeric=args.on_numeric)):
         out = specs[k][2] if len(specs[k]) > 2 else f"output_offline_{k}.txt"
         write_csv(out, rows)
         print("Generated output file: ", out)

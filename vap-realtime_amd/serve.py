@@ -3,8 +3,9 @@
 MANY GPUs behind the reference's ONE port pair.  One process: one engine per GPU (``vapx_create`` with ``device_id = r``), one passive native
 front-end per engine (its own receive / tick / send threads, ``vapx_ingest_*``), and one front door (``vapx_frontdoor_*``) that owns
 ``port_num_in`` / ``port_num_out`` and hands every accepted connection to a GPU.  Dialogue k lands on GPU ``k mod N`` (lowest free global slot) and
-stays there — its state lives there; there is no collective.  Same argument names as the reference plus ``--streams`` (slots per GPU), ``--gpus``
-and ``--mode``.
+stays there — its state lives there; there is no collective.  Same argument names as the reference plus ``--streams`` (slots per GPU), ``--gpus``,
+``--mode`` and ``--precision {fp32,split}`` (``split`` = the opt-in split-precision engine for a dedicated node: C5 at >= 4096 streams per GPU
+within 10 ms needs it).
 
     python -m vap_realtime_amd.serve --vap_model asset/vap/vap_state_dict_jp_20hz_2500msec.pt --cpc_model asset/cpc/60k_epoch4-d0f474de.pt \\
         --streams 4096 --gpus 8
@@ -36,7 +37,8 @@ def build(args):
             dev = 0 if args.share_gpu else r
             eng = engine.Engine(blob, args.vap_process_rate, args.context_len_sec, max_streams=args.streams,
                                 max_batch=min(args.streams, args.max_batch), mode=mode, device_id=dev,
-                                groups=2)   # two intra-tick overlap groups: ragged ticks of a few hundred streams get 20 % shorter
+                                groups=2,   # two intra-tick overlap groups: ragged ticks of a few hundred streams get 20 % shorter
+                                split_f16=(args.precision == "split"))
             engines.append(eng)
             passive = n > 1
             shards.append(ingest.NativeServer(eng, port_in=-1 if passive else args.port_num_in, port_out=-1 if passive else args.port_num_out,
@@ -73,6 +75,10 @@ def main(argv=None) -> int:
     ap.add_argument("--streams", type=int, default=1, help="dialogue slots per GPU (the reference serves exactly one)")
     ap.add_argument("--max_batch", type=int, default=1024)
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--precision", choices=["fp32", "split"], default="fp32",
+                    help="fp32: every contraction on the fp32 MFMA (default; safe next to other tenants).  split: VAPX_FLAG_SPLIT_F16 — the same "
+                         "contractions as fp32-accurate 3-term f16 split products, ~2x the streams per GPU at the same <= 1e-4 parity; for a "
+                         "DEDICATED GPU/node (a process that issues f16 MFMAs all day can disturb co-running tenants: DESIGN.md \"co-running f16 MFMA\")")
     ap.add_argument("--share-gpu", dest="share_gpu", action="store_true", help="plumbing check on a 1-GPU box: every shard's engine on device 0")
     ap.add_argument("--max_wait_ms", type=float, default=2.0)
     ap.add_argument("--rx_threads", type=int, default=4)
@@ -90,7 +96,7 @@ def main(argv=None) -> int:
         print(f"[vapx] start-up failed: {e}", file=sys.stderr, flush=True)
         return 1
     pin, pout = (door.port_in, door.port_out) if door else (shards[0].port_in, shards[0].port_out)
-    print(f"[vapx] {len(engines)} GPU(s) x {args.streams} dialogue slots, mode {mode}, {args.vap_process_rate} Hz / {args.context_len_sec} s — "
+    print(f"[vapx] {len(engines)} GPU(s) x {args.streams} dialogue slots, mode {mode}, {args.precision} arithmetic, {args.vap_process_rate} Hz / {args.context_len_sec} s — "
           f"input :{pin}, output :{pout}" + (" (front door: dialogue k -> GPU k mod N)" if door else ""), flush=True)
     last = time.time()
     while not stop["now"]:

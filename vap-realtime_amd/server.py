@@ -14,8 +14,10 @@ single client and runs inference inline in the receive loop (rvap/vap_main/vap_m
   one became ready (ragged ticks: only the ready streams are stepped);
 * result packets are byte-identical in layout to ``util.conv_vapresult_2_bytearray``.
 
-The model object only needs ``.hop``, ``.mode``, ``.n_streams``, ``.process(new_samples, ids)`` and
-``.reset(id)`` (``realtime.ManyStreamVAP``).
+The model object only needs ``.hop``, ``.mode``, ``.n_streams``, ``.reset(id)`` and
+``.process(new_samples, ids, on_numeric="status")`` (``realtime.ManyStreamVAP``): with ``on_numeric="status"`` a non-finite stream
+is reported through ``result["status"]`` instead of an exception, so that the other streams of the tick are still served.  A model
+whose ``process`` only takes ``(new_samples, ids)`` works too (no ``status`` key = nothing flagged).
 """
 from __future__ import annotations
 
@@ -143,7 +145,10 @@ class ManyStreamServer:
             return
         frames = self.asm.pop(ready)
         echo = self.asm.last_echo
-        res = self.vap.process(frames, ready.astype(np.int32), on_numeric="status")
+        try:
+            res = self.vap.process(frames, ready.astype(np.int32), on_numeric="status")
+        except TypeError:                                 # a user-supplied model with the two-argument contract
+            res = self.vap.process(frames, ready.astype(np.int32))
         t = time.time()
         # a stream whose results are not finite (poisoned state, engine status column) is reset and gets no packet this
         # tick; every other stream of the batch is served as usual

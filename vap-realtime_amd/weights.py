@@ -293,6 +293,7 @@ def frag_pack(W: np.ndarray, n0: int, k0: int) -> np.ndarray:
 
 
 F16X3_WEIGHT_SCALE = 256.0   # weights are split as 2^8 w so that the low part stays a normal f16 (undone exactly in the kernel)
+F16X3_SAT = 255.0 * 256.0    # the one bound of every f16 weight copy: |w| < 255 (csrc/engine.hip vapx_create checks the same number)
 
 
 def frag_pack_f16x3(W: np.ndarray, n0: int, k0: int) -> np.ndarray:
@@ -303,8 +304,7 @@ def frag_pack_f16x3(W: np.ndarray, n0: int, k0: int) -> np.ndarray:
     accumulators then hold ADJACENT columns, so every epilogue access (global stores / residual loads, f16 (hi, lo) LDS stores) moves
     two values per instruction."""
     sub = np.ascontiguousarray(W[n0:n0 + 256, k0:k0 + 256], dtype=np.float32) * np.float32(F16X3_WEIGHT_SCALE)
-    if np.abs(sub).max() >= 60000.0:
-        raise ValueError("weights too large for the split-f16 path (|w| >= 234)")
+    sub = np.clip(sub, -F16X3_SAT, F16X3_SAT)                # only |w| >= 255 saturates: vapx_create refuses the split path for those
     hi = sub.astype(np.float16)
     lo = (sub - hi.astype(np.float32)).astype(np.float16)
 
@@ -319,8 +319,7 @@ def frag_pack_f16x3_w8(W: np.ndarray, n0: int, k0: int) -> np.ndarray:
     the 32 output columns 32 w .. 32 w + 31.  w' = 2^8 w = hi + lo (both f16), order [8 wave][16 kc][2 hi/lo][64 lane][8] with
     value = w'[n0 + 32w + (lane&31)][k0 + 16kc + 8(lane>>5) + i]; returned as a float32 container (65536)."""
     sub = np.ascontiguousarray(W[n0:n0 + 256, k0:k0 + 256], dtype=np.float32) * np.float32(F16X3_WEIGHT_SCALE)
-    if np.abs(sub).max() >= 60000.0:
-        raise ValueError("weights too large for the split-f16 path (|w| >= 234)")
+    sub = np.clip(sub, -F16X3_SAT, F16X3_SAT)                # only |w| >= 255 saturates: vapx_create refuses the split path for those
     hi = sub.astype(np.float16)
     lo = (sub - hi.astype(np.float32)).astype(np.float16)
 
@@ -333,9 +332,11 @@ def frag_pack_f16x3_w8(W: np.ndarray, n0: int, k0: int) -> np.ndarray:
 def split16_pack(W: np.ndarray) -> np.ndarray:
     """[N][K] GEMM weight (K contiguous) -> its pre-split copy for the split-precision GEMM (csrc/gemm_f32.hip, GemmArgs::W16): w' = 2^8 w =
     hi + lo (both f16), the SAME [N][K] addressing in 16-byte units — float offset n K + 4 q holds the four hi halves of k = 4 q .. 4 q + 3
-    followed by their four lo halves — so the kernel stages it with the loads it uses for the fp32 matrix and no conversion.  Values
-    beyond the f16 range saturate here; vapx_create refuses VAPX_FLAG_SPLIT_F16 for such a checkpoint (|w| >= 255)."""
-    sub = np.clip(np.ascontiguousarray(W, dtype=np.float32) * np.float32(F16X3_WEIGHT_SCALE), -60000.0, 60000.0)
+    followed by their four lo halves — so the kernel stages it with the loads it uses for the fp32 matrix and no conversion.  ONE bound
+    for every f16 copy (here, frag_pack_f16x3, frag_pack_f16x3_w8, vapx_create): |w| < 255, i.e. |2^8 w| < 65280 (f16 max 65504).  Larger
+    values saturate at +-65280 in the copies — the fp32 path never reads them — and vapx_create refuses VAPX_FLAG_SPLIT_F16 for exactly
+    those checkpoints, so no weight the split path accepts is ever altered."""
+    sub = np.clip(np.ascontiguousarray(W, dtype=np.float32) * np.float32(F16X3_WEIGHT_SCALE), -F16X3_SAT, F16X3_SAT)
     N, K = sub.shape
     hi = sub.astype(np.float16)
     lo = (sub - hi.astype(np.float32)).astype(np.float16)
