@@ -77,10 +77,18 @@ __global__ __launch_bounds__(512, 1) void attention_long_f16x3_kernel(AttnArgs a
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..7
   const int it = w < 4 ? w : 11 - w;                          // this wave's 32-query tile: the two waves of a SIMD (w, w + 4) own 9 key tiles together
   const bool ringed = a.ring_rot != nullptr;
-  const int dq = tid & 15;                                    // feature quad 4 dq .. 4 dq + 3 of the rows this thread stages
+  const int dq = tid & 15;                                    // K: feature quad 4 dq .. 4 dq + 3 of the rows this thread stages
+  // V: thread -> (feature quad dqv, key quad gv) chosen so that the TRANSPOSED LDS stores are bank-conflict-free.  A ds_write_b64 is served
+  // in groups of 16 consecutive lanes over 32 banks; a thread writes 8 bytes of row 4 dqv + dd at key slot(G), and rows 4 apart differ by
+  // 16 banks only — so with lanes = dqv (round 3) a group's 16 stores fell on two bank pairs: 8-way conflicts, 59 % of the kernel's
+  // LDS-array cycles (profiles/r03_c3_split_pmc.txt).  Now a group holds 2 feature quads (banks +0 / +16) x 8 key quads, whose slots
+  // (G>>2)*16 + (G&1)*8 + ((G>>1)&1)*4 halves land on dword offsets {0,4,2,6,8,12,10,14}: 16 distinct bank pairs.  Global loads: one
+  // wave instruction still reads whole 64-byte lines (8 keys x 128 contiguous bytes).
+  const int dqv = (tid & 1) | (((tid >> 4) & 3) << 1) | (((tid >> 6) & 1) << 3);
+  const int gv = ((tid >> 1) & 7) | (((tid >> 7) & 3) << 3);   // 0..31: key quad within a round of 32
 
-  // raw K / V rows of the item being staged next: thread (key = (u*512 + tid) >> 4, dq) for K; for V four CONSECUTIVE keys per round
-  // (4 x 4 block, transposed in registers when it goes to LDS)
+  // raw K / V rows of the item being staged next: thread (key = (u*512 + tid) >> 4, dq) for K; for V four CONSECUTIVE keys 4 G .. 4 G + 3
+  // (G = u*32 + gv) x feature quad dqv per round (4 x 4 block, transposed in registers when it goes to LDS)
   f32x4 kr[8], vr[8];
   auto issue_kv = [&](int item) {
     const int h = item & 3, bc = item >> 2, b = bc >> 1;
@@ -89,7 +97,7 @@ __global__ __launch_bounds__(512, 1) void attention_long_f16x3_kernel(AttnArgs a
     const int kvbc = a.swap_kv ? (bc ^ 1) : bc;
     const long slab_kv = ringed ? ((long)(a.ids ? uniform_load(a.ids, b) : b) * 2 + (bc & 1)) : (long)kvbc;
     const float* kp = a.k + slab_kv * T * a.ldkv + h * 64 + dq * 4;     // item-uniform part + this thread's feature quad
-    const float* vp = a.v + slab_kv * T * a.ldkv + h * 64 + dq * 4;
+    const float* vp = a.v + slab_kv * T * a.ldkv + h * 64 + dqv * 4;
     auto row_off = [&](int j) {                                          // 32-bit offset of logical row j (clamped to the window)
       j = j < n ? j : n - 1;
       int r = j + rot;
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(512, 1) void attention_long_f16x3_kernel(AttnArgs a
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) vr[u * 4 + e] = *(const f32x4*)(vp + row_off(4 * (u * 32 + (tid >> 4)) + e));
+      for (int e = 0; e < 4; ++e) vr[u * 4 + e] = *(const f32x4*)(vp + row_off(4 * (u * 32 + gv) + e));
   };
 
   // maxima of the rows in kr / vr -> sred (the power-of-two scales of the item they belong to).  Called at the END of the previous item's
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(512, 1) void attention_long_f16x3_kernel(AttnArgs a
       // V^T (keys >= n: zeros; masked keys have P = 0 exactly, and 0 x garbage must stay 0)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const int G = u * 32 + (tid >> 4);                   // keys 4 G .. 4 G + 3
+        const int G = u * 32 + gv;                           // keys 4 G .. 4 G + 3
         if (4 * G < nt_valid * 32) {
           const int slot = (G >> 2) * 16 + (G & 1) * 8 + ((G >> 1) & 1) * 4;   // 16-key chunk, lane half that consumes the quad, first / second quad
 #pragma unroll
@@ -192,8 +200,8 @@ __global__ __launch_bounds__(512, 1) void attention_long_f16x3_kernel(AttnArgs a
             for (int e = 0; e < 4; ++e) y[e] = 4 * G + e < n ? vr[u * 4 + e][dd] * vs : 0.f;
             h16x4 hh, ll;
             split4(y, hh, ll);
-            *(h16x4*)&Vh[(dq * 4 + dd) * LDV + slot] = hh;
-            *(h16x4*)&Vl[(dq * 4 + dd) * LDV + slot] = ll;
+            *(h16x4*)&Vh[(dqv * 4 + dd) * LDV + slot] = hh;
+            *(h16x4*)&Vl[(dqv * 4 + dd) * LDV + slot] = ll;
           }
         }
       }
