@@ -12,6 +12,7 @@
 #include <netinet/in.h>
 #include <netinet/tcp.h>
 #include <sys/epoll.h>
+#include <sys/resource.h>
 #include <sys/socket.h>
 #include <time.h>
 #include <unistd.h>
@@ -59,7 +60,8 @@ struct Stream {
   std::mutex mu;
   std::deque<double> sent;          // send-completion time of each frame not yet answered
   std::vector<uint8_t> rbuf;
-  long answered = 0;
+  long answered = 0, frames = 0;
+  double t_first_sent = 0, t_first_answer = 0;
 };
 
 int main(int argc, char** argv) {
@@ -93,20 +95,38 @@ int main(int argc, char** argv) {
     audio[2 * i] = 0.2 * sin(2 * M_PI * 140.0 * t) * (0.6 + 0.4 * sin(2 * M_PI * 4.0 * t)) + 1e-3 * ((rand() % 2001) / 1000.0 - 1.0);
     audio[2 * i + 1] = 0.15 * sin(2 * M_PI * 210.0 * t + 1.0) * (i / hop % 2 ? 1.0 : 0.05) + 1e-3 * ((rand() % 2001) / 1000.0 - 1.0);
   }
+  {   // two sockets per stream: raise the soft descriptor limit if it is short
+    rlimit rl;
+    const rlim_t need = (rlim_t)2 * S + 256;
+    if (getrlimit(RLIMIT_NOFILE, &rl) == 0 && rl.rlim_cur < need) {
+      rl.rlim_cur = rl.rlim_max == RLIM_INFINITY ? need : std::min<rlim_t>(rl.rlim_max, need);
+      setrlimit(RLIMIT_NOFILE, &rl);
+      if (getrlimit(RLIMIT_NOFILE, &rl) == 0 && rl.rlim_cur < need) fprintf(stderr, "loadgen: RLIMIT_NOFILE %llu < %llu needed\n", (unsigned long long)rl.rlim_cur, (unsigned long long)need);
+    }
+  }
   std::vector<Stream> st(S);
+  const double td0 = now_s();
   for (int i = 0; i < S; ++i) st[i].fd_in = dial(host, port_in);
-  usleep(300000);
+  const double td1 = now_s();
+  usleep((useconds_t)(300000 + 100 * S));            // let the server adopt every connection before the next step
+
+  const double td2 = now_s();
   for (int i = 0; i < S; ++i) st[i].fd_out = dial(host, port_out);
-  usleep(300000);
+  const double td3 = now_s();
+  usleep((useconds_t)(300000 + 100 * S));
+  fprintf(stderr, "loadgen CLOCK_MONOTONIC: inputs dialled %.3f .. %.3f, outputs dialled %.3f .. %.3f\n", td0, td1, td2, td3);
 
   std::atomic<bool> stop{false};
   std::atomic<long> frames_sent{0}, frames_answered{0}, late{0}, slipped{0};
   std::atomic<long> max_send_lag_us{0}, max_recv_gap_us{0}, max_send_call_us{0};   // the load generator's own stalls (so they are not blamed on the server)
   auto amax = [](std::atomic<long>& a, long v) { long m = a.load(); while (v > m && !a.compare_exchange_weak(m, v)) {} };
   std::mutex lat_mu;
+  struct Stall { double t; int stream; float ms; };
+  std::vector<Stall> stalls;                          // answers later than 50 ms: when (s after the measurement start), which stream, how late
   std::vector<float> lats;
   lats.reserve((size_t)(S * hz * seconds * 1.1));
   const double t_start = now_s() + 0.2;
+  fprintf(stderr, "loadgen CLOCK_MONOTONIC: t_start %.3f\n", t_start);
   const double t_measure = t_start + warm;          // latencies before this are not recorded (window fill / ramp-up)
   const double t_end = t_measure + seconds;
 
@@ -134,6 +154,7 @@ int main(int argc, char** argv) {
       if (e.pk + 1 == packets_per_frame) {   // time stamp BEFORE the frame's last packet leaves: the answer may overtake us
         std::lock_guard<std::mutex> lk(st[e.s].mu);
         st[e.s].sent.push_back(now_s());
+        if (st[e.s].frames++ == 0) st[e.s].t_first_sent = st[e.s].sent.back();
       }
       const double t_call = now_s();
       while (left) {
@@ -184,6 +205,7 @@ int main(int argc, char** argv) {
             std::lock_guard<std::mutex> lk(s.mu);
             if (!s.sent.empty()) { t_sent = s.sent.front(); s.sent.pop_front(); }
           }
+          if (s.answered == 0) s.t_first_answer = t;
           ++s.answered;
           frames_answered.fetch_add(1);
           if (t_sent >= t_measure) {
@@ -191,6 +213,7 @@ int main(int argc, char** argv) {
             if (ms > late_ms) late.fetch_add(1);
             std::lock_guard<std::mutex> lk(lat_mu);
             lats.push_back((float)ms);
+            if (ms > 50.0 && stalls.size() < 4096) stalls.push_back({t - t_measure, (int)evs[k].data.u32, (float)ms});
           }
         }
         if (off) s.rbuf.erase(s.rbuf.begin(), s.rbuf.begin() + off);
@@ -212,7 +235,34 @@ int main(int argc, char** argv) {
   auto pct = [&](double q) { return lats.empty() ? 0.0 : (double)lats[std::min(lats.size() - 1, (size_t)(q * lats.size()))]; };
   long unanswered = 0;
   for (auto& s : st) unanswered += (long)s.sent.size();
-  printf("{\"streams\": %d, \"frame_hz\": %d, \"packet_ms\": %d, \"seconds_measured\": %.1f, \"frames_sent\": %ld, \"frames_answered\": %ld, "
+  // stall events: late answers clustered in time (a TCP retransmission timeout shows as one stream ~200 ms late, a host stall as many at once)
+  std::sort(stalls.begin(), stalls.end(), [](const Stall& a, const Stall& b) { return a.t < b.t; });
+  std::string stall_json = "[";
+  {
+    size_t i = 0; int shown = 0;
+    while (i < stalls.size() && shown < 24) {
+      size_t j = i; float worst = 0; std::vector<int> ids;
+      while (j < stalls.size() && stalls[j].t - stalls[i].t < 0.3) { worst = std::max(worst, stalls[j].ms); if (std::find(ids.begin(), ids.end(), stalls[j].stream) == ids.end()) ids.push_back(stalls[j].stream); ++j; }
+      char b[160];
+      snprintf(b, sizeof b, "%s{\"t_s\": %.2f, \"late_answers\": %zu, \"streams\": %zu, \"first_stream\": %d, \"worst_ms\": %.1f}", shown ? ", " : "", stalls[i].t, j - i, ids.size(), ids[0], worst);
+      stall_json += b; ++shown; i = j;
+    }
+    stall_json += "]";
+  }
+  printf("{\"stall_events_over_50ms\": %s, ", stall_json.c_str());
+  {   // streams with unanswered frames: how many frames they sent / got back and when the first answer came (relative to their first frame)
+    std::string u = "[";
+    int shown = 0;
+    for (int i = 0; i < S; ++i)
+      if (!st[i].sent.empty() && shown < 24) {
+        char b[160];
+        snprintf(b, sizeof b, "%s{\"stream\": %d, \"frames_sent\": %ld, \"answered\": %ld, \"first_answer_after_first_frame_ms\": %.1f}", shown ? ", " : "", i, st[i].frames,
+                 st[i].answered, (st[i].t_first_answer - st[i].t_first_sent) * 1e3);
+        u += b; ++shown;
+      }
+    printf("\"streams_with_unanswered_frames\": %s], ", u.c_str());
+  }
+  printf("\"streams\": %d, \"frame_hz\": %d, \"packet_ms\": %d, \"seconds_measured\": %.1f, \"frames_sent\": %ld, \"frames_answered\": %ld, "
          "\"unanswered_at_end\": %ld, \"latency_samples\": %zu, \"lat_p50_ms\": %.3f, \"lat_p99_ms\": %.3f, \"lat_p999_ms\": %.3f, \"lat_max_ms\": %.3f, "
          "\"late_over_%.0fms\": %ld, \"schedule_slips\": %ld, \"client_max_send_lag_ms\": %.2f, \"client_max_send_call_ms\": %.2f, \"client_max_recv_pass_ms\": %.2f, \"stream_frames_per_s\": %.1f}\n",
          S, hz, packet_ms, seconds, frames_sent.load(), frames_answered.load(), unanswered, lats.size(), pct(0.50), pct(0.99), pct(0.999),

@@ -23,6 +23,40 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def net_counters():
+    """Kernel-side evidence for client-visible stalls: TCP retransmissions / timeouts (/proc/net/snmp, /proc/net/netstat) and packets the
+    per-CPU softnet backlog DROPPED (/proc/net/softnet_stat, 2nd column; the loopback device hands every segment to that queue, bounded by
+    net.core.netdev_max_backlog).  A dropped loopback segment comes back only after the retransmission timeout (>= 200 ms)."""
+    out = {}
+    try:
+        with open("/proc/net/snmp") as f:
+            rows = [l.split() for l in f if l.startswith("Tcp:")]
+        out.update({k: int(v) for k, v in zip(rows[0][1:], rows[1][1:]) if k in ("RetransSegs", "OutSegs", "InSegs")})
+    except Exception:
+        pass
+    try:
+        with open("/proc/net/netstat") as f:
+            rows = [l.split() for l in f if l.startswith("TcpExt:")]
+        keep = ("TCPTimeouts", "TCPLossProbes", "TCPLostRetransmit", "TCPBacklogDrop", "TCPRcvQDrop", "ListenDrops", "ListenOverflows", "TCPSynRetrans",
+                "TCPFastRetrans", "TCPSlowStartRetrans", "PruneCalled", "TCPRcvCollapsed", "TCPDelivered", "TCPSackRecovery")
+        out.update({k: int(v) for k, v in zip(rows[0][1:], rows[1][1:]) if k in keep})
+    except Exception:
+        pass
+    try:
+        with open("/proc/net/softnet_stat") as f:
+            cols = [[int(x, 16) for x in l.split()] for l in f]
+        out["softnet_dropped"] = sum(c[1] for c in cols)
+        out["softnet_time_squeeze"] = sum(c[2] for c in cols)
+    except Exception:
+        pass
+    try:
+        with open("/proc/sys/net/core/netdev_max_backlog") as f:
+            out["netdev_max_backlog"] = int(f.read())
+    except Exception:
+        pass
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=256)
@@ -46,6 +80,7 @@ def main():
     ap.add_argument("--devices", default="", help="with --shards N: comma list of N device ids, one engine per listed GPU (default: all on device 0)")
     ap.add_argument("--split-f16", action="store_true", help="engines on the opt-in split-precision path (serve --precision split)")
     ap.add_argument("--mode", default="vap", choices=["vap", "bc", "nod"])
+    ap.add_argument("--backlog", type=int, default=0, help="try to raise net.core.netdev_max_backlog to this before the run (needs root; 0 = leave it)")
     ap.add_argument("--fake", action="store_true", help="native front-end over a trivial step function (plumbing only, no GPU)")
     args = ap.parse_args()
     loadgen = os.path.join(ROOT, "tools", "loadgen")
@@ -111,6 +146,13 @@ def main():
         print(json.dumps({"round": rep, "frames_answered": first["frames_answered"], "frames_sent": first["frames_sent"],
                           "lat_p99_ms": first["lat_p99_ms"]}), file=sys.stderr)
         time.sleep(1.0)
+    if args.backlog > 0:
+        try:
+            with open("/proc/sys/net/core/netdev_max_backlog", "w") as f:
+                f.write(str(args.backlog))
+        except Exception as e:                                    # noqa: BLE001
+            print(f"could not set netdev_max_backlog: {e}", file=sys.stderr)
+    net0 = net_counters()
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE)
     base = {}
     if hasattr(srv, "stats"):                       # server-side latency window = the load generator's measured window
@@ -118,6 +160,8 @@ def main():
         base = srv.stats(reset_latency_window=True)
     out = proc.communicate(timeout=args.seconds + args.warm + 120)[0].decode()
     res = json.loads(out.strip().splitlines()[-1])
+    net1 = net_counters()
+    res["net_counters_delta"] = {k: (net1[k] - net0.get(k, 0) if k != "netdev_max_backlog" else net1[k]) for k in net1}
     res["server"] = kind
     if hasattr(srv, "stats"):
         st = srv.stats()

@@ -17,6 +17,7 @@
 #include <netinet/tcp.h>
 #include <sys/epoll.h>
 #include <sys/eventfd.h>
+#include <sys/resource.h>
 #include <sys/socket.h>
 #include <sys/uio.h>
 #include <time.h>
@@ -64,6 +65,11 @@ double unix_now() {
   timespec ts;
   clock_gettime(CLOCK_REALTIME, &ts);
   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+inline void atomic_max(std::atomic<int64_t>& a, int64_t v) {
+  int64_t m = a.load(std::memory_order_relaxed);
+  while (v > m && !a.compare_exchange_weak(m, v, std::memory_order_relaxed)) {}
 }
 
 // ---- codec ---------------------------------------------------------------------------------------
@@ -143,6 +149,9 @@ struct Slot {
   std::atomic<bool> paused{false};        // written by the slot's rx / accept thread, read by whoever frees a buffer
   std::mutex lmu;                         // guards listeners
   std::vector<int> listeners;
+  // VAPX_INGEST_DEBUG bookkeeping (relaxed counters, printed at close): where do a stream's frames go?
+  std::atomic<int64_t> dbg_ready{0}, dbg_sent{0}, dbg_nolistener{0};
+  double dbg_t_first_ready = 0, dbg_t_attach = 0, dbg_t_first_sent = 0;
   Slot() { for (auto& s : state) s = B_FREE; }
 };
 
@@ -188,6 +197,7 @@ struct vapx_ingest {
   std::vector<int> out_all;                // broadcast listeners
   std::vector<int> lcount;                 // listeners per slot (under slots_mu)
   int lmin = 0, lcursor = 0;               // fewest listeners on any slot; lowest slot that may still have that few
+  int free_hint = 0;                       // no input slot below this one is free (under slots_mu): adoption is O(1) amortised, not a scan of S slots
   int ep_accept = -1;                      // the accept thread's epoll (listen sockets only)
   std::thread accept_thread;
   std::mutex ready_mu;
@@ -207,7 +217,9 @@ struct vapx_ingest {
   std::atomic<int64_t> step_us{0};
   // stall diagnostics (printed at close when VAPX_INGEST_DEBUG is set): longest single pass of an rx thread over its ready sockets, longest gap
   // between two passes that both had work, longest step
-  std::atomic<int64_t> dbg_rx_pass_us{0}, dbg_rx_gap_us{0}, dbg_step_us{0};
+  std::atomic<int64_t> dbg_rx_pass_us{0}, dbg_rx_gap_us{0}, dbg_step_us{0}, dbg_send_us{0}, dbg_job_tx_us{0}, dbg_recv_us{0};
+  double dbg_t_in_first = 0, dbg_t_in_last = 0, dbg_t_out_first = 0, dbg_t_out_last = 0;   // accept thread only: CLOCK_MONOTONIC of the first / last adopted connection
+  std::atomic<int64_t> accept_fd_errors{0};   // accept4() failed for lack of descriptors (EMFILE / ENFILE): the process limit is below 2 x streams
   Hist lat;
   std::string err;
   bool pinned_blocks = true;               // staging came from vapx_host_alloc (false: plain calloc, no HIP device)
@@ -290,6 +302,7 @@ void drop_input(vapx_ingest* g, int r, int slot) {
   {
     std::lock_guard<std::mutex> lk(g->slots_mu);
     s.fd_in = -1;
+    if (slot < g->free_hint) g->free_hint = slot;
     s.gen.fetch_add(1);                     // frames of this connection still queued are dropped by the tick thread
   }
   g->in_conns.fetch_sub(1);
@@ -354,6 +367,7 @@ size_t feed(vapx_ingest* g, int slot, const uint8_t* p, size_t n) {
       const int b = s.wbuf;
       const double t = mono_now();
       s.t_ready[b] = t;
+      if (s.dbg_ready.fetch_add(1, std::memory_order_relaxed) == 0) s.dbg_t_first_ready = t;
       s.state[b].store(B_READY, std::memory_order_release);
       s.wbuf = -1; s.fill = 0;
       {
@@ -376,7 +390,9 @@ void on_data(vapx_ingest* g, int r, int slot, uint8_t* scratch, size_t cap, uint
     return;
   }
   for (int round = 0; round < 4; ++round) {   // bounded work per wake-up: fairness between streams
+    const double tr0 = mono_now();
     ssize_t n = recv(s.fd_in, scratch, cap, 0);
+    atomic_max(g->dbg_recv_us, (int64_t)((mono_now() - tr0) * 1e6));              // longest recv() call
     if (n < 0) {
       if (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR) return;
       drop_input(g, r, slot);
@@ -423,11 +439,21 @@ void do_resume(vapx_ingest* g, int r, int slot) {
   ep_mod(g->ep[r], s.fd_in, K_DATA | (uint32_t)slot, true);
 }
 
+// accept4 failed: out of descriptors -> count it and back off (the listen socket stays readable, the level-triggered epoll would spin)
+bool accept_failed_for_fds(vapx_ingest* g) {
+  if (errno != EMFILE && errno != ENFILE && errno != ENOBUFS && errno != ENOMEM) return false;
+  if (g->accept_fd_errors.fetch_add(1) == 0)
+    fprintf(stderr, "[vapx ingest] accept: out of file descriptors (%s) - raise `ulimit -n` above 2 x streams + 64; connections wait in the listen queue\n", strerror(errno));
+  std::this_thread::sleep_for(std::chrono::milliseconds(10));
+  return true;
+}
+
 // lowest free input slot, or -1 (the front door compares this across shards)
 int lowest_free_slot(vapx_ingest* g) {
   std::lock_guard<std::mutex> lk(g->slots_mu);
-  for (int i = 0; i < g->S; ++i)
-    if (g->slots[i].fd_in < 0) return i;
+  for (int i = g->free_hint; i < g->S; ++i)
+    if (g->slots[i].fd_in < 0) { g->free_hint = i; return i; }
+  g->free_hint = g->S;
   return -1;
 }
 
@@ -435,9 +461,12 @@ int lowest_free_slot(vapx_ingest* g) {
 bool adopt_in(vapx_ingest* g, int fd) {
   int slot = -1;
   {
+    // (round 4: this was a scan from slot 0 — 4096 dialogues connecting at once cost the accept thread ~S^2 / 2 slot visits, the output
+    // connections queued behind them were attached after the first frames had been answered, and those answers went to nobody)
     std::lock_guard<std::mutex> lk(g->slots_mu);
-    for (int i = 0; i < g->S; ++i)
+    for (int i = g->free_hint; i < g->S; ++i)
       if (g->slots[i].fd_in < 0) { slot = i; break; }
+    g->free_hint = slot >= 0 ? slot + 1 : g->S;
     if (slot >= 0) g->slots[slot].fd_in = fd;
   }
   if (slot < 0) return false;
@@ -452,6 +481,7 @@ bool adopt_in(vapx_ingest* g, int fd) {
     g->resets.push_back({slot, g->cfg.reset_on_connect ? 0 : 1});
   }
   g->in_conns.fetch_add(1);
+  { const double t = mono_now(); if (g->dbg_t_in_first == 0) g->dbg_t_in_first = t; g->dbg_t_in_last = t; }
   ep_add(g->ep[slot % g->R], fd, K_DATA | (uint32_t)slot);
   return true;
 }
@@ -459,7 +489,7 @@ bool adopt_in(vapx_ingest* g, int fd) {
 void accept_in(vapx_ingest* g) {
   for (;;) {
     int fd = accept4(g->lin, nullptr, nullptr, SOCK_NONBLOCK);
-    if (fd < 0) return;
+    if (fd < 0) { accept_failed_for_fds(g); return; }
     if (!adopt_in(g, fd)) close(fd);        // every stream slot is taken
   }
 }
@@ -481,6 +511,7 @@ void adopt_out(vapx_ingest* g, int fd) {
   int one = 1;
   setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
   g->out_conns.fetch_add(1);
+  { const double t = mono_now(); if (g->dbg_t_out_first == 0) g->dbg_t_out_first = t; g->dbg_t_out_last = t; }
   if (g->broadcast) { std::lock_guard<std::mutex> lk(g->slots_mu); g->out_all.push_back(fd); return; }
   const int best = next_listener_slot(g).second;
   std::lock_guard<std::mutex> lk(g->slots_mu);
@@ -488,12 +519,13 @@ void adopt_out(vapx_ingest* g, int fd) {
   ++g->lcount[best];
   std::lock_guard<std::mutex> l2(g->slots[best].lmu);
   g->slots[best].listeners.push_back(fd);
+  if (g->slots[best].dbg_t_attach == 0) g->slots[best].dbg_t_attach = mono_now();
 }
 
 void accept_out(vapx_ingest* g) {
   for (;;) {
     int fd = accept4(g->lout, nullptr, nullptr, SOCK_NONBLOCK);
-    if (fd < 0) return;
+    if (fd < 0) { accept_failed_for_fds(g); return; }
     adopt_out(g, fd);
   }
 }
@@ -517,10 +549,6 @@ void accept_main(vapx_ingest* g) {
   }
 }
 
-inline void atomic_max(std::atomic<int64_t>& a, int64_t v) {
-  int64_t m = a.load(std::memory_order_relaxed);
-  while (v > m && !a.compare_exchange_weak(m, v, std::memory_order_relaxed)) {}
-}
 
 void rx_main(vapx_ingest* g, int r) {
   std::vector<uint8_t> scratch(256 * 1024);
@@ -602,7 +630,10 @@ void tx_main(vapx_ingest* g) {
         const size_t total = 4 + plen;
         auto send_to = [&](std::vector<int>& fds) {
           for (size_t i = 0; i < fds.size();) {
-            if (send_packet(fds[i], iov, 5, total)) { g->tx_bytes.fetch_add((int64_t)total, std::memory_order_relaxed); ++i; }
+            const double ts0 = mono_now();
+            const bool sent = send_packet(fds[i], iov, 5, total);
+            atomic_max(g->dbg_send_us, (int64_t)((mono_now() - ts0) * 1e6));      // longest sendmsg() call (the socket is non-blocking)
+            if (sent) { g->tx_bytes.fetch_add((int64_t)total, std::memory_order_relaxed); ++i; }
             else { close(fds[i]); fds.erase(fds.begin() + i); g->dropped.fetch_add(1); g->out_conns.fetch_sub(1); }
           }
         };
@@ -612,6 +643,8 @@ void tx_main(vapx_ingest* g) {
           {
             std::lock_guard<std::mutex> lk(s.lmu);
             const size_t before = s.listeners.size();
+            if (before == 0) s.dbg_nolistener.fetch_add(1, std::memory_order_relaxed);
+            else if (s.dbg_sent.fetch_add(1, std::memory_order_relaxed) == 0) s.dbg_t_first_sent = mono_now();
             send_to(s.listeners);
             gone = before - s.listeners.size();
           }
@@ -626,6 +659,7 @@ void tx_main(vapx_ingest* g) {
       job.finished += k1 - k0;
       if (job.finished >= job.n) {           // every packet of this tick is out: the next tick's rows may go (and the Job may be reused)
         if (!g->job_queue.empty() && g->job_queue.front() == j) g->job_queue.pop_front();
+        atomic_max(g->dbg_job_tx_us, (int64_t)((unix_now() - job.t_unix) * 1e6));   // results ready -> last packet of the tick handed to the kernel
         job.busy = false;
         g->job_done_cv.notify_all();
         g->job_cv.notify_all();
@@ -777,6 +811,21 @@ int open_common(vapx_ingest* g, const vapx_ingest_config* cfg) {
     j.rows.reserve(g->max_batch);
   }
   if (!g->stage || !g->batch_audio || !g->jobs[0].out || !g->jobs[1].out) return VAPX_E_NOMEM;
+  // One descriptor per input connection and one per listener: 2 x S and some.  Raise the soft RLIMIT_NOFILE towards the hard limit if it
+  // is short (round 4: on a box with `ulimit -n 8192` the last 18 of 4096 output connections waited in the listen queue until descriptors
+  // came free, their first results went to nobody, and a FIFO-pairing load generator then saw those 18 dialogues "N frames late" for good)
+  {
+    const rlim_t need = (rlim_t)2 * (rlim_t)g->S + 256;
+    rlimit rl;
+    if (getrlimit(RLIMIT_NOFILE, &rl) == 0 && rl.rlim_cur != RLIM_INFINITY && rl.rlim_cur < need) {
+      rlimit want = rl;
+      want.rlim_cur = rl.rlim_max == RLIM_INFINITY ? need : std::min<rlim_t>(rl.rlim_max, std::max<rlim_t>(need, rl.rlim_cur));
+      (void)setrlimit(RLIMIT_NOFILE, &want);
+      if (getrlimit(RLIMIT_NOFILE, &rl) == 0 && rl.rlim_cur < need)
+        fprintf(stderr, "[vapx ingest] RLIMIT_NOFILE is %llu (hard limit), %llu are needed for %d dialogue slots with one listener each: later "
+                "connections will wait in the listen queue\n", (unsigned long long)rl.rlim_cur, (unsigned long long)need, g->S);
+    }
+  }
   // port_in < 0: a PASSIVE shard of a multi-GPU front door (vapx_frontdoor_open): it listens on nothing, connections are handed to it
   const bool passive = cfg->port_in < 0;
   if (passive != (cfg->port_out < 0)) return VAPX_E_INVAL;   // a shard is passive on BOTH ports or on none (-1 / >= 0 mixed is a configuration error)
@@ -896,8 +945,27 @@ void vapx_ingest_close(vapx_ingest_handle g) {
   g->job_cv.notify_all();
   for (auto& t : g->tx_threads) if (t.joinable()) t.join();
   if (getenv("VAPX_INGEST_DEBUG"))
-    fprintf(stderr, "[vapx ingest] longest rx pass %.2f ms, longest gap between busy rx passes %.2f ms, longest step %.2f ms, latency max %.2f ms\n",
-            g->dbg_rx_pass_us.load() * 1e-3, g->dbg_rx_gap_us.load() * 1e-3, g->dbg_step_us.load() * 1e-3, (double)g->lat.max_us.load() * 1e-3);
+    fprintf(stderr, "[vapx ingest] longest rx pass %.2f ms, longest gap between busy rx passes %.2f ms, longest step %.2f ms, latency max %.2f ms, "
+            "longest recv() %.2f ms, longest sendmsg() %.2f ms, longest tick fan-out (results ready -> last packet sent) %.2f ms\n",
+            g->dbg_rx_pass_us.load() * 1e-3, g->dbg_rx_gap_us.load() * 1e-3, g->dbg_step_us.load() * 1e-3, (double)g->lat.max_us.load() * 1e-3,
+            g->dbg_recv_us.load() * 1e-3, g->dbg_send_us.load() * 1e-3, g->dbg_job_tx_us.load() * 1e-3);
+  if (getenv("VAPX_INGEST_DEBUG") && g->slots) {
+    // streams whose results went nowhere (no output connection attached yet) or whose frames did not all come back out
+    int shown = 0, odd = 0;
+    for (int i = 0; i < g->S; ++i) {
+      Slot& s = g->slots[i];
+      const int64_t rdy = s.dbg_ready.load(), snt = s.dbg_sent.load(), nol = s.dbg_nolistener.load();
+      if (nol == 0 && rdy == snt) continue;
+      ++odd;
+      if (shown++ < 24)
+        fprintf(stderr, "[vapx ingest] slot %d: %ld frames assembled, %ld sent, %ld had NO listener; first frame ready %.3f s, listener attached %.3f s, first packet sent %.3f s (after the first slot's first frame)\n",
+                i, (long)rdy, (long)snt, (long)nol, s.dbg_t_first_ready - g->slots[0].dbg_t_first_ready, s.dbg_t_attach - g->slots[0].dbg_t_first_ready,
+                s.dbg_t_first_sent - g->slots[0].dbg_t_first_ready);
+    }
+    fprintf(stderr, "[vapx ingest] accept4 failures for lack of descriptors: %ld; CLOCK_MONOTONIC: inputs adopted %.3f .. %.3f, outputs adopted %.3f .. %.3f, slot 0's first frame %.3f\n",
+            (long)g->accept_fd_errors.load(), g->dbg_t_in_first, g->dbg_t_in_last, g->dbg_t_out_first, g->dbg_t_out_last, g->slots[0].dbg_t_first_ready);
+    fprintf(stderr, "[vapx ingest] %d of %d slots lost results to a missing listener or did not send every assembled frame\n", odd, g->S);
+  }
   if (g->slots) {
     for (int i = 0; i < g->S; ++i) {
       if (g->slots[i].fd_in >= 0) close(g->slots[i].fd_in);
