@@ -329,12 +329,31 @@ __global__ __launch_bounds__(512, 1) void ffn_block_f16x3_kernel(const FfnArgs g
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[rt][r] *= up;
     }
-    // gelu + f16 split of one 4-value group (q = 4 rt + j) of a hidden chunk's accumulators -> sH
+    // gelu + f16 split of one 4-value group (q = 4 rt + j) of a hidden chunk's accumulators -> sH.  The operand scale 2^-8, the result
+    // scale hs, the 1 / sqrt 2 of erf's argument and the log2 e of v_exp_f32 are folded into three constants: gelu_fast (common.h, A&S 7.1.26) as
+    //   z' = |a| k1 (z'^2 = log2 e x^2 / 2),  t = 1 / (1 + k2 z'),  e = 1 - poly(t) t 2^(-z'^2),  result = hc + copysign(e, a) hc,  hc = a k3
+    // — 11 plain VALU operations + rcp + exp2 per element instead of 19 + 2 (the same formula, other rounding points).  (Measured: the phase
+    // does not get shorter — it is not bound by the operation count; profiles/r04_experiments.)
+    constexpr double kSqrtLog2e = 1.2011224087864498;
+    const float k1 = (float)(0.70710678118654752440 * kSqrtLog2e) * kWScaleInv;
+    constexpr float k2 = (float)(0.3275911 / kSqrtLog2e);
+    const float k3 = 0.5f * kWScaleInv * hs;
     auto gelu_group = [&](const f32x16(&h)[2], int q) {
       const int rt = q >> 2, j = q & 3;
       f32x4 y;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) y[e] = gelu_fast(h[rt][4 * j + e] * kWScaleInv) * hs;
+      for (int e = 0; e < 4; ++e) {
+        const float a = h[rt][4 * j + e];
+        const float z = fabsf(a) * k1;
+        const float t = __builtin_amdgcn_rcpf(fmaf(k2, z, 1.0f));
+        float pl = fmaf(1.061405429f, t, -1.453152027f);
+        pl = fmaf(pl, t, 1.421413741f);
+        pl = fmaf(pl, t, -0.284496736f);
+        pl = fmaf(pl, t, 0.254829592f);
+        const float er = fmaf(-(pl * t), __builtin_amdgcn_exp2f(-z * z), 1.0f);     // erf(|x| / sqrt 2)
+        const float hc = a * k3;
+        y[e] = fmaf(copysignf(er, a), hc, hc);
+      }
       const h16x4 hh = __builtin_convertvector(y, h16x4);
       const h16x4 ll = __builtin_convertvector(y - __builtin_convertvector(hh, f32x4), h16x4);
       *(h16x4*)&sHh[(rt * 32 + l31) * LD16 + ccol + 8 * j] = hh;
