@@ -24,8 +24,8 @@ pass() {  # name, counters...
   local name=$1; shift
   : > $OUT/$name.txt
   if [ "$WL" = "c3" ]; then
-    rocprofv3 --pmc "$@" --kernel-exclude-regex attention_long2 --kernel-iteration-range "[250-259]" -f csv -d $RAW/${name}_a -o run -- $BENCH > $OUT/$name.log 2>&1
-    rocprofv3 --pmc "$@" --kernel-include-regex attention_long2 --kernel-iteration-range "[1270-1295]" -f csv -d $RAW/${name}_b -o run -- $BENCH >> $OUT/$name.log 2>&1
+    rocprofv3 --pmc "$@" --kernel-exclude-regex attention_long --kernel-iteration-range "[250-259]" -f csv -d $RAW/${name}_a -o run -- $BENCH > $OUT/$name.log 2>&1
+    rocprofv3 --pmc "$@" --kernel-include-regex attention_long --kernel-iteration-range "[1270-1295]" -f csv -d $RAW/${name}_b -o run -- $BENCH >> $OUT/$name.log 2>&1
   else
     rocprofv3 --pmc "$@" -f csv -d $RAW/${name}_a -o run -- $BENCH > $OUT/$name.log 2>&1
   fi

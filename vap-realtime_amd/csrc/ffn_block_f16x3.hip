@@ -49,13 +49,17 @@ constexpr float kWScaleInv = 1.0f / 256.0f;   // weights are packed as 2^8 w
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 
 // MODE as FfnArgs::mode (0: xmid from global; 1: attention-output projection + the whole block; 2: projection + LN + wqkvf chunks only)
+// MODE 2 (projection + LayerNorm + cross-query projection: two contractions per tile, no FFN) never touches the X tile: it is launched with
+// ONE (hi, lo) tile of LDS (68 KB) and compiled for 4 waves per SIMD, so that TWO workgroups share a CU and one's staging / statistics / store
+// phases run under the other's contractions (round 4: 22 us per tile with 5 us of MFMA in it when it ran alone on its CU).  Each workgroup
+// still feeds 64 rows per weight fragment, so the pair needs no more of the CU's vector-memory path per MFMA than one workgroup does.
 template <int MODE>
-__global__ __launch_bounds__(512, 1) void ffn_block_f16x3_kernel(const FfnArgs g) {
+__global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel(const FfnArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr int BM = 64;
-  _Float16* sXh = (_Float16*)lds_raw;     // LN_ffn(x) tile, hi / lo
+  _Float16* sXh = (_Float16*)lds_raw;     // LN_ffn(x) tile, hi / lo (MODE 2: absent — sH starts here)
   _Float16* sXl = sXh + BM * LD16;
-  _Float16* sHh = sXl + BM * LD16;        // attention rows / gelu chunk / raw x / LN rows, hi / lo
+  _Float16* sHh = MODE == 2 ? sXh : sXl + BM * LD16;   // attention rows / gelu chunk / raw x / LN rows, hi / lo
   _Float16* sHl = sHh + BM * LD16;
   float* sHf = (float*)sHh;               // the same bytes as ONE fp32 tile [BM][LD16] (2 x BM x LD16 halves = BM x LD16 floats)
   float* rinv = (float*)(sHl + BM * LD16);   // [BM] 1 / s_row of the rows staged with a power-of-two scale
@@ -229,6 +233,19 @@ __global__ __launch_bounds__(512, 1) void ffn_block_f16x3_kernel(const FfnArgs g
   // wave's, DS operations of a wave complete in order — and stores 8 rows x 128 contiguous bytes = 16 whole lines per instruction.
   float* sT = (float*)sXh + w * (64 * 32);
   auto store_global = [&](const f32x16(&acc)[2], float* base, int ld, int col0) {
+    if constexpr (MODE == 2) {               // no X tile to borrow (and no registers to spare at 4 waves per SIMD): straight from the accumulators
+      float* bu = base + (long)m0 * ld + col0 + w * 32 + 4 * hi;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const int lr = rt * 32 + l31;
+        if (m0 + lr < g.M) {
+          float* p = bu + (unsigned)(lr * ld);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) *(f32x4*)(p + 8 * j) = quad(acc[rt], j);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
       const int row = rt * 32 + l31;
@@ -478,7 +495,7 @@ hipError_t launch_ffn_block_f16x3(const FfnArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)ffn_block_f16x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ffn_block_f16x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  const size_t lds = (size_t)4 * 64 * LD16 * sizeof(_Float16) + 64 * sizeof(float);
+  const size_t lds = (size_t)(a.mode == 2 ? 2 : 4) * 64 * LD16 * sizeof(_Float16) + 64 * sizeof(float);   // mode 2: one (hi, lo) tile, two workgroups per CU
   const dim3 grid((a.M + 63) / 64), block(512);
   if (a.mode == 1 || a.mode == 2) {
     if (!a.att || !a.wprojf || !a.resid || !a.xmid_out) return hipErrorInvalidValue;
