@@ -107,7 +107,10 @@ typedef struct vapx_config {
   int32_t struct_size;  /* sizeof(vapx_config), for ABI evolution */
   int32_t device_id;    /* HIP device ordinal */
   int32_t frame_hz;     /* 5, 10, 20 or 50: VAPRealTime frame_rate   vap_main.py:192,219 */
-  int32_t ctx_frames;   /* T = int(context_len_sec*frame_rate)        vap_main.py:221 */
+  int32_t ctx_frames;   /* T = int(context_len_sec*frame_rate)        vap_main.py:221.  1 <= T <= 256 (vapx_create returns VAPX_E_INVAL beyond):
+                         * every published checkpoint fits (largest: 20 Hz x 10 s = 200 rows, README.md; BASELINE configs[2]: 50 Hz x 5 s = 250);
+                         * the reference's ALiBi transformer itself takes any T (modules.py:303-308) — longer windows need more key tiles than
+                         * the long-window attention kernels hold on chip and are not built */
   int32_t max_streams;  /* stream slots whose state lives in HBM */
   int32_t max_batch;    /* max streams per vapx_step call (sizes scratch) */
   int32_t mode;         /* VAPX_MODE_* */
