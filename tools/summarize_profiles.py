@@ -42,6 +42,7 @@ traffic["_how_r02"] = ("r02 entries: tools/profile_configs.sh (rocprofv3 --pmc F
                        "`bench.py --workload <w> --configs= --steps 4`), means per dispatch by tools/pmc_summary.py; KiB units; "
                        "bytes_per_launch_corrected = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per MI355X_MICROARCH.md (gfx950 tallies 128-B "
                        "read requests at 64 B).")
+traffic["_how_r04"] = ("r04 entries: same recipe on the round-4 kernels (tools/profile_configs.sh <workload> r04 4; c3 passes restricted to steady-state dispatches).")
 traffic["_how_r03"] = ("r03 entries (c2, s4096_20hz, c3, c5 re-measured on the round-3 kernels; C3 at its full 4096 streams, not scaled from 512): same recipe as "
                        "_how_r02; the class entry of a workload (\"ffn_block\", \"attention\", ...) is the first kernel of that class in name order, i.e. "
                        "ffn_block_kernel<1, 1> for C3.")

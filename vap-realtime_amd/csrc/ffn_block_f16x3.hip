@@ -229,7 +229,8 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
   // different rows per store instruction: 64 partial cache lines, 1.8 us to issue the eight stores of a wave (round-3 timeline), six such
   // phases per tile.  The X tile's bytes are dead whenever a tile is stored (the FFN1 contractions are over; mode 2 never uses them), and
   // [64 rows][32 columns] fp32 = 8 KB per wave x 8 waves is exactly that region: a wave writes its quads (16-byte units, unit q of row r at
-  // q ^ ((r >> 1) & 7): conflict-free both ways for the ds_*_b128 lane groups), reads them back as rows — no barrier: both sides are this
+  // q ^ (r & 7): conflict-free both ways — ds_write_b128 is served in groups of 8 consecutive lanes over 32 banks, ds_read_b128 in
+  // the groups of 16 of MI355X_MICROARCH.md over 64), reads them back as rows — no barrier: both sides are this
   // wave's, DS operations of a wave complete in order — and stores 8 rows x 128 contiguous bytes = 16 whole lines per instruction.
   float* sT = (float*)sXh + w * (64 * 32);
   auto store_global = [&](const f32x16(&acc)[2], float* base, int ld, int col0) {
@@ -250,13 +251,13 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
     for (int rt = 0; rt < 2; ++rt) {
       const int row = rt * 32 + l31;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) *(f32x4*)&sT[row * 32 + 4 * ((2 * j + hi) ^ ((row >> 1) & 7))] = quad(acc[rt], j);
+      for (int j = 0; j < 4; ++j) *(f32x4*)&sT[row * 32 + 4 * ((2 * j + hi) ^ (row & 7))] = quad(acc[rt], j);
     }
     float* bu = base + (long)m0 * ld + col0 + w * 32 + 4 * (lane & 7);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int R = (lane >> 3) + 8 * i;
-      const f32x4 v = *(const f32x4*)&sT[R * 32 + 4 * ((lane & 7) ^ ((R >> 1) & 7))];
+      const f32x4 v = *(const f32x4*)&sT[R * 32 + 4 * ((lane & 7) ^ (R & 7))];
       if (m0 + R < g.M) *(f32x4*)(bu + (unsigned)(R * ld)) = v;
     }
   };
