@@ -416,7 +416,7 @@ def run_workload(name, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=0, split
     if dominant == "ffn_block" and split_f16:
         kernel = "ffn_block_f16x3_kernel"
     roof = {"bound": "mfma", "kernel": kernel, "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tf / peak,
-            "traffic": None if split_f16 else load_traffic(f"{S}x{hz}hz_T{T}" + ("" if mode == "vap" else "_" + mode), dominant),
+            "traffic": load_traffic(f"{S}x{hz}hz_T{T}" + ("" if mode == "vap" else "_" + mode) + ("_split_f16" if split_f16 else ""), dominant),
             "avg_launch_us": avg_launch_s * 1e6, "launches_per_step": launches_per_step, "gflop_per_launch": flop_per_launch / 1e9,
             "flop_count": "algorithmic FLOPs of the launch (dense T x T for attention), MACs x 2"}
     ab = ALGO_BYTES_PER_STREAM_FRAME.get((hz, T))
