@@ -812,8 +812,8 @@ int open_common(vapx_ingest* g, const vapx_ingest_config* cfg) {
   }
   if (!g->stage || !g->batch_audio || !g->jobs[0].out || !g->jobs[1].out) return VAPX_E_NOMEM;
   // One descriptor per input connection and one per listener: 2 x S and some.  Raise the soft RLIMIT_NOFILE towards the hard limit if it
-  // is short (round 4: on a box with `ulimit -n 8192` the last 18 of 4096 output connections waited in the listen queue until descriptors
-  // came free, their first results went to nobody, and a FIFO-pairing load generator then saw those 18 dialogues "N frames late" for good)
+  // is short, and say so if the hard limit is short too: connections beyond it wait in the listen queue (accept4 fails with EMFILE, counted
+  // in accept_fd_errors), and a dialogue whose output connection is not attached yet loses its results — they go to nobody
   {
     const rlim_t need = (rlim_t)2 * (rlim_t)g->S + 256;
     rlimit rl;
