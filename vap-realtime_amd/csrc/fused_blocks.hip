@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BM = 32 * MT;
   float* sX = lds;                 // [BM][260] LN_ffn(x) tile (A operand of FFN1)
-  float* sH = lds + BM * LDH;      // [BM][260] gelu chunk / raw x / LN_self(x)
+  float* sH = MODE == 2 ? lds : lds + BM * LDH;      // [BM][260] gelu chunk / raw x / LN_self(x).  MODE 2 (projection + LN + cross-q only) never touches sX: it is
+                                                     // launched with ONE tile of LDS, and at 158 registers three of its workgroups share a CU (round 4)
   const int tid = threadIdx.x, lane = tid & 63;
   // wave index as an SGPR: weight-fragment addresses become scalar base + lane offset (SALU pointer
   // bumps, saddr loads) instead of per-lane 64-bit VALU adds — measured 2.8 -> ~1.6 VALU per MFMA
@@ -985,7 +986,7 @@ hipError_t launch_ffn_block(const FfnArgs& a, hipStream_t st) {
     });
     if (!a.att || !a.wprojf || !a.resid || !a.xmid_out) return hipErrorInvalidValue;
     if (a.mode == 1) hipLaunchKernelGGL((ffn_block_kernel<1, 1>), dim3((a.M + 31) / 32), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((ffn_block_kernel<1, 2>), dim3((a.M + 31) / 32), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((ffn_block_kernel<1, 2>), dim3((a.M + 31) / 32), dim3(256), lds / 2, st, a);   // one tile: three workgroups per CU
     return hipGetLastError();
   }
   hipLaunchKernelGGL(ffn_block_kernel<1>, dim3((a.M + 31) / 32), dim3(256), lds, st, a);
