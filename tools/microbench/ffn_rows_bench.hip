@@ -1,8 +1,8 @@
-// Micro-benchmark of ffn_rows_f16x3_kernel (csrc/ffn_rows_f16x3.hip) on synthetic rows: times `iters` launches of one mode / tail
+// Micro-benchmark of ffn_rows_f16x3_kernel (ffn_rows_f16x3.hip next to this file: the round-5 row-stationary experiment) on synthetic rows: times `iters` launches of one mode / tail
 // combination over M rows and prints us per 128-row tile per CU.  Experiment knobs are compile-time (-DRS_EXP_...): timing only, the
 // numbers a knob produces are wrong.  Build (from the repo root):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Ivap-realtime_amd/csrc [-DRS_EXP_NO_DMA ...] -o tools/microbench/ffn_rows_bench tools/microbench/ffn_rows_bench.hip
-#include "../../vap-realtime_amd/csrc/ffn_rows_f16x3.hip"
+#include "ffn_rows_f16x3.hip"
 
 #include <cstdio>
 #include <cstring>
@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
   float *gam = dalloc(256), *bet = dalloc(256);
   hipMemcpy(gam, ones.data(), 1024, hipMemcpyHostToDevice);
   hipMemcpy(bet, zeros.data(), 1024, hipMemcpyHostToDevice);
-  FfnArgs a;
+  RowsArgs a;
   memset(&a, 0, sizeof a);
   a.xmid = resid; a.lnf_g = gam; a.lnf_b = bet; a.xout = xout; a.ln_g = gam; a.ln_b = bet; a.M = M; a.hid_scale = 1.0f;
   a.mode = mode; a.att = att; a.resid = resid; a.wrs = wrs; a.wprojf = wrs;

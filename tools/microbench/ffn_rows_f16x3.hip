@@ -38,6 +38,11 @@
 
 #include "fused_blocks.h"
 
+// (experiment, not part of libvapx: FfnArgs + the layer's weight program, see tools/microbench/ffn_rows_pack.py)
+struct RowsArgs : FfnArgs {
+  const float* wrs;
+};
+
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -89,7 +94,7 @@ __device__ unsigned long long* rs_trace_buf;
 // output projection + residual run first (long windows).  TAIL: the next layer's cross K|V (raw rows) and Q|K|V (LN_self rows) follow;
 // otherwise the block ends with x_out (+ LN_self(x_out) -> xn_out when asked for: the fused last-row block reads it).
 template <int MODE, bool TAIL>
-__global__ __launch_bounds__(512, 2) void ffn_rows_f16x3_kernel(const FfnArgs g) {
+__global__ __launch_bounds__(512, 2) void ffn_rows_f16x3_kernel(const RowsArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..7: rows 16 w .. 16 w + 15 of the 128-row tile
@@ -458,14 +463,14 @@ __global__ __launch_bounds__(512, 2) void ffn_rows_f16x3_kernel(const FfnArgs g)
 
 }  // namespace
 
-bool ffn_rows_f16x3_supported(const FfnArgs& a) {
+bool ffn_rows_f16x3_supported(const RowsArgs& a) {
   if (!a.wrs || (a.mode != 0 && a.mode != 1)) return false;
   const bool tail = a.wkvxf && a.wqkvf && a.n_qkv_chunks == 3;
   const bool none = !a.wkvxf && !a.wqkvf;
   return tail || none;
 }
 
-hipError_t launch_ffn_rows_f16x3(const FfnArgs& a, hipStream_t st) {
+hipError_t launch_ffn_rows_f16x3(const RowsArgs& a, hipStream_t st) {
   if (a.M <= 0) return hipSuccess;
   if (!ffn_rows_f16x3_supported(a)) return hipErrorInvalidValue;
   if (a.mode == 1 && (!a.att || !a.resid)) return hipErrorInvalidValue;

@@ -31,7 +31,6 @@ struct Layer {
   const float *w0f, *w3f, *wqkvf, *wkvxf, *wprojf, *wqxf, *wprojxf;   // fragment-major copies (fused blocks)
   const float *w0h, *w3h, *wqkvh, *wkvxh, *wprojh, *wqxh, *wprojxh;                             // split-precision (f16 hi/lo) fragment copies
   const float *wproj8, *wqx8, *wprojx8;   // the attention projections in the 8-wave format of the 64-row flat-row blocks (long windows)
-  const float* wrs;                       // the layer's weight program of the row-stationary split-precision block (ffn_rows_f16x3.hip)
   float hid_scale = 1.0f;   // split-precision path: static power-of-two scale of the GELU hidden row (1 unless the weights allow |gelu(h)| >= 2^15)
 };
 
@@ -469,12 +468,7 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
       if ((size_t)(M + 31) / 32 > 16384) fa.trace = nullptr;
     }
 #endif
-    if (split) {
-      // row-stationary 128-row block: modes 0 / 1 with the whole next-layer tail or none of it (the A/B flag variants keep the 64-row block)
-      fa.wrs = (h->cfg.flags & VAPX_FLAG_SPLIT_BLOCK64) ? nullptr : Lw.wrs;
-      ProfScope ps(h, CLS_FFN, st);
-      HIPCHK(h, ffn_rows_f16x3_supported(fa) ? launch_ffn_rows_f16x3(fa, st) : launch_ffn_block_f16x3(fa, st));
-    }
+    if (split) { ProfScope ps(h, CLS_FFN, st); HIPCHK(h, launch_ffn_block_f16x3(fa, st)); }
     else
     { ProfScope ps(h, CLS_FFN, st); HIPCHK(h, launch_ffn_block(fa, st)); }
   }
@@ -871,7 +865,6 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
     Lw.w0h = get("w0h"); Lw.w3h = get("w3h"); Lw.wqkvh = get("wqkvh"); Lw.wkvxh = get("wkvxh");
     Lw.wprojh = get("wprojh"); Lw.wqxh = get("wqxh"); Lw.wprojxh = get("wprojxh");
     Lw.wproj8 = get("wproj8"); Lw.wqx8 = get("wqx8"); Lw.wprojx8 = get("wprojx8");
-    Lw.wrs = get("wrs");
   }
   if (cfg->flags & VAPX_FLAG_SPLIT_F16) {
     // Static guarantees of the split-precision path, from the weights alone (host copy of the blob):

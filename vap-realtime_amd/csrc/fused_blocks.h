@@ -39,9 +39,6 @@ struct FfnArgs {
   const int* resid_rot; // [B] or null
   const int* resid_ids; // [B] stream slots (null: identity)
   int resid_T;
-  // split-precision path: the layer's weight PROGRAM for the row-stationary block (csrc/ffn_rows_f16x3.hip; weights.frag_pack_f16x3_rs,
-  // blob entry L<l>.wrs), or null (then launch_ffn_block_f16x3's 64-row block runs)
-  const float* wrs;
 };
 
 struct AttnBlockArgs {
@@ -94,6 +91,4 @@ hipError_t launch_last_block(const LastBlockArgs& a, hipStream_t st);
 hipError_t launch_conv_tail(const ConvTailArgs& a, int B, hipStream_t st);
 hipError_t launch_attn_block(const AttnBlockArgs& a, int B, hipStream_t st);   // T <= 64 only
 hipError_t launch_ffn_block(const FfnArgs& a, hipStream_t st);
-bool ffn_rows_f16x3_supported(const FfnArgs& a);                     // modes 0 / 1 with either the whole next-layer tail (cross K|V + Q|K|V) or none of it
-hipError_t launch_ffn_rows_f16x3(const FfnArgs& a, hipStream_t st);   // row-stationary 128-row block (a.wrs)
 hipError_t launch_ffn_block_f16x3(const FfnArgs& a, hipStream_t st);   // w0f/w3f/wqkvf/wkvxf point to the *h (f16 hi/lo) copies

@@ -260,11 +260,6 @@ def blob_entries(K: int, mode: str) -> List[Tuple[str, int]]:
             e.append((f"{p}.wkvxh", 2 * DIM * DIM))                                                                  # w8 format
             e.append((f"{p}.wqxh", DIM * DIM)); e.append((f"{p}.wprojxh", DIM * DIM))
             e.append((f"{p}.wqx8", DIM * DIM)); e.append((f"{p}.wprojx8", DIM * DIM))
-        # row-stationary split-precision flat-row block (csrc/ffn_rows_f16x3.hip): the layer's whole weight PROGRAM in consumption
-        # order, 256 KB per 256x256 contraction (frag_pack_f16x3_rs): output projection (self for layer 0, cross otherwise), then per
-        # 128-wide hidden sub-chunk sc = 0..5 [W0 rows 128 sc .. | W3 columns 128 sc ..] (128 KB each), then the NEXT layer's cross K,
-        # cross V, Q, K, V as 128-column halves (layers 0-2)
-        e.append((f"{p}.wrs", (12 if l < 3 else 7) * DIM * DIM))
     # fused last-row block (csrc/last_block.hip): fourteen 256x256 units of layer 3, 16x16x4-MFMA fragment-major
     # [unit][8 w][16 kc][2 ns][64 lane][4]: Wq, Wk^T per head, Wv, Wproj, Wq_x, Wk_x^T per head, Wv_x, Wproj_x,
     # W0 column chunks 0-2, W3 k-chunks 0-2
@@ -331,32 +326,6 @@ def frag_pack_f16x3_w8(W: np.ndarray, n0: int, k0: int) -> np.ndarray:
     def lay(a):   # [n = (w, l31)][k = (kc, kh, i)] -> [w][kc][kh][l31][i]
         return a.reshape(8, 32, 16, 2, 8).transpose(0, 2, 3, 1, 4)
     both = np.stack([lay(hi), lay(lo)], axis=2)           # [w][kc][hl][kh][l31][i]
-    return np.ascontiguousarray(both).reshape(-1).view(np.float32)
-
-
-def frag_pack_f16x3_rs(W: np.ndarray, n0: int, k0: int, halves: bool = False) -> np.ndarray:
-    """256x256 sub-matrix -> the weight stream of the ROW-STATIONARY split-precision block (csrc/ffn_rows_f16x3.hip): a wave keeps its 16
-    rows in registers through the whole chain and reads every weight fragment (the A operand of v_mfma_f32_16x16x32_f16: 16 output
-    columns x 32 k) from an LDS ring that LDS-DMA fills linearly, so the stream is laid out in exactly the order it is consumed.
-    w' = 2^8 w = hi + lo (f16).
-    Full order  [8 kc][16 t][2 hi/lo][64 lane][8 s]  (one k-step of 32 = all sixteen 16-column tiles, 32 KB);
-    halves      [2 g][8 kc][8 t'][2 hi/lo][64 lane][8 s], t = 8 g + t'  (the 128-column halves one after the other, 16 KB per k-step).
-    value = w'[n0 + 16 t + (lane & 15)][k0 + 32 kc + 16 (s >> 2) + 4 (lane >> 4) + (s & 3)]: the k order inside a 32-chunk is the one in
-    which a lane's accumulator registers of the PREVIOUS contraction hold its row (register r of tile t <-> column 16 t + 4 (lane >> 4) + r;
-    a k-chunk = two tiles), so accumulators become the next B operand without moving."""
-    sub = np.ascontiguousarray(W[n0:n0 + 256, k0:k0 + 256], dtype=np.float32) * np.float32(F16X3_WEIGHT_SCALE)
-    sub = np.clip(sub, -F16X3_SAT, F16X3_SAT)
-    hi = sub.astype(np.float16)
-    lo = (sub - hi.astype(np.float32)).astype(np.float16)
-    kc, g, s_ = np.meshgrid(np.arange(8), np.arange(4), np.arange(8), indexing="ij")
-    kidx = 32 * kc + 16 * (s_ >> 2) + 4 * g + (s_ & 3)                                   # [kc][g][s]
-
-    def lay(a):   # [n = (t, i)][k] -> [kc][t][g][i][s]
-        x = a.reshape(16, 16, 256)[:, :, kidx]                                           # [t][i][kc][g][s]
-        return x.transpose(2, 0, 3, 1, 4)
-    both = np.stack([lay(hi), lay(lo)], axis=2)                                          # [kc][t][hl][g][i][s]
-    if halves:
-        both = both.reshape(8, 2, 8, 2, 4, 16, 8).transpose(1, 0, 2, 3, 4, 5, 6)         # [g2][kc][t'][hl][g][i][s]
     return np.ascontiguousarray(both).reshape(-1).view(np.float32)
 
 
@@ -483,21 +452,6 @@ def pack_blob(cpc_sd: Dict[str, np.ndarray], vap_sd: Dict[str, np.ndarray], mode
             put(f"{p}.wprojx8", frag_pack_f16x3_w8(A(vap_sd[f"{src}.mha_cross.proj.weight"]), 0, 0))
             put(f"{p}.wqxf", frag_pack(A(vap_sd[f"{src}.mha_cross.query.weight"]), 0, 0))
             put(f"{p}.wprojxf", frag_pack(A(vap_sd[f"{src}.mha_cross.proj.weight"]), 0, 0))
-    def lsrc(l):
-        return "ar_channel.layers.0" if l == 0 else f"ar.layers.{l - 1}"
-    for l in range(4):
-        src = lsrc(l)
-        w0, w3 = A(vap_sd[f"{src}.ffnetwork.0.weight"]), A(vap_sd[f"{src}.ffnetwork.3.weight"])
-        prog = [frag_pack_f16x3_rs(A(vap_sd[f"{src}.mha.proj.weight" if l == 0 else f"{src}.mha_cross.proj.weight"]), 0, 0)]
-        for c in range(3):   # hidden row in six 128-wide sub-chunks: W0 rows 128 sc .. (halves order), then W3's k-steps of the same hidden columns
-            a0 = frag_pack_f16x3_rs(w0, c * 256, 0, halves=True)
-            a3 = frag_pack_f16x3_rs(w3, 0, c * 256)
-            prog += [a0[:32768], a3[:32768], a0[32768:], a3[32768:]]
-        if l < 3:
-            nx = lsrc(l + 1)
-            for nm in ("mha_cross.key", "mha_cross.value", "mha.query", "mha.key", "mha.value"):
-                prog.append(frag_pack_f16x3_rs(A(vap_sd[f"{nx}.{nm}.weight"]), 0, 0, halves=True))
-        put(f"L{l}.wrs", np.concatenate(prog))
     s3 = "ar.layers.2"
     w0_3, w3_3 = A(vap_sd[f"{s3}.ffnetwork.0.weight"]), A(vap_sd[f"{s3}.ffnetwork.3.weight"])
     put("L3.last16", np.concatenate(
