@@ -54,7 +54,7 @@ WORKLOADS = {   # name -> (streams per GPU, frame_hz, ctx_sec, mode, default ste
     "s4096_20hz": (4096, 20, 2.5, "vap", 100, 5),
     "c5": (4096, 20, 2.5, "bc+nod", 48, 3),
 }
-KERNEL_NAMES = {"ffn_block": "ffn_block_kernel", "attention": "attn_block_kernel", "conv_tail": "conv_tail_kernel",
+KERNEL_NAMES = {"ffn_block": "ffn_block_kernel", "ffn_proj": "ffn_block_kernel<.., 2>", "attention": "attn_block_kernel", "conv_tail": "conv_tail_kernel",
                 "last_row": "last_block_kernel", "lstm": "lstm_kernel", "head": "head_kernel", "conv0": "conv0_kernel"}
 
 
@@ -87,7 +87,10 @@ def model_macs(hz: int, T: int, mode: str = "vap", leader: bool = True) -> dict:
         "gemm_resid_ln": 0,
         # FFN + next layer's QKV / cross-KV (last pruned layer: absorbed); long windows: + the attention output projections and
         # the cross-attention query projections, which ride in the same flat-row blocks (fused_blocks.hip, modes 1 / 2)
-        "ffn_block": rows * D * (n_ffn * 2 * 768 + n_next * (768 + 512) + (0 if fused else n_proj * D)),
+        # (mode 1: one pre-projection per FFN block).  The mode-2 launches — attention output projection + LN_src + cross-attention query,
+        # two per stereo layer executed on all rows — are a class of their own ("ffn_proj": csrc/engine.hip CLS_FFN_PROJ)
+        "ffn_block": rows * D * (n_ffn * 2 * 768 + n_next * (768 + 512) + (0 if fused else n_ffn * D)),
+        "ffn_proj": 0 if fused else rows * D * (n_proj - n_ffn) * D,
         # pruned layer 3 on one row per channel: 14 contractions (q, Wk^T q, Wv, proj, their cross twins, FFN) + two
         # 4-head single-query attentions over T rows of 256 (score + weighted sum)
         "last_row": 0 if full else 2 * (14 * D * D + 2 * 4 * T * D * 2),
@@ -334,14 +337,16 @@ def fill_and_gate(wl: Workload, name: str):
 
 
 def load_traffic(key: str, dominant: str):
-    """HBM bytes / launch of the dominant kernel from the committed PMC passes (separate rocprofv3 --pmc runs of this very
-    command, profiles/pmc_traffic.json; counters cannot be collected inside a timed run)."""
+    """(mean HBM bytes per launch of the dominant kernel CLASS, HBM bytes of a whole tick) from the committed PMC passes (separate
+    rocprofv3 --pmc runs of this very command, profiles/pmc_traffic.json + tools/pmc_tick.py; counters cannot be collected inside a timed
+    run).  The class mean covers exactly the launches the class's HIP-event time covers."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            pt = json.load(f)
-        return pt.get(key, {}).get(dominant, {}).get("bytes_per_launch_corrected")
+            tick = json.load(f).get(key, {}).get("_tick")
+        c = tick["by_class"].get(dominant)
+        return (c["bytes_corrected"] / c["launches"] if c else None), tick["bytes_corrected"]
     except Exception:
-        return None
+        return None, None
 
 
 def run_workload(name, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=0, split_f16=False, defer_join=False):
@@ -357,7 +362,7 @@ def run_workload(name, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=0, split
         dist_util.barrier(dist, torch.cuda.synchronize)
 
     gate, twin = fill_and_gate(wl, name + ("_split_f16" if split_f16 else ""))
-    wl.profile_enable(range(13))
+    wl.profile_enable(range(len(engine.PROF_CLASSES)))
     wl.profile_read()
     NP = 3 if S * T > 100000 else 5
     for i in range(NP):
@@ -415,11 +420,17 @@ def run_workload(name, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=0, split
         kernel = "attention_long2_kernel"
     if dominant == "ffn_block" and split_f16:
         kernel = "ffn_block_f16x3_kernel"
+    class_traffic, tick_traffic = load_traffic(f"{S}x{hz}hz_T{T}" + ("" if mode == "vap" else "_" + mode) + ("_split_f16" if split_f16 else ""), dominant)
     roof = {"bound": "mfma", "kernel": kernel, "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tf / peak,
-            "traffic": load_traffic(f"{S}x{hz}hz_T{T}" + ("" if mode == "vap" else "_" + mode) + ("_split_f16" if split_f16 else ""), dominant),
+            # achieved, avg_launch_us, gflop_per_launch and traffic all describe the SAME launches: the `launches_per_step` launches of the
+            # dominant class per tick (long windows: the mode-1 flat-row blocks; the mode-2 blocks are the class "ffn_proj")
+            "traffic": class_traffic,
             "avg_launch_us": avg_launch_s * 1e6, "launches_per_step": launches_per_step, "gflop_per_launch": flop_per_launch / 1e9,
             "flop_count": "algorithmic FLOPs of the launch (dense T x T for attention), MACs x 2"}
     ab = ALGO_BYTES_PER_STREAM_FRAME.get((hz, T))
+    if ab and tick_traffic and nm == 1:
+        roof["tick_traffic"] = tick_traffic                      # HBM bytes of ONE tick, every kernel (PMC, this workload at this size)
+        roof["traffic_ratio"] = tick_traffic / (ab * S)          # / algorithmic bytes: activation hand-offs between the launches of a tick
     if ab:
         roof["hbm_algorithmic"] = {"bytes_per_stream_frame": ab, "achieved_gbs": value * ab / 1e9 / world, "peak_gbs": HBM_PEAK_GBS,
                                    "frac": value * ab / 1e9 / world / HBM_PEAK_GBS, "note": "the path is MFMA-bound: the HBM roof is two orders of magnitude away"}
@@ -439,8 +450,9 @@ def run_workload(name, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=0, split
         "per_rank": ({"value_min": S * steps / max(t[0] for t in dt_rank), "value_max": S * steps / min(t[0] for t in dt_rank)} if world > 1 else None),
         "realtime_streams_sustained": value / hz,
         "executed_gflop_per_stream_frame": exec_gflop, "executed_gflop_per_stream_frame_causal_attention": exec_gflop_causal,
-        "executed_tflops": value * exec_gflop / 1e3,
-        "executed_frac_of_fp32_mfma_peak": value * exec_gflop / 1e3 / (FP32_MFMA_PEAK_TF * world),
+        "executed_tflops": value * exec_gflop_causal / 1e3,          # attention counted as executed (causal tiles only)
+        "executed_tflops_dense_attention": value * exec_gflop / 1e3,
+        "executed_frac_of_fp32_mfma_peak": value * exec_gflop_causal / 1e3 / (FP32_MFMA_PEAK_TF * world),
         "roofline": roof,
         "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1])},
         # every kernel class against the same roof (algorithmic FLOPs of the class per step / its time in the profiled pass;
@@ -697,7 +709,7 @@ def compact_line(result: dict, full_path: str = "") -> str:
                         "tolerance_abs": result["parity_gate"]["tolerance_abs"]},
         "roofline": {"bound": roof["bound"], "kernel": roof["kernel"], "achieved": _r(roof["achieved"]), "peak": _r(roof["peak"]),
                      "unit": roof["unit"], "frac": _r(roof["frac"], 4), "traffic": _r(roof.get("traffic")), "avg_launch_us": _r(roof["avg_launch_us"]),
-                     "launches_per_step": _r(roof["launches_per_step"], 3)},
+                     "launches_per_step": _r(roof["launches_per_step"], 3), "traffic_ratio": _r(roof.get("traffic_ratio"), 3)},
     }
     if "executed_frac_of_fp32_mfma_peak" in result:
         line["executed_tflops"] = _r(result["executed_tflops"], 4)

@@ -240,10 +240,11 @@ int vapx_gemm(void* hip_stream, int32_t M, int32_t N, int32_t K, const float* A,
  * class ids: 0..4 = the GEMM by epilogue (vapx_gemm's epi 0..4), 5 fused conv2-4 tail, 6 fused FFN block,
  * 7 last-row path of the final layer, 8 conv0, 9 lstm,
  * 10 ring gather+LN, 11 attention, 12 heads, 13 the GEMM with epilogue 5 (bias + LayerNorm + GELU: a trunk follower's
- * downsample, nod's Combinator on all rows).  enable(mask) selects classes (0 = off);
+ * downsample, nod's Combinator on all rows), 14 the long-window mode-2 flat-row block (attention output projection + ln_src_attn + cross-attention
+ * query projection; the FFN block proper stays class 6).  enable(mask) selects classes (0 = off);
  * read() synchronises the device, sums the elapsed time and launch count per class since the
  * last read into total_ms[n_classes] / launches[n_classes], and recycles the events. */
-#define VAPX_PROF_CLASSES 14
+#define VAPX_PROF_CLASSES 15
 int vapx_profile_enable(vapx_handle h, uint32_t class_mask);
 int vapx_profile_read(vapx_handle h, double* total_ms, int64_t* launches, int32_t n_classes);
 

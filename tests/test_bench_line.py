@@ -91,6 +91,33 @@ def test_no_kernel_class_is_booked_twice():
         assert c in names, c
 
 
+def test_roofline_bookkeeping_describes_one_set_of_launches():
+    """Round 4's line divided the HBM bytes of ONE mode-1 launch by the mean time of three mode-1 and two mode-2 launches.  Now the mode-2
+    launches are a profile class of their own, `traffic` is the class mean over exactly the launches the HIP events cover, the tick total
+    and its ratio to the algorithmic bytes ride in the line, and `executed_tflops` counts the attention tiles that run."""
+    from vap_realtime_amd import engine
+    assert engine.PROF_CLASSES[14] == "ffn_proj"
+    D = 256
+    for hz, T, mode, n_ffn, n_proj in ((50, 250, "vap", 3, 7), (20, 100, "nod", 4, 10)):
+        m = bench.model_macs(hz, T, mode)
+        assert m["ffn_proj"] == 2 * T * D * (n_proj - n_ffn) * D
+        assert m["ffn_block"] == 2 * T * D * (n_ffn * 2 * 768 + (n_ffn - 1) * (768 + 512) + n_ffn * D)
+    assert bench.model_macs(20, 50, "vap")["ffn_proj"] == 0      # short windows: the projections ride in the fused attention block
+    # the C3 tick of the committed PMC passes: class means and the tick total
+    cls, tick = bench.load_traffic("4096x50hz_T250", "ffn_block")
+    cls2, _ = bench.load_traffic("4096x50hz_T250", "ffn_proj")
+    assert 15e9 < cls < 25e9 and 6e9 < cls2 < 10e9 and 100e9 < tick < 160e9
+    ratio = tick / (bench.ALGO_BYTES_PER_STREAM_FRAME[(50, 250)] * 4096)
+    assert 40 < ratio < 80
+    full = canned()
+    full["roofline"]["traffic_ratio"] = ratio
+    full["roofline"]["tick_traffic"] = tick
+    line = strict(bench.compact_line(full))
+    assert line["roofline"]["traffic_ratio"] == pytest.approx(ratio, rel=1e-2) and len(json.dumps(line)) < 4096
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"executed_tflops": value * exec_gflop_causal / 1e3' in src
+
+
 def test_bench_main_prints_only_the_compact_line():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert src.count("print(compact_line(") == 1

@@ -1,5 +1,7 @@
 """Pin the oracle (oracle/vap_oracle.py) against golden vectors produced by the imported,
 unmodified reference (tools/make_golden.py).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -112,3 +114,25 @@ def test_poison_golden_records_what_the_reference_does_with_a_nan_sample():
         assert np.isnan(z["p_now"][3:, s]).all() and np.isnan(z["p_future"][3:, s]).all()
         assert np.isnan(z["vad"][3:, s, 0]).all() and np.isfinite(z["vad"][:, s, 1]).all()
     assert np.isfinite(z["logits"][:, 0]).all() and np.isfinite(z["vad"][:, 0]).all()
+
+
+def test_every_fixture_carries_every_key_the_current_generator_writes():
+    """The fixtures are regenerated by tools/make_golden.py from the unmodified reference; a fixture written by an older version of
+    the script (round 4: vap20 / bc20 lacked meta.cpc_seed / meta.e_stride) must not linger: script and data have to agree."""
+    import importlib.util
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "tools", "make_golden.py")
+    src = open(path).read()
+    written = set(re.findall(r'out\["(meta\.[a-z_]+)"\]', src))
+    assert {"meta.cpc_seed", "meta.e_stride", "meta.weights_fp", "meta.audio_fp"} <= written
+    spec = importlib.util.spec_from_file_location("make_golden", path)
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    for name, cfg in mg.CASES.items():
+        z = np.load(os.path.join(root, "tests", "golden", f"{name}.npz"))
+        need = written - ({"meta.kinds"} if "kinds" not in cfg else set())
+        missing = sorted(need - set(z.files))
+        assert not missing, (name, missing)
+        assert int(z["meta.e_stride"]) == cfg.get("e_stride", 1) and int(z["meta.cpc_seed"]) == cfg.get("cpc_seed", cfg["seed"])
+        assert int(z["meta.n_frames"]) == cfg["n_frames"] and [int(s) for s in z["meta.streams"]] == cfg["streams"]

@@ -229,7 +229,11 @@ void geometry(int hz, int* hop, int* L, int P[5], int* ncpc) {
 // kernel classes for profiling: 0..4 = GEMM by epilogue (EPI_STORE .. EPI_CN_RELU), then the rest; EPI_BIAS_LN_GELU (= 5 as an epilogue id)
 // is booked as class 13 — 5 is the fused conv tail (round 3 booked both under 5: a follower's downsample GEMM was priced as conv_tail)
 enum { CLS_CONVTAIL = 5, CLS_FFN = 6, CLS_LASTROW = 7, CLS_CONV0 = 8, CLS_LSTM = 9, CLS_GATHER = 10, CLS_ATTN = 11, CLS_HEAD = 12,
-       CLS_GEMM_BIAS_LN_GELU = 13, CLS_COUNT = 14 };
+       CLS_GEMM_BIAS_LN_GELU = 13,
+       CLS_FFN_PROJ = 14,   // long windows: the mode-2 flat-row block (attention output projection + LN_src + cross-attention query): two
+                            // contractions per row where the FFN block proper has seven to twelve — its own class so that a class's
+                            // FLOPs, time and HBM bytes describe the same launches (bench.py roofline)
+       CLS_COUNT = 15 };
 static inline int gemm_class(int epi) { return epi == EPI_BIAS_LN_GELU ? CLS_GEMM_BIAS_LN_GELU : epi; }
 
 struct ProfScope {
@@ -415,7 +419,7 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
         memset(&fp, 0, sizeof fp);
         fp.mode = 2; fp.M = M; fp.att = sc.att; fp.wprojf = split ? Lw.wproj8 : Lw.wprojf; fp.resid = xin; fp.xmid_out = sc.xmid;
         fp.ln_g = Lw.ln_src_g; fp.ln_b = Lw.ln_src_b; fp.wqkvf = split ? Lw.wqx8 : Lw.wqxf; fp.n_qkv_chunks = 1; fp.qkv = sc.qx;
-        { ProfScope ps(h, CLS_FFN, st); HIPCHK(h, split ? launch_ffn_block_f16x3(fp, st) : launch_ffn_block(fp, st)); }
+        { ProfScope ps(h, CLS_FFN_PROJ, st); HIPCHK(h, split ? launch_ffn_block_f16x3(fp, st) : launch_ffn_block(fp, st)); }
         AttnArgs ax{sc.qx, sc.kvx, sc.kvx + 256, sc.att, sc.bn, T, 256, 512, 1};
         { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, split ? launch_attention_f16x3(ax, B, st) : launch_attention(ax, B, st)); }
         pre_w = split ? Lw.wprojx8 : Lw.wprojxf; pre_resid = sc.xmid;

@@ -33,7 +33,7 @@ EXPORTS = ("vapx_abi_version", "vapx_blob_floats", "vapx_create", "vapx_destroy"
            "vapx_aggregate", "vapx_frontdoor_open", "vapx_frontdoor_ports", "vapx_frontdoor_counts", "vapx_frontdoor_close")
 PROF_CLASSES = {0: "gemm_store", 1: "gemm_gelu", 2: "gemm_resid", 3: "gemm_resid_ln", 4: "gemm_cn_relu",
                 5: "conv_tail", 6: "ffn_block", 7: "last_row", 8: "conv0", 9: "lstm", 10: "gather_ln", 11: "attention", 12: "head",
-                13: "gemm_bias_ln_gelu"}
+                13: "gemm_bias_ln_gelu", 14: "ffn_proj"}
 
 
 class VapxError(RuntimeError):
