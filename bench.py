@@ -120,6 +120,62 @@ def attention_executed_fraction(T: int) -> float:
     return (nt * (nt + 1) / 2) / (nt * nt)
 
 
+def front_door_plumbing_check(n_shards: int, per_shard: int = 2) -> dict:
+    """The serving side of `--gpus N` without a GPU (the --rendezvous-only leg): ONE front door (`vapx_frontdoor_*`, the reference's single
+    port pair, vap_main.py:338-366) over N passive native front-ends, each driven by a stand-in step function that tags its answers with
+    its shard; N x per_shard dialogues connect, send one frame each and must be answered by shard k mod N, slot k div N."""
+    import numpy as np
+    from vap_realtime_amd import engine, ingest, wire
+    hop = 800
+
+    def make(tag):
+        def step(ids, audio, out):
+            out[:, :] = 0.0
+            out[:, 4] = tag
+            out[:, 5] = ids
+            out[:, engine.OUT_NVALID] = 1.0
+            return 0
+        return step
+    shards = [ingest.NativeServer.over_function(make(float(g)), per_shard, 20, max_wait_s=0.05, port_in=-1, port_out=-1) for g in range(n_shards)]
+    door = ingest.FrontDoor(shards, port_in=0, port_out=0)
+    owners = []
+    try:
+        def wait(cond, timeout=10.0):
+            t0 = time.time()
+            while not cond():
+                if time.time() - t0 > timeout:
+                    raise TimeoutError("front door plumbing check")
+                time.sleep(0.002)
+        n = n_shards * per_shard
+        ins, outs = [], []
+        for k in range(n):
+            ins.append(socket.create_connection(("127.0.0.1", door.port_in)))
+            wait(lambda: door.counts()["accepted_in"] == k + 1)
+        for k in range(n):
+            outs.append(socket.create_connection(("127.0.0.1", door.port_out)))
+            wait(lambda: door.counts()["accepted_out"] == k + 1)
+        x = np.zeros((2, hop))
+        for k in range(n):
+            ins[k].sendall(wire.encode_input(x[0] + 0.001 * (k + 1), x[1]))
+        for k in range(n):
+            outs[k].settimeout(10)
+            head = b""
+            while len(head) < 4:
+                head += outs[k].recv(4 - len(head))
+            size = int.from_bytes(head, "little")
+            body = b""
+            while len(body) < size:
+                body += outs[k].recv(size - len(body))
+            r = wire.decode_result(body)
+            owners.append([int(r["vad"][0]), int(r["vad"][1])])
+        ok = owners == [[k % n_shards, k // n_shards] for k in range(n)]
+        for so in ins + outs:
+            so.close()
+        return {"shards": n_shards, "dialogues": n, "owners": owners, "ok": bool(ok), "counts": door.counts()}
+    finally:
+        door.close()
+
+
 def free_port() -> int:
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -733,6 +789,8 @@ def compact_line(result: dict, full_path: str = "") -> str:
         line["split_f16"] = {"error": sp["error"][:80]}
     if result.get("per_rank"):
         line["per_rank"] = result["per_rank"]
+    if result.get("ranks_seen"):
+        line["ranks_seen"] = result["ranks_seen"]
     if result.get("configs"):
         line["configs"] = {k: _sub_summary(v) for k, v in result["configs"].items()}
     fe = result.get("front_end")
@@ -818,11 +876,14 @@ def main():
         ends = dist_util.gather_ints(dist, [mine[0], mine[-1], len(mine), os.getpid()])
         dist_util.barrier(dist)
         worst = dist_util.max_over_ranks(dist, 0.001 * (rank + 1))
+        seen = dist_util.ranks_seen(dist)
+        door = front_door_plumbing_check(world) if rank == 0 else None
+        dist_util.barrier(dist)
         if dist is not None:
             dist.destroy_process_group()
         if rank == 0:
             print(json.dumps({"rendezvous_only": True, "n_gpus": world, "shards": [e[:3] for e in ends], "pids": [e[3] for e in ends],
-                              "max_over_ranks": worst, "cores_pinned": pinned}))
+                              "max_over_ranks": worst, "cores_pinned": pinned, "ranks_seen": seen, "front_door": door}))
         return
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
@@ -931,6 +992,9 @@ def main():
     }
     result.update({k: v for k, v in head.items() if k not in result})
     result["config"] = head["config"]
+    if world > 1:
+        # proof that the ranks of this record met over the collective backend: sum of one 1 per rank over RCCL ("nccl") on the device
+        result["ranks_seen"] = dist_util.ranks_seen(dist, "cuda")
     if args.split_f16:
         result["dtype"] = "f16x3 split products, f32 accumulate (opt-in)"
     # kept from round 1 for continuity: throughput priced with the reference's DENSE FLOP count
@@ -955,9 +1019,18 @@ def main():
     if side and args.front_end_streams > 0:
         # every rank's engines are closed by now; rank 0 serves `front_end_streams` real-time TCP clients — one engine per GPU of the
         # job behind ONE port pair when world > 1 — while the other ranks wait in a CPU (gloo) rendezvous, their GPUs idle
+        # (the front door is ONE process over the GPUs of ONE node: the leg needs every rank of the job on this node and a visible device
+        # per rank; the waiting ranks release their cached device memory first)
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        torch.cuda.empty_cache()
         if rank == 0:
-            devs = [0] * world if args.share_gpu else list(range(world))
-            result["front_end"] = front_end_record(args.front_end_streams, 10.0, devices=devs if world > 1 else None)
+            if world != local_world:
+                result["front_end"] = {"error": f"skipped: {world} ranks over more than one node (LOCAL_WORLD_SIZE {local_world})"}
+            elif not args.share_gpu and torch.cuda.device_count() < world:
+                result["front_end"] = {"error": f"skipped: {torch.cuda.device_count()} visible devices for {world} ranks"}
+            else:
+                devs = [0] * world if args.share_gpu else list(range(world))
+                result["front_end"] = front_end_record(args.front_end_streams, 10.0, devices=devs if world > 1 else None)
         dist_util.gather_ints(dist, [rank])
 
     if rank == 0 and not args.no_cpu_baseline and mode == "vap":

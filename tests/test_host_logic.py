@@ -168,6 +168,25 @@ def test_bench_gpus_flag_really_spawns_one_rank_per_gpu():
     assert r["max_over_ranks"] == 0.002                               # the reduction saw rank 1's value
 
 
+def test_bench_gpus_4_launch_path_ranks_meet_and_one_front_door_serves_four_shards():
+    """The SCALE path kept warm without a GPU: `python bench.py --gpus 4` as the driver invokes it -> four ranks rendezvous over
+    torch.distributed (gloo here; "nccl" = RCCL on the GPU node, where the same all-reduce fills `ranks_seen` of the record), shard
+    4 x 4096 streams contiguously, and rank 0 serves 8 dialogues through ONE front door over four passive per-GPU front-ends
+    (stand-in step functions): dialogue k is answered by shard k mod 4, slot k div 4 (vapx_frontdoor_*, vap_main.py:338-366)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--rendezvous-only"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    r = json.loads([l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 4 and len(set(r["pids"])) == 4
+    assert r["shards"] == [[4096 * k, 4096 * (k + 1) - 1, 4096] for k in range(4)]
+    assert r["ranks_seen"] == {"backend": "gloo", "n": 4}
+    fd = r["front_door"]
+    assert fd["ok"] and fd["shards"] == 4 and fd["dialogues"] == 8 and fd["owners"] == [[k % 4, k // 4] for k in range(8)]
+    assert fd["counts"]["accepted_in"] == 8 and fd["counts"]["accepted_out"] == 8 and fd["counts"]["refused"] == 0
+
+
 def test_bench_flop_accounting_matches_the_survey_counts():
     """bench.py's per-kernel MAC table: the executed work it prices is below the reference's dense count by the exact savings
     (last-layer pruning, absorbed K/V, cached layer-0 Q|K|V), for both the fused (T <= 64) and the long-window kernel chains."""

@@ -117,6 +117,22 @@ def barrier(dist, device_sync=None):
         device_sync()
 
 
+def ranks_seen(dist, device: Optional[str] = None):
+    """{"backend": ..., "n": ...}: an all-reduce (sum) of one 1 per rank over the backend that carries the bench's barrier — with "nccl"
+    (RCCL) on a CUDA tensor, i.e. over xGMI: the record of a multi-GPU run then PROVES that N ranks met over RCCL, whatever the launcher
+    claimed.  Single process: {"backend": "none", "n": 1}."""
+    if dist is None:
+        return {"backend": "none", "n": 1}
+    import torch
+    backend = str(dist.get_backend())
+    dev = device or "cpu"
+    if dev != "cpu" and "nccl" not in backend:
+        dev = "cpu"
+    t = torch.ones(1, dtype=torch.float32, device=dev)
+    dist.all_reduce(t)
+    return {"backend": "nccl" if (dev != "cpu" and "nccl" in backend) else "gloo", "n": int(round(float(t.item())))}
+
+
 def max_over_ranks(dist, value: float, device: Optional[str] = None) -> float:
     if dist is None:
         return value
