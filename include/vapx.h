@@ -288,8 +288,19 @@ typedef struct vapx_ingest_config {
   double gain;              /* audio_gain, 1.0 = off */
   int32_t target_util_pct;  /* pacing: the next tick starts no earlier than (previous tick's start + its duration * 100 / pct), so the
                                engine stays at most pct % busy and batches grow instead of the queue (0 = 90; 100 = back-to-back) */
-  int32_t reserved;
+  int32_t flags;            /* VAPX_INGEST_* (0 = defaults) */
+  /* thread placement (optional; a caller that passes the shorter struct of ABI 2 as first shipped gets 0 / 0 = no pinning): with
+     cpu_count > 0 the front-end pins its threads to the cores cpu_first .. cpu_first + cpu_count - 1 (wrapping): tick (and accept) thread on
+     the first, then one core per receive thread, then one per sender thread.  Give the cores of the GPU's NUMA node, and keep load
+     generators / other tenants off them: with 4096 connections the kernel's softirq work for the sockets otherwise lands on whatever core a
+     front-end thread happens to run on and its tail latency follows the neighbours'. */
+  int32_t cpu_first;
+  int32_t cpu_count;
 } vapx_ingest_config;
+#define VAPX_INGEST_KEEP_NOFILE 1   /* never touch RLIMIT_NOFILE.  Default (flag clear): vapx_ingest_open* needs one descriptor per dialogue
+                                       and one per listener; if the process's SOFT limit is below 2 x streams + 256 it is raised towards the
+                                       hard limit with setrlimit() — a process-wide change the host should know about (select()-based code
+                                       with FD_SETSIZE tables must not be handed descriptors >= 1024) */
 
 typedef struct vapx_ingest_stats {
   int64_t frames_done;      /* stream-frames stepped and answered */
@@ -314,6 +325,9 @@ int vapx_ingest_open_fn(vapx_ingest_step_fn step, vapx_ingest_reset_fn reset, vo
                         int32_t frame_hz, int32_t mode, const vapx_ingest_config* cfg, vapx_ingest_handle* out);
 int vapx_ingest_ports(vapx_ingest_handle g, int32_t* port_in, int32_t* port_out);   /* (0, 0) for a passive shard */
 int vapx_ingest_stats_read(vapx_ingest_handle g, vapx_ingest_stats* out, int32_t reset_latency_window);
+/* Exact server-side count of late answers in the current latency window (since the last stats_read(.., 1)): result packets handed to the
+ * kernel more than 10 ms after their frame was complete on the host — the north-star bound — and the packets of the window. */
+int vapx_ingest_late_read(vapx_ingest_handle g, int64_t* over_10ms, int64_t* answered);
 void vapx_ingest_close(vapx_ingest_handle g);
 
 /* ---- one front door for N GPUs -----------------------------------------------------------------------------------------------------

@@ -1,6 +1,7 @@
 """Native front-end (libvapx vapx_ingest_* / vapx_wire_*): codec bytes == the reference's rvap/common/util.py output (goldens of
 the imported reference, tests/golden/wire.npz), and the socket plumbing — routing, ragged ticks, segmentation, back-pressure,
 broadcast, non-finite streams — over a Python step function (the real model has no CPU path)."""
+import ctypes as C
 import os
 import socket
 import struct
@@ -312,6 +313,112 @@ def test_random_segmentation_and_reconnects_keep_every_stream_exact():
         for c in ins + outs:
             c.close()
         srv.close()
+
+
+def test_many_streams_four_senders_every_stream_sees_its_frames_in_order():
+    """Per-stream order with several sender threads (advisor r04): 384 dialogues, 4 senders, 4 receivers, ticks back to back (the step
+    function is instant, so consecutive ticks overlap on their way out).  A stream's packets always leave through sender slot % 4, which walks
+    over the ticks in publication order: every listener must see its own frames 0, 1, 2, ... with non-decreasing time stamps — and the old
+    config struct (without the placement fields) must still be accepted."""
+    hop, S, F_ = 800, 384, 12
+    seen = np.zeros(S, np.int64)
+
+    def step(ids, audio, out):
+        out[:, 0] = audio[:, 0, 0]            # p_now[0] = the frame's first sample = its (stream, frame) tag
+        out[:, 1] = ids
+        return 0
+    srv = ingest.NativeServer.over_function(step, S, 20, max_wait_s=0.001, min_batch=1, rx_threads=4, tx_threads=4)
+    try:
+        ins = [socket.create_connection(("127.0.0.1", srv.port_in)) for _ in range(S)]
+        _wait(lambda: srv.stats()["in_connections"] == S, 20)
+        outs = [socket.create_connection(("127.0.0.1", srv.port_out)) for _ in range(S)]
+        _wait(lambda: srv.stats()["out_connections"] == S, 20)
+        got = [[] for _ in range(S)]
+        errs = []
+
+        def reader(lo, hi):
+            try:
+                for _ in range(F_):
+                    for k in range(lo, hi):
+                        _, r = _read_result(outs[k])
+                        got[k].append((r["t"], r["p_now"][0], int(r["p_now"][1])))
+            except Exception as e:            # noqa: BLE001
+                errs.append(e)
+        readers = [threading.Thread(target=reader, args=(a, min(S, a + 96))) for a in range(0, S, 96)]
+        for t in readers:
+            t.start()
+        for f in range(F_):                   # frames of all streams back to back: ticks pile up behind the senders
+            for k in range(S):
+                x = np.zeros((2, hop))
+                x[0, 0] = f + 1
+                ins[k].sendall(wire.encode_input(x[0], x[1]))
+        for t in readers:
+            t.join(60)
+        assert not errs, errs
+        slot_of = {}
+        for k in range(S):
+            assert [g[1] for g in got[k]] == [float(f + 1) for f in range(F_)], (k, got[k])      # in order, none lost, none doubled
+            assert all(b[0] >= a[0] for a, b in zip(got[k], got[k][1:]))                        # time stamps never go back
+            assert len({g[2] for g in got[k]}) == 1                                              # one dialogue per listener
+            slot_of[k] = got[k][0][2]
+        assert sorted(slot_of.values()) == list(range(S))
+        st = srv.stats()
+        assert st["frames_done"] == S * F_ and st["answered"] == S * F_ and 0 <= st["late_over_10ms"] <= S * F_
+    finally:
+        srv.close()
+    # a caller built against the first ABI-2 header passes the config WITHOUT the placement fields: still accepted, nothing pinned
+    lib = engine.load_library()
+    old = (C.c_int32 * 14)()
+    cfg = ingest.NativeServer._cfg(0, 0, 1.0, 0.002, 0, True, None, 0, 0, False)
+    C.memmove(old, C.byref(cfg), 56)
+    old[0] = 56
+    assert ingest._IngestConfig.cpu_first.offset == 56
+    h = C.c_void_p()
+    keep = ingest._STEP_FN(lambda u, n, i, a, o: 0)
+    assert lib.vapx_ingest_open_fn(C.cast(keep, C.c_void_p), None, None, 2, 2, 20, 0, C.byref(old), C.byref(h)) == 0
+    lib.vapx_ingest_close(h)
+    old[0] = 48                               # any other length is a configuration error
+    assert lib.vapx_ingest_open_fn(C.cast(keep, C.c_void_p), None, None, 2, 2, 20, 0, C.byref(old), C.byref(h)) != 0
+
+
+def test_pinned_front_end_threads_sit_on_the_configured_cores():
+    """vapx_ingest_config.cpu_first / cpu_count: tick (+ accept) on the first core of the range, then one per receive thread, then one per
+    sender.  Read back from /proc: every thread of the process that is pinned to exactly one core of the range."""
+    avail = sorted(os.sched_getaffinity(0))
+    if len(avail) < 4:
+        pytest.skip("needs four cores")
+    first = avail[0]
+    count = 0
+    while count < len(avail) and avail[count] == first + count:
+        count += 1
+    if count < 4:
+        pytest.skip("needs four consecutive cores")
+    count = min(count, 6)
+
+    def single_core_threads():
+        cores = []
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                m = os.sched_getaffinity(int(tid))
+            except OSError:
+                continue
+            if len(m) == 1:
+                cores.append(next(iter(m)))
+        return sorted(cores)
+    before = single_core_threads()
+    lib = engine.load_library()
+    cfg = ingest.NativeServer._cfg(0, 0, 1.0, 0.002, 0, True, None, 2, 2, False, 0.9, (first, count), True)
+    keep = ingest._STEP_FN(lambda u, n, i, a, o: 0)
+    h = C.c_void_p()
+    assert lib.vapx_ingest_open_fn(C.cast(keep, C.c_void_p), None, None, 4, 4, 20, 0, C.byref(cfg), C.byref(h)) == 0
+    try:
+        new = single_core_threads()
+        for c in before:
+            new.remove(c)
+        want = sorted([first, first] + [first + (1 + k) % count for k in range(2)] + [first + (3 + k) % count for k in range(2)])
+        assert new == want, (new, want)
+    finally:
+        lib.vapx_ingest_close(h)
 
 
 class TaggedModel(Model):

@@ -251,3 +251,34 @@ def test_non_finite_stream_is_reset_and_skipped_while_the_others_are_served():
         assert vap.resets == [1, 1] and srv.numeric_resets == 2   # ... and was reset each time; the server kept running
     finally:
         srv.stop()
+
+
+def test_process_contract_is_decided_once_and_an_inner_type_error_is_not_retried():
+    """Round 4 called process(.., on_numeric="status") inside `try: ... except TypeError: process(frames, ids)`: a TypeError raised INSIDE a
+    model that does take on_numeric was swallowed and the model stepped a second time on the same frames (advisor r04).  The contract now
+    comes from the signature, once, and an inner TypeError surfaces after exactly one call."""
+    class TwoArg(FakeVap):
+        def process(self, frames, ids):
+            return super().process(frames, ids)
+
+    class Broken(FakeVap):
+        def process(self, frames, ids, on_numeric="raise"):
+            self.calls.append("x")
+            raise TypeError("a dtype bug inside the model")
+    hop = 800
+    for cls, want in ((FakeVap, True), (TwoArg, False), (Broken, True)):
+        srv = ManyStreamServer(cls(1, hop), port_in=0, port_out=0)
+        assert srv._status_contract is want
+        srv.lin.close(); srv.lout.close()
+    vap = Broken(1, hop)
+    srv = ManyStreamServer(vap, port_in=0, port_out=0, max_wait_s=0.0)
+    srv.in_conn[0] = None
+    srv.asm.push(0, wire.encode_input(np.zeros(hop), np.zeros(hop)))
+    srv.first_ready_t = time.time() - 1.0
+    try:
+        srv._maybe_tick()
+        raise AssertionError("the model's TypeError was swallowed")
+    except TypeError as e:
+        assert "dtype bug" in str(e)
+    assert vap.calls == ["x"]                 # stepped once, not twice
+    srv.lin.close(); srv.lout.close()

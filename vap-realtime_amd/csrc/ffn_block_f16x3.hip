@@ -232,6 +232,7 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
   // q ^ (r & 7): conflict-free both ways — ds_write_b128 is served in groups of 8 consecutive lanes over 32 banks, ds_read_b128 in
   // the groups of 16 of MI355X_MICROARCH.md over 64), reads them back as rows — no barrier: both sides are this
   // wave's, DS operations of a wave complete in order — and stores 8 rows x 128 contiguous bytes = 16 whole lines per instruction.
+  static_assert(8 * 64 * 32 * sizeof(float) <= 2 * BM * LD16 * sizeof(_Float16), "the eight wave-private transposition tiles must fit inside the X tile they borrow");
   float* sT = (float*)sXh + w * (64 * 32);
   auto store_global = [&](const f32x16(&acc)[2], float* base, int ld, int col0) {
     if constexpr (MODE == 2) {               // no X tile to borrow (and no registers to spare at 4 waves per SIMD): straight from the accumulators
@@ -253,6 +254,11 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
 #pragma unroll
       for (int j = 0; j < 4; ++j) *(f32x4*)&sT[row * 32 + 4 * ((2 * j + hi) ^ (row & 7))] = quad(acc[rt], j);
     }
+    // the reads below fetch OTHER lanes' quads: the DS operations of a wave complete in order, but nothing in the language says so to the
+    // compiler — a wavefront-scope release / acquire pair and a wave barrier pin "all eight stores, then the loads" (advisor r04)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     float* bu = base + (long)m0 * ld + col0 + w * 32 + 4 * (lane & 7);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {

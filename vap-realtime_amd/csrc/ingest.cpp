@@ -15,6 +15,8 @@
 #include <fcntl.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <pthread.h>
+#include <sched.h>
 #include <sys/epoll.h>
 #include <sys/eventfd.h>
 #include <sys/resource.h>
@@ -28,6 +30,7 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <deque>
@@ -162,7 +165,8 @@ struct Job {                               // one tick's rows on their way out
   std::vector<Ready> rows;
   float* out = nullptr;                    // [max_batch][VAPX_OUT_STRIDE] pinned
   double t_unix = 0;
-  int claimed = 0, finished = 0;          // rows handed to / completed by the senders (under job_mu)
+  std::vector<std::vector<int>> part;      // row indices per sender thread: slot % X — a stream is always sent by the same thread
+  int senders_done = 0;                    // sender threads that are through with this job (under job_mu)
   bool busy = false;
 };
 
@@ -209,7 +213,7 @@ struct vapx_ingest {
 
   std::mutex job_mu;
   std::condition_variable job_cv, job_done_cv;
-  std::deque<int> job_queue;
+  int64_t jobs_published = 0;              // job k of the run lives in jobs[k & 1] (under job_mu)
 
   // stats
   std::atomic<int64_t> frames_done{0}, ticks{0}, rx_bytes{0}, tx_bytes{0}, in_conns{0}, out_conns{0}, dropped{0}, numeric_resets{0},
@@ -221,6 +225,8 @@ struct vapx_ingest {
   double dbg_t_in_first = 0, dbg_t_in_last = 0, dbg_t_out_first = 0, dbg_t_out_last = 0;   // accept thread only: CLOCK_MONOTONIC of the first / last adopted connection
   std::atomic<int64_t> accept_fd_errors{0};   // accept4() failed for lack of descriptors (EMFILE / ENFILE): the process limit is below 2 x streams
   Hist lat;
+  std::atomic<int64_t> late10{0};          // packets of the current latency window handed over > 10 ms after their frame was complete
+  bool debug = false;                      // VAPX_INGEST_DEBUG set at open: per-call stall diagnostics (two clock reads per recv / sendmsg)
   std::string err;
   bool pinned_blocks = true;               // staging came from vapx_host_alloc (false: plain calloc, no HIP device)
 
@@ -390,9 +396,9 @@ void on_data(vapx_ingest* g, int r, int slot, uint8_t* scratch, size_t cap, uint
     return;
   }
   for (int round = 0; round < 4; ++round) {   // bounded work per wake-up: fairness between streams
-    const double tr0 = mono_now();
+    const double tr0 = g->debug ? mono_now() : 0.0;
     ssize_t n = recv(s.fd_in, scratch, cap, 0);
-    atomic_max(g->dbg_recv_us, (int64_t)((mono_now() - tr0) * 1e6));              // longest recv() call
+    if (g->debug) atomic_max(g->dbg_recv_us, (int64_t)((mono_now() - tr0) * 1e6));   // longest recv() call
     if (n < 0) {
       if (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR) return;
       drop_input(g, r, slot);
@@ -556,8 +562,8 @@ void rx_main(vapx_ingest* g, int r) {
   double t_last_busy = 0.0;
   while (!g->stop.load()) {
     int n = epoll_wait(g->ep[r], evs, 256, 100);
-    const double t_in = mono_now();
-    if (n > 0 && t_last_busy > 0.0) atomic_max(g->dbg_rx_gap_us, (int64_t)((t_in - t_last_busy) * 1e6));
+    const double t_in = g->debug ? mono_now() : 0.0;
+    if (g->debug && n > 0 && t_last_busy > 0.0) atomic_max(g->dbg_rx_gap_us, (int64_t)((t_in - t_last_busy) * 1e6));
     for (int i = 0; i < n; ++i) {
       const uint64_t tag = evs[i].data.u64, kind = tag & ~0xffffffffull;
       if (kind == K_WAKE) {
@@ -572,10 +578,12 @@ void rx_main(vapx_ingest* g, int r) {
         for (int slot : todo) do_resume(g, r, slot);
       } else on_data(g, r, (int)(tag & 0xffffffffu), scratch.data(), scratch.size(), evs[i].events);
     }
-    if (n > 0) {
-      t_last_busy = mono_now();
-      atomic_max(g->dbg_rx_pass_us, (int64_t)((t_last_busy - t_in) * 1e6));
-    } else t_last_busy = 0.0;
+    if (g->debug) {
+      if (n > 0) {
+        t_last_busy = mono_now();
+        atomic_max(g->dbg_rx_pass_us, (int64_t)((t_last_busy - t_in) * 1e6));
+      } else t_last_busy = 0.0;
+    }
   }
 }
 
@@ -589,31 +597,24 @@ bool send_packet(int fd, iovec* iov, int niov, size_t total) {
   return n == (ssize_t)total;
 }
 
-void tx_main(vapx_ingest* g) {
+void tx_main(vapx_ingest* g, int x) {
   std::vector<uint8_t> tail(64 + 8 * 256);
   const int hop = g->hop;
+  int64_t next = 0;                          // the job this thread sends next: every sender walks over EVERY job, in publication order
   while (true) {
-    // claim a chunk of rows of the OLDEST job (claims and completions are serialised by job_mu: a few thousand lock operations per
-    // second).  Jobs are sent strictly one after the other: a job leaves the queue when its last row has been SENT, not when its last row
-    // has been claimed — otherwise a thread could send stream s's frame of tick k + 1 while another thread is still working through the
-    // chunk of tick k that holds s's previous frame, and a listener would see the two packets in the wrong order (round 4: found by
-    // tests/test_ingest.py::test_random_segmentation...: frames 1 and 2 of one stream swapped in 1 of 3 runs).
-    int j = -1, k0 = 0, k1 = 0;
+    // Per-stream order without serialising the ticks: the rows of a job are partitioned by slot % X, so a stream's packets always leave
+    // through the same thread, and that thread works through the jobs in the order they were published — a listener can never see frame
+    // k + 1 before frame k (round 4 kept the order by sending one job at a time: every sender idled while the last chunk of a tick was
+    // still going out; advisor r04).  A job is handed back to the tick thread when all X senders are through with it.
+    int j = -1;
     {
       std::unique_lock<std::mutex> lk(g->job_mu);
-      for (;;) {
-        if (!g->job_queue.empty() && g->jobs[g->job_queue.front()].claimed < g->jobs[g->job_queue.front()].n) break;
-        if (g->stop.load()) return;
-        g->job_cv.wait(lk);                  // nothing queued, or the front job is fully claimed and its last chunks are still being sent
-      }
-      j = g->job_queue.front();
-      Job& job = g->jobs[j];
-      k0 = job.claimed;
-      k1 = std::min(job.n, k0 + 8);
-      job.claimed = k1;
+      g->job_cv.wait(lk, [&] { return g->jobs_published > next || g->stop.load(); });
+      if (g->jobs_published <= next) return;   // stopping, nothing left to send
+      j = (int)(next & 1);
     }
     Job& job = g->jobs[j];
-    for (int k = k0; k < k1; ++k) {
+    for (int k : job.part[x]) {
       const Ready& rd = job.rows[k];
       const float* row = job.out + (size_t)k * VAPX_OUT_STRIDE;
       Slot& s = g->slots[rd.slot];
@@ -630,9 +631,9 @@ void tx_main(vapx_ingest* g) {
         const size_t total = 4 + plen;
         auto send_to = [&](std::vector<int>& fds) {
           for (size_t i = 0; i < fds.size();) {
-            const double ts0 = mono_now();
+            const double ts0 = g->debug ? mono_now() : 0.0;
             const bool sent = send_packet(fds[i], iov, 5, total);
-            atomic_max(g->dbg_send_us, (int64_t)((mono_now() - ts0) * 1e6));      // longest sendmsg() call (the socket is non-blocking)
+            if (g->debug) atomic_max(g->dbg_send_us, (int64_t)((mono_now() - ts0) * 1e6));   // longest sendmsg() call (the socket is non-blocking)
             if (sent) { g->tx_bytes.fetch_add((int64_t)total, std::memory_order_relaxed); ++i; }
             else { close(fds[i]); fds.erase(fds.begin() + i); g->dropped.fetch_add(1); g->out_conns.fetch_sub(1); }
           }
@@ -650,19 +651,19 @@ void tx_main(vapx_ingest* g) {
           }
           for (size_t d = 0; d < gone; ++d) listener_dropped(g, rd.slot);   // (slots_mu is never taken under a slot's lmu here)
         }
-        g->lat.add(mono_now() - rd.t);
+        const double lat = mono_now() - rd.t;
+        g->lat.add(lat);
+        if (lat > 0.010) g->late10.fetch_add(1, std::memory_order_relaxed);
       }
       release_buf(g, rd.slot, rd.buf);
     }
+    ++next;
     {
       std::lock_guard<std::mutex> lk(g->job_mu);
-      job.finished += k1 - k0;
-      if (job.finished >= job.n) {           // every packet of this tick is out: the next tick's rows may go (and the Job may be reused)
-        if (!g->job_queue.empty() && g->job_queue.front() == j) g->job_queue.pop_front();
-        atomic_max(g->dbg_job_tx_us, (int64_t)((unix_now() - job.t_unix) * 1e6));   // results ready -> last packet of the tick handed to the kernel
+      if (++job.senders_done >= g->X) {      // every packet of this tick is out: the Job may be reused
+        if (g->debug) atomic_max(g->dbg_job_tx_us, (int64_t)((unix_now() - job.t_unix) * 1e6));   // results ready -> last packet of the tick handed to the kernel
         job.busy = false;
         g->job_done_cv.notify_all();
-        g->job_cv.notify_all();
       }
     }
   }
@@ -745,7 +746,7 @@ void tick_main(vapx_ingest* g) {
     const double t1 = mono_now();
     earliest_next = t0 + (t1 - t0) / util;
     g->step_us.fetch_add((int64_t)((t1 - t0) * 1e6));
-    atomic_max(g->dbg_step_us, (int64_t)((t1 - t0) * 1e6));
+    if (g->debug) atomic_max(g->dbg_step_us, (int64_t)((t1 - t0) * 1e6));
     g->ticks.fetch_add(1);
     g->batch_sum.fetch_add(n);
     if (rc != 0 && rc != VAPX_E_NUMERIC) {   // the step itself failed: nothing to send; free the frames and keep serving
@@ -762,13 +763,14 @@ void tick_main(vapx_ingest* g) {
       }
     g->frames_done.fetch_add(n);
     job.t_unix = unix_now();
+    for (auto& pt : job.part) pt.clear();
+    for (int k = 0; k < n; ++k) job.part[job.rows[k].slot % g->X].push_back(k);
     {
       std::lock_guard<std::mutex> lk(g->job_mu);
       job.n = n;
-      job.claimed = 0;
-      job.finished = 0;
+      job.senders_done = 0;
       job.busy = true;
-      g->job_queue.push_back(jsel);
+      ++g->jobs_published;                   // this job is number jobs_published - 1 and sits in jobs[jsel]: publications alternate slots
     }
     g->job_cv.notify_all();
     jsel ^= 1;
@@ -785,8 +787,30 @@ void engine_reset(void* user, int32_t sid) {
   else (void)vapx_reset_stream(g->engine, sid);
 }
 
-int open_common(vapx_ingest* g, const vapx_ingest_config* cfg) {
-  g->cfg = *cfg;
+// pin a thread to one core of the configured range (vapx_ingest_config.cpu_first / cpu_count); failures are ignored: placement is a
+// tail-latency measure, not a correctness one
+void pin_to(std::thread& t, const vapx_ingest_config& c, int k) {
+  if (c.cpu_count <= 0 || !t.joinable()) return;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  CPU_SET((c.cpu_first + (k % c.cpu_count)) % CPU_SETSIZE, &set);
+  (void)pthread_setaffinity_np(t.native_handle(), sizeof set, &set);
+}
+
+// the caller's config, whatever its vintage: the struct only ever grows at the end and says how long it is
+bool read_config(const vapx_ingest_config* cfg, vapx_ingest_config* out) {
+  constexpr int32_t kFirst = (int32_t)offsetof(vapx_ingest_config, cpu_first);   // ABI 2 as first shipped: up to `reserved` (now `flags`)
+  if (!cfg || (cfg->struct_size != kFirst && cfg->struct_size != (int32_t)sizeof(vapx_ingest_config))) return false;
+  memset(out, 0, sizeof *out);
+  memcpy(out, cfg, (size_t)cfg->struct_size);
+  out->struct_size = (int32_t)sizeof(vapx_ingest_config);
+  return true;
+}
+
+int open_common(vapx_ingest* g, const vapx_ingest_config* cfg_in) {
+  if (!read_config(cfg_in, &g->cfg)) return VAPX_E_INVAL;
+  const vapx_ingest_config* cfg = &g->cfg;
+  g->debug = getenv("VAPX_INGEST_DEBUG") != nullptr;
   if (g->cfg.gain == 0.0) g->cfg.gain = 1.0;
   g->R = cfg->rx_threads > 0 ? std::min(cfg->rx_threads, 16) : 2;
   g->X = cfg->tx_threads > 0 ? std::min(cfg->tx_threads, 16) : 2;
@@ -809,12 +833,13 @@ int open_common(vapx_ingest* g, const vapx_ingest_config* cfg) {
     j.out = grab(ob);
     if (j.out) memset(j.out, 0, ob * sizeof(float));   // hipHostMalloc memory is not zeroed: a step function may leave columns unset
     j.rows.reserve(g->max_batch);
+    j.part.assign(g->X, {});
   }
   if (!g->stage || !g->batch_audio || !g->jobs[0].out || !g->jobs[1].out) return VAPX_E_NOMEM;
   // One descriptor per input connection and one per listener: 2 x S and some.  Raise the soft RLIMIT_NOFILE towards the hard limit if it
   // is short, and say so if the hard limit is short too: connections beyond it wait in the listen queue (accept4 fails with EMFILE, counted
   // in accept_fd_errors), and a dialogue whose output connection is not attached yet loses its results — they go to nobody
-  {
+  if (!(cfg->flags & VAPX_INGEST_KEEP_NOFILE)) {
     const rlim_t need = (rlim_t)2 * (rlim_t)g->S + 256;
     rlimit rl;
     if (getrlimit(RLIMIT_NOFILE, &rl) == 0 && rl.rlim_cur != RLIM_INFINITY && rl.rlim_cur < need) {
@@ -849,8 +874,13 @@ int open_common(vapx_ingest* g, const vapx_ingest_config* cfg) {
     g->accept_thread = std::thread(accept_main, g);
   }
   for (int r = 0; r < g->R; ++r) g->rx_threads.emplace_back(rx_main, g, r);
-  for (int x = 0; x < g->X; ++x) g->tx_threads.emplace_back(tx_main, g);
+  for (int x = 0; x < g->X; ++x) g->tx_threads.emplace_back(tx_main, g, x);
   g->tick_thread = std::thread(tick_main, g);
+  // placement: tick + accept on the first core of the range, then one core per receive thread, then one per sender
+  pin_to(g->tick_thread, g->cfg, 0);
+  pin_to(g->accept_thread, g->cfg, 0);
+  for (int r = 0; r < g->R; ++r) pin_to(g->rx_threads[r], g->cfg, 1 + r);
+  for (int x = 0; x < g->X; ++x) pin_to(g->tx_threads[x], g->cfg, 1 + g->R + x);
   return VAPX_OK;
 }
 
@@ -860,7 +890,8 @@ extern "C" {
 
 int vapx_ingest_open_fn(vapx_ingest_step_fn step, vapx_ingest_reset_fn reset, void* user, int32_t n_streams, int32_t max_batch,
                         int32_t frame_hz, int32_t mode, const vapx_ingest_config* cfg, vapx_ingest_handle* out) {
-  if (!step || !cfg || !out || cfg->struct_size != (int32_t)sizeof(vapx_ingest_config)) return VAPX_E_INVAL;
+  vapx_ingest_config probe;
+  if (!step || !out || !read_config(cfg, &probe)) return VAPX_E_INVAL;
   if (n_streams < 1 || max_batch < 1 || max_batch > n_streams) return VAPX_E_INVAL;
   if (frame_hz != 5 && frame_hz != 10 && frame_hz != 20 && frame_hz != 50) return VAPX_E_INVAL;
   if (mode < 0 || mode > 2) return VAPX_E_INVAL;
@@ -874,7 +905,8 @@ int vapx_ingest_open_fn(vapx_ingest_step_fn step, vapx_ingest_reset_fn reset, vo
 }
 
 int vapx_ingest_open(vapx_handle engine, const vapx_ingest_config* cfg, vapx_ingest_handle* out) {
-  if (!engine || !cfg || !out || cfg->struct_size != (int32_t)sizeof(vapx_ingest_config)) return VAPX_E_INVAL;
+  vapx_ingest_config probe;
+  if (!engine || !out || !read_config(cfg, &probe)) return VAPX_E_INVAL;
   vapx_config ec;
   int rc = vapx_get_config(engine, &ec);
   if (rc != VAPX_OK) return rc;
@@ -927,7 +959,14 @@ int vapx_ingest_stats_read(vapx_ingest_handle g, vapx_ingest_stats* st, int32_t 
   st->lat_p99_ms = g->lat.pct(0.99);
   st->lat_max_ms = (double)g->lat.max_us.load() * 1e-3;
   st->step_mean_ms = st->ticks ? (double)g->step_us.load() / (double)st->ticks * 1e-3 : 0.0;
-  if (reset_latency_window) g->lat.clear();
+  if (reset_latency_window) { g->lat.clear(); g->late10.store(0); }
+  return VAPX_OK;
+}
+
+int vapx_ingest_late_read(vapx_ingest_handle g, int64_t* over_10ms, int64_t* answered) {
+  if (!g) return VAPX_E_INVAL;
+  if (over_10ms) *over_10ms = g->late10.load();
+  if (answered) *answered = g->lat.cnt.load();
   return VAPX_OK;
 }
 
@@ -944,12 +983,12 @@ void vapx_ingest_close(vapx_ingest_handle g) {
   if (g->tick_thread.joinable()) g->tick_thread.join();
   g->job_cv.notify_all();
   for (auto& t : g->tx_threads) if (t.joinable()) t.join();
-  if (getenv("VAPX_INGEST_DEBUG"))
+  if (g->debug)
     fprintf(stderr, "[vapx ingest] longest rx pass %.2f ms, longest gap between busy rx passes %.2f ms, longest step %.2f ms, latency max %.2f ms, "
             "longest recv() %.2f ms, longest sendmsg() %.2f ms, longest tick fan-out (results ready -> last packet sent) %.2f ms\n",
             g->dbg_rx_pass_us.load() * 1e-3, g->dbg_rx_gap_us.load() * 1e-3, g->dbg_step_us.load() * 1e-3, (double)g->lat.max_us.load() * 1e-3,
             g->dbg_recv_us.load() * 1e-3, g->dbg_send_us.load() * 1e-3, g->dbg_job_tx_us.load() * 1e-3);
-  if (getenv("VAPX_INGEST_DEBUG") && g->slots) {
+  if (g->debug && g->slots) {
     // streams whose results went nowhere (no output connection attached yet) or whose frames did not all come back out
     int shown = 0, odd = 0;
     for (int i = 0; i < g->S; ++i) {

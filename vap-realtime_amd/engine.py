@@ -28,7 +28,7 @@ EXPORTS = ("vapx_abi_version", "vapx_blob_floats", "vapx_create", "vapx_destroy"
            "vapx_attach_trunk", "vapx_join", "vapx_reset_stream", "vapx_get_state", "vapx_set_state", "vapx_encode_audio",
            "vapx_transformer", "vapx_peek", "vapx_gemm", "vapx_last_error", "vapx_profile_enable",
            "vapx_profile_read", "vapx_bad_slots", "vapx_host_alloc", "vapx_host_free", "vapx_reset_carry", "vapx_get_config",
-           "vapx_ingest_open", "vapx_ingest_open_fn", "vapx_ingest_ports", "vapx_ingest_stats_read", "vapx_ingest_close",
+           "vapx_ingest_open", "vapx_ingest_open_fn", "vapx_ingest_ports", "vapx_ingest_stats_read", "vapx_ingest_late_read", "vapx_ingest_close",
            "vapx_wire_decode_input", "vapx_wire_encode_result", "vapx_vap_head", "vapx_va_classifier", "vapx_softmax256",
            "vapx_aggregate", "vapx_frontdoor_open", "vapx_frontdoor_ports", "vapx_frontdoor_counts", "vapx_frontdoor_close")
 PROF_CLASSES = {0: "gemm_store", 1: "gemm_gelu", 2: "gemm_resid", 3: "gemm_resid_ln", 4: "gemm_cn_relu",
@@ -116,6 +116,8 @@ def load_library(path: Optional[str] = None):
     lib.vapx_ingest_ports.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     lib.vapx_ingest_stats_read.restype = i32
     lib.vapx_ingest_stats_read.argtypes = [vp, vp, i32]
+    lib.vapx_ingest_late_read.restype = i32
+    lib.vapx_ingest_late_read.argtypes = [vp, vp, vp]
     lib.vapx_ingest_close.restype = None
     lib.vapx_ingest_close.argtypes = [vp]
     lib.vapx_frontdoor_open.restype = i32

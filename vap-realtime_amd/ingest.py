@@ -25,7 +25,7 @@ class _IngestConfig(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("port_in", C.c_int32), ("port_out", C.c_int32), ("rx_threads", C.c_int32),
                 ("tx_threads", C.c_int32), ("max_wait_us", C.c_int32), ("min_batch", C.c_int32), ("reset_on_connect", C.c_int32),
                 ("broadcast", C.c_int32), ("bind_any", C.c_int32), ("gain", C.c_double), ("target_util_pct", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("flags", C.c_int32), ("cpu_first", C.c_int32), ("cpu_count", C.c_int32)]
 
 
 class _IngestStats(C.Structure):
@@ -42,10 +42,14 @@ _RESET_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32)
 class NativeServer:
     def __init__(self, eng: "_engine.Engine", port_in: int = 50007, port_out: int = 50008, gain: float = 1.0, max_wait_s: float = 0.002,
                  min_batch: int = 0, reset_on_connect: bool = True, broadcast: Optional[bool] = None, rx_threads: int = 0,
-                 tx_threads: int = 0, bind_any: bool = False, target_util: float = 0.9):
+                 tx_threads: int = 0, bind_any: bool = False, target_util: float = 0.9, cores: Optional[tuple] = None,
+                 keep_nofile: bool = False):
+        """``cores`` = (first, count): pin the front-end's tick / receive / sender threads to that core range (the GPU's NUMA node; keep
+        load generators and other tenants off it).  ``keep_nofile``: never raise the process's RLIMIT_NOFILE (include/vapx.h)."""
         self.lib = _engine.load_library()
         self._keep = [eng]
-        cfg = self._cfg(port_in, port_out, gain, max_wait_s, min_batch, reset_on_connect, broadcast, rx_threads, tx_threads, bind_any, target_util)
+        cfg = self._cfg(port_in, port_out, gain, max_wait_s, min_batch, reset_on_connect, broadcast, rx_threads, tx_threads, bind_any, target_util,
+                        cores, keep_nofile)
         h = C.c_void_p()
         rc = self.lib.vapx_ingest_open(eng._h, C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -54,10 +58,12 @@ class NativeServer:
         self._ports()
 
     @staticmethod
-    def _cfg(port_in, port_out, gain, max_wait_s, min_batch, reset_on_connect, broadcast, rx_threads, tx_threads, bind_any, target_util=0.9):
+    def _cfg(port_in, port_out, gain, max_wait_s, min_batch, reset_on_connect, broadcast, rx_threads, tx_threads, bind_any, target_util=0.9,
+             cores=None, keep_nofile=False):
+        first, count = (int(cores[0]), int(cores[1])) if cores else (0, 0)
         return _IngestConfig(C.sizeof(_IngestConfig), port_in, port_out, rx_threads, tx_threads, int(max_wait_s * 1e6), min_batch,
                              1 if reset_on_connect else 0, -1 if broadcast is None else int(bool(broadcast)), int(bool(bind_any)), gain,
-                             int(round(target_util * 100)), 0)
+                             int(round(target_util * 100)), 1 if keep_nofile else 0, first, count)
 
     @classmethod
     def over_function(cls, step: Callable, n_streams: int, frame_hz: int = 20, mode: str = "vap", max_batch: Optional[int] = None,
@@ -103,9 +109,15 @@ class NativeServer:
         self.port_in, self.port_out = a.value, b.value
 
     def stats(self, reset_latency_window: bool = False) -> dict:
+        """Counters + the latency window (frame complete on the host -> packet handed to the kernel); ``late_over_10ms`` / ``answered`` are the
+        exact counts of the window (read BEFORE an optional reset of the window)."""
+        late, ans = C.c_int64(0), C.c_int64(0)
+        self.lib.vapx_ingest_late_read(self._h, C.byref(late), C.byref(ans))
         st = _IngestStats()
         self.lib.vapx_ingest_stats_read(self._h, C.byref(st), 1 if reset_latency_window else 0)
-        return {k: getattr(st, k) for k, _ in _IngestStats._fields_}
+        d = {k: getattr(st, k) for k, _ in _IngestStats._fields_}
+        d["late_over_10ms"], d["answered"] = late.value, ans.value
+        return d
 
     def close(self):
         if getattr(self, "_h", None):

@@ -21,6 +21,7 @@ whose ``process`` only takes ``(new_samples, ids)`` works too (no ``status`` key
 """
 from __future__ import annotations
 
+import inspect
 import selectors
 import socket
 import threading
@@ -36,6 +37,13 @@ class ManyStreamServer:
     def __init__(self, vap, port_in: int = 50007, port_out: int = 50008, host: str = "127.0.0.1", gain: float = 1.0,
                  max_wait_s: float = 0.004, broadcast: Optional[bool] = None, reset_on_connect: bool = True):
         self.vap = vap
+        # which contract the model's process() has is decided ONCE, from its signature (a blanket `except TypeError` around the call would
+        # also swallow a TypeError raised INSIDE a model that does take on_numeric, and step its state a second time: advisor r04)
+        try:
+            params = inspect.signature(vap.process).parameters
+            self._status_contract = "on_numeric" in params or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values())
+        except (TypeError, ValueError):
+            self._status_contract = False
         self.S = vap.n_streams
         self.hop = vap.hop
         self.mode = getattr(vap, "mode", "vap")
@@ -145,9 +153,9 @@ class ManyStreamServer:
             return
         frames = self.asm.pop(ready)
         echo = self.asm.last_echo
-        try:
+        if self._status_contract:
             res = self.vap.process(frames, ready.astype(np.int32), on_numeric="status")
-        except TypeError:                                 # a user-supplied model with the two-argument contract
+        else:                                             # a user-supplied model with the two-argument contract
             res = self.vap.process(frames, ready.astype(np.int32))
         t = time.time()
         # a stream whose results are not finite (poisoned state, engine status column) is reset and gets no packet this
