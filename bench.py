@@ -681,11 +681,15 @@ def gather_paced(dist, rank, world, rec):
     return rec
 
 
-def front_end_record(streams: int, seconds: float, devices=None):
+def front_end_record(streams: int, seconds: float, devices=None, repeat: int = 1):
     """The native TCP front-end (vapx_ingest_*) + one engine under tools/loadgen: `streams` real-time dialogue clients sending the
     reference's 10 ms packets (2560 B, vap_main.py:373-391), every result packet (12 880 B at 20 Hz) read back and timed.
     `devices` (multi-GPU job): one engine per listed GPU behind ONE port pair (vapx_frontdoor_*, what `serve --gpus N` runs; the
-    reference's single port pair, vap_main.py:338-366), `streams` clients in total."""
+    reference's single port pair, vap_main.py:338-366), `streams` clients in total.  `repeat` independent runs (fresh server each):
+    the record is the WORST run by client-side p99, the others' one-line summaries ride along.  Next to the load generator's
+    (client-side) figures the record carries the server's own latency window (frame complete on the host -> packet handed to the
+    kernel: p50 / p99 / max and the exact count of answers later than 10 ms), so that a bad run can be attributed: server, co-located
+    clients, or loopback."""
     cmd = [sys.executable, os.path.join(ROOT, "tools", "server_load.py"), "--streams", str(streams), "--seconds", str(seconds), "--warm", "4"]
     if devices and len(devices) > 1:
         cmd += ["--shards", str(len(devices)), "--devices", ",".join(str(d) for d in devices)]
@@ -695,23 +699,36 @@ def front_end_record(streams: int, seconds: float, devices=None):
             os.sched_setaffinity(0, range(os.cpu_count() or 1))
         except Exception:
             pass
-    try:
+
+    def one():
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=seconds + 240, preexec_fn=unpin)
         line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]
         r = json.loads(line)
         keep = ("streams", "frames_sent", "frames_answered", "stream_frames_per_s", "realtime_streams_served", "lat_p50_ms", "lat_p99_ms",
-                "lat_max_ms", "late_over_10ms", "server", "server_window")
+                "lat_max_ms", "late_over_10ms", "server", "server_window", "placement")
         rec = {k: r[k] for k in keep if k in r}
         st = r.get("server_stats", {})
-        rec["server_latency_ms"] = {k: st[k] for k in st if k.startswith("lat_")}
+        per = st.get("per_shard") or [st]
+        # (several shards: the worst shard's percentiles, the sum of the late answers)
+        rec["server_latency_ms"] = {k: max(p_.get(k, 0.0) for p_ in per) for k in ("lat_p50_ms", "lat_p99_ms", "lat_max_ms", "lat_mean_ms")}
+        rec["server_late_over_10ms"] = sum(int(p_.get("late_over_10ms", 0)) for p_ in per)
+        rec["server_answered"] = sum(int(p_.get("answered", 0)) for p_ in per)
         if devices and len(devices) > 1:
             rec["shards"] = len(devices)
             rec["front_door"] = st.get("front_door")
             rec["frames_done_per_shard"] = [p_.get("frames_done") for p_ in st.get("per_shard", [])]
-        rec["how"] = "tools/server_load.py: native front-end + engine on this GPU, tools/loadgen on the same host (loopback TCP), reference wire format"
+        return rec
+    try:
+        runs = [one() for _ in range(max(1, repeat))]
+        rec = max(runs, key=lambda r: r.get("lat_p99_ms", 0.0))
+        rec["runs"] = [{k: r.get(k) for k in ("lat_p50_ms", "lat_p99_ms", "lat_max_ms", "late_over_10ms", "frames_sent", "frames_answered")}
+                       | {"server_p99_ms": r["server_latency_ms"]["lat_p99_ms"], "server_late_over_10ms": r["server_late_over_10ms"]} for r in runs]
+        rec["how"] = (f"tools/server_load.py x {len(runs)} (worst run by client-side p99 shown): native front-end + engine on this GPU, its threads pinned to "
+                      "cores of the GPU's NUMA node, tools/loadgen on the other cores of the same host (loopback TCP), reference wire format")
         return rec
     except Exception as e:                                        # noqa: BLE001 - a side record must not cost the headline
         return {"error": f"{type(e).__name__}: {e}"}
+
 
 COMPACT_LIMIT = 4096          # bytes: the driver keeps an 8 KB tail of stdout; round 3's 30.8 KB line could not be parsed
 
@@ -795,9 +812,15 @@ def compact_line(result: dict, full_path: str = "") -> str:
         line["configs"] = {k: _sub_summary(v) for k, v in result["configs"].items()}
     fe = result.get("front_end")
     if isinstance(fe, dict):
-        line["front_end"] = ({"error": str(fe["error"])[:80]} if "error" in fe else
-                             {k: _r(fe.get(k)) for k in ("streams", "shards", "frames_sent", "frames_answered", "lat_p50_ms", "lat_p99_ms", "lat_max_ms", "late_over_10ms")
-                              if fe.get(k) is not None})
+        if "error" in fe:
+            line["front_end"] = {"error": str(fe["error"])[:80]}
+        else:
+            line["front_end"] = {k: _r(fe.get(k)) for k in ("streams", "shards", "frames_sent", "frames_answered", "lat_p50_ms", "lat_p99_ms", "lat_max_ms",
+                                                              "late_over_10ms") if fe.get(k) is not None}
+            sl = fe.get("server_latency_ms") or {}
+            # the server's own view of the same window: frame complete on the host -> packet handed to the kernel
+            line["front_end"].update({"srv_p50_ms": _r(sl.get("lat_p50_ms"), 3), "srv_p99_ms": _r(sl.get("lat_p99_ms"), 3), "srv_max_ms": _r(sl.get("lat_max_ms"), 3),
+                                      "srv_late_over_10ms": fe.get("server_late_over_10ms"), "runs": len(fe.get("runs") or [1])})
     if full_path:
         line["full_record"] = full_path
     text = json.dumps(line, allow_nan=False, separators=(",", ":"))
@@ -844,6 +867,7 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the latency legs, the split-precision side records and the front-end record")
     ap.add_argument("--paced-sec", type=float, default=10.0, help="duration of each paced many-stream latency run (0 = skip)")
     ap.add_argument("--front-end-streams", type=int, default=4096, help="real-time TCP clients of the front-end record (0 = skip)")
+    ap.add_argument("--front-end-repeat", type=int, default=3, help="independent runs of the front-end record; the worst (client-side p99) is reported")
     ap.add_argument("--groups", type=int, default=0, help="intra-tick overlap groups (0 = engine default)")
     ap.add_argument("--split-f16", action="store_true",
                     help="opt-in: GEMM-shaped contractions as fp32-accurate 3-term f16 split products (VAPX_FLAG_SPLIT_F16)")
@@ -1030,7 +1054,7 @@ def main():
                 result["front_end"] = {"error": f"skipped: {torch.cuda.device_count()} visible devices for {world} ranks"}
             else:
                 devs = [0] * world if args.share_gpu else list(range(world))
-                result["front_end"] = front_end_record(args.front_end_streams, 10.0, devices=devs if world > 1 else None)
+                result["front_end"] = front_end_record(args.front_end_streams, 10.0, devices=devs if world > 1 else None, repeat=args.front_end_repeat)
         dist_util.gather_ints(dist, [rank])
 
     if rank == 0 and not args.no_cpu_baseline and mode == "vap":

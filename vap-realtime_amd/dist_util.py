@@ -94,6 +94,53 @@ def pin_rank_to_cores(local_rank: int, local_world: int, device_index=None, shar
         return None
 
 
+def gpu_node_cores(device_index: int = 0):
+    """Cores (of this process's affinity mask) on the NUMA node of GPU ``device_index``'s PCI function, or every allowed core when sysfs does
+    not say.  Used to place the TCP front-end's threads next to the GPU they feed and load generators away from them."""
+    avail = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+            node = int(f.read())
+        if node >= 0:
+            with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+                cores = [c for c in _parse_cpulist(f.read()) if c in avail]
+            if cores:
+                return cores
+    except Exception:                                             # noqa: BLE001
+        pass
+    return avail
+
+
+def front_end_placement(device_index: int, n_threads: int, skip: int = 0):
+    """((first, count) for vapx_ingest_config / NativeServer(cores=...), cores left for everybody else): ``n_threads`` consecutive cores of
+    the longest run on the GPU's NUMA node (fewer if the node is smaller; ``skip`` cores of that run belong to front-ends placed earlier on
+    the same node), and the allowed cores outside that range — preferring other NUMA nodes' cores first — for load generators.
+    (None, all cores) when there are not even two cores to tell apart."""
+    avail = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    node = gpu_node_cores(device_index)
+    if len(avail) < 2 or not node:
+        return None, avail
+    runs, cur = [], [node[0]]
+    for c in node[1:]:
+        if c == cur[-1] + 1:
+            cur.append(c)
+        else:
+            runs.append(cur)
+            cur = [c]
+    runs.append(cur)
+    run = max(runs, key=len)
+    if skip >= len(run):
+        skip = 0                                                  # (more front-ends than the node has cores for: share from the start)
+    run = run[skip:]
+    count = max(1, min(len(run), n_threads, len(avail) - 1))
+    mine = set(run[:count])
+    others = [c for c in avail if c not in mine and c not in node] + [c for c in node if c not in mine and c in avail]
+    return (run[0], count), (others or avail)
+
+
 def barrier(dist, device_sync=None):
     """Device synchronise, rendezvous of all ranks, device synchronise.  With a CUDA backend the rendezvous is an all-reduce
     of one CUDA scalar (RCCL over xGMI), otherwise a CPU barrier.  Either way the HOST returns only after every rank has

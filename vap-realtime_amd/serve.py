@@ -24,7 +24,7 @@ import time
 
 def build(args):
     """(engines, shards, front door or None): N = 1 listens directly (no extra hop), N > 1 goes through the front door."""
-    from . import checkpoints, engine, ingest, weights as W
+    from . import checkpoints, dist_util, engine, ingest, weights as W
     if args.synthetic_weights is not None:
         cpc, vap = W.synthetic_weights(args.synthetic_weights, args.vap_process_rate, args.mode or "vap")
         blob, mode = W.pack_blob(cpc, vap, args.mode or "vap"), args.mode or "vap"
@@ -32,6 +32,7 @@ def build(args):
         blob, hz, mode = checkpoints.import_checkpoints(args.vap_model, args.cpc_model, frame_rate=args.vap_process_rate, mode=args.mode)
     n = max(1, args.gpus)
     engines, shards, door = [], [], None
+    taken = {}                                   # cores of a NUMA node's run already given to an earlier shard's front-end
     try:
         for r in range(n):
             dev = 0 if args.share_gpu else r
@@ -41,9 +42,15 @@ def build(args):
                                 split_f16=(args.precision == "split"))
             engines.append(eng)
             passive = n > 1
+            cores = None
+            if not args.no_pin:                  # tick / receive / sender threads next to their GPU, every shard on cores of its own
+                node_key = tuple(dist_util.gpu_node_cores(dev)[:1])
+                nthr = 1 + args.rx_threads + args.tx_threads
+                cores, _ = dist_util.front_end_placement(dev, nthr, skip=taken.get(node_key, 0))
+                taken[node_key] = taken.get(node_key, 0) + nthr
             shards.append(ingest.NativeServer(eng, port_in=-1 if passive else args.port_num_in, port_out=-1 if passive else args.port_num_out,
                                               gain=args.audio_gain, max_wait_s=args.max_wait_ms * 1e-3, bind_any=args.bind_any,
-                                              rx_threads=args.rx_threads, tx_threads=args.tx_threads))
+                                              rx_threads=args.rx_threads, tx_threads=args.tx_threads, cores=cores))
         if n > 1:
             door = ingest.FrontDoor(shards, args.port_num_in, args.port_num_out, bind_any=args.bind_any)
     except Exception:
@@ -84,6 +91,8 @@ def main(argv=None) -> int:
     ap.add_argument("--rx_threads", type=int, default=4)
     ap.add_argument("--tx_threads", type=int, default=4)
     ap.add_argument("--bind_any", action="store_true", help="listen on 0.0.0.0 instead of 127.0.0.1")
+    ap.add_argument("--no-pin", dest="no_pin", action="store_true",
+                    help="do not pin the front-end's threads (default: tick / receive / sender threads on consecutive cores of their GPU's NUMA node)")
     ap.add_argument("--stats_sec", type=float, default=10.0)
     ap.add_argument("--synthetic-weights", dest="synthetic_weights", type=int, default=None)
     args = ap.parse_args(argv)
