@@ -705,8 +705,13 @@ def front_end_record(streams: int, seconds: float, devices=None, repeat: int = 1
         line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]
         r = json.loads(line)
         keep = ("streams", "frames_sent", "frames_answered", "stream_frames_per_s", "realtime_streams_served", "lat_p50_ms", "lat_p99_ms",
-                "lat_max_ms", "late_over_10ms", "server", "server_window", "placement")
+                "lat_max_ms", "late_over_10ms", "server", "server_window", "placement", "host_limits")
         rec = {k: r[k] for k in keep if k in r}
+        nd = r.get("net_counters_delta", {})
+        # what the HOST was doing: 1-minute load average (other tenants included), the cores this container actually got during the run and
+        # whether its cgroup was throttled — on a shared box the front-end's tail follows these, not the code
+        rec["host"] = {"loadavg_1m": float((r.get("host_limits", {}).get("loadavg") or [0])[0]), "cgroup_cpu_max": r.get("host_limits", {}).get("cgroup_cpu_max"),
+                       "cores_used": round(nd.get("cgroup_usage_usec", 0) / 1e6 / (seconds + 5.0), 1), "cgroup_throttled_periods": nd.get("cgroup_nr_throttled")}
         st = r.get("server_stats", {})
         per = st.get("per_shard") or [st]
         # (several shards: the worst shard's percentiles, the sum of the late answers)
@@ -722,7 +727,8 @@ def front_end_record(streams: int, seconds: float, devices=None, repeat: int = 1
         runs = [one() for _ in range(max(1, repeat))]
         rec = max(runs, key=lambda r: r.get("lat_p99_ms", 0.0))
         rec["runs"] = [{k: r.get(k) for k in ("lat_p50_ms", "lat_p99_ms", "lat_max_ms", "late_over_10ms", "frames_sent", "frames_answered")}
-                       | {"server_p99_ms": r["server_latency_ms"]["lat_p99_ms"], "server_late_over_10ms": r["server_late_over_10ms"]} for r in runs]
+                       | {"server_p99_ms": r["server_latency_ms"]["lat_p99_ms"], "server_late_over_10ms": r["server_late_over_10ms"],
+                          "loadavg_1m": r["host"]["loadavg_1m"], "cores_used": r["host"]["cores_used"]} for r in runs]
         rec["how"] = (f"tools/server_load.py x {len(runs)} (worst run by client-side p99 shown): native front-end + engine on this GPU, its threads pinned to "
                       "cores of the GPU's NUMA node, tools/loadgen on the other cores of the same host (loopback TCP), reference wire format")
         return rec
@@ -820,7 +826,9 @@ def compact_line(result: dict, full_path: str = "") -> str:
             sl = fe.get("server_latency_ms") or {}
             # the server's own view of the same window: frame complete on the host -> packet handed to the kernel
             line["front_end"].update({"srv_p50_ms": _r(sl.get("lat_p50_ms"), 3), "srv_p99_ms": _r(sl.get("lat_p99_ms"), 3), "srv_max_ms": _r(sl.get("lat_max_ms"), 3),
-                                      "srv_late_over_10ms": fe.get("server_late_over_10ms"), "runs": len(fe.get("runs") or [1])})
+                                      "srv_late_over_10ms": fe.get("server_late_over_10ms"), "runs": len(fe.get("runs") or [1]),
+                                      "best_p99_ms": _r(min((r_.get("lat_p99_ms") or 1e9) for r_ in (fe.get("runs") or [fe])), 3),
+                                      "host_loadavg": _r((fe.get("host") or {}).get("loadavg_1m"), 3), "cores_used": (fe.get("host") or {}).get("cores_used")})
     if full_path:
         line["full_record"] = full_path
     text = json.dumps(line, allow_nan=False, separators=(",", ":"))

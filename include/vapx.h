@@ -297,6 +297,9 @@ typedef struct vapx_ingest_config {
   int32_t cpu_first;
   int32_t cpu_count;
 } vapx_ingest_config;
+#define VAPX_INGEST_CORE_SET 2      /* with cpu_count > 0: every front-end thread may run on ANY core of the range (one affinity set) instead of
+                                       one core each: keeps other processes' work off the range without nailing a thread to a core that the
+                                       kernel then borrows for softirq work */
 #define VAPX_INGEST_KEEP_NOFILE 1   /* never touch RLIMIT_NOFILE.  Default (flag clear): vapx_ingest_open* needs one descriptor per dialogue
                                        and one per listener; if the process's SOFT limit is below 2 x streams + 256 it is raised towards the
                                        hard limit with setrlimit() — a process-wide change the host should know about (select()-based code

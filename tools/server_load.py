@@ -54,6 +54,35 @@ def net_counters():
             out["netdev_max_backlog"] = int(f.read())
     except Exception:
         pass
+    # CPU-bandwidth throttling of this container (cgroup v2 cpu.stat / v1 cpu.stat): a cgroup that exhausts its quota is frozen until the
+    # next 100 ms period — every thread of server AND load generator stalls at once, whatever their placement
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat", "/sys/fs/cgroup/cpu,cpuacct/cpu.stat"):
+        try:
+            with open(path) as f:
+                for l in f:
+                    k, v = l.split()
+                    if k in ("nr_periods", "nr_throttled", "throttled_usec", "throttled_time", "usage_usec"):
+                        out["cgroup_" + k] = int(v)
+            break
+        except Exception:
+            continue
+    return out
+
+
+def host_limits():
+    out = {"cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()}
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                out["cgroup_cpu_max"] = f.read().strip()
+            break
+        except Exception:
+            continue
+    try:
+        with open("/proc/loadavg") as f:
+            out["loadavg"] = f.read().split()[:3]
+    except Exception:
+        pass
     return out
 
 
@@ -83,6 +112,9 @@ def main():
     ap.add_argument("--backlog", type=int, default=0, help="try to raise net.core.netdev_max_backlog to this before the run (needs root; 0 = leave it)")
     ap.add_argument("--fake", action="store_true", help="native front-end over a trivial step function (plumbing only, no GPU)")
     ap.add_argument("--no-pin", action="store_true", help="do not place the front-end's threads / the load generator on disjoint cores")
+    ap.add_argument("--pin-mode", default="each", choices=["each", "set", "clients-only"],
+                    help="each: one core per front-end thread; set: the front-end's threads share the core range as one affinity set (16 cores); "
+                         "clients-only: the front-end floats, only the load generator is kept off the GPU node's top cores")
     args = ap.parse_args()
     loadgen = os.path.join(ROOT, "tools", "loadgen")
     if not os.path.exists(loadgen):
@@ -96,7 +128,9 @@ def main():
     cores, client_cores = (None, None)
     if not args.no_pin and not args.python:
         first_dev = int(args.devices.split(",")[0]) if args.devices else 0
-        cores, client_cores = dist_util.front_end_placement(first_dev, 1 + args.rx_threads + args.tx_threads)
+        cores, client_cores = dist_util.front_end_placement(first_dev, 16 if args.pin_mode != "each" else 1 + args.rx_threads + args.tx_threads)
+        if args.pin_mode == "clients-only":
+            cores = None
     if args.fake:
         def step(ids, audio, out):
             out[:, 0:2] = np.abs(audio).mean(axis=2)
@@ -149,7 +183,8 @@ def main():
             eng = engine.Engine(W.pack_blob(cpc, vap_sd, args.mode), args.hz, args.ctx_sec, max_streams=S, max_batch=args.max_batch or None, groups=args.groups,
                                 mode=args.mode, split_f16=args.split_f16)
             srv = ingest.NativeServer(eng, port_in=0, port_out=0, max_wait_s=args.max_wait_ms * 1e-3, min_batch=args.min_batch,
-                                      rx_threads=args.rx_threads, tx_threads=args.tx_threads, target_util=args.target_util, cores=cores)
+                                      rx_threads=args.rx_threads, tx_threads=args.tx_threads, target_util=args.target_util, cores=cores,
+                                      core_set=(args.pin_mode == "set"))
             kind = "native front-end (vapx_ingest_*) + engine"
     cmd = [loadgen, "--port-in", str(srv.port_in), "--port-out", str(srv.port_out), "--streams", str(S), "--hz", str(args.hz),
            "--seconds", str(args.seconds), "--warm", str(args.warm), "--packet-ms", str(args.packet_ms), "--threads", str(args.client_threads)]
@@ -180,6 +215,7 @@ def main():
     res = json.loads(out.strip().splitlines()[-1])
     net1 = net_counters()
     res["net_counters_delta"] = {k: (net1[k] - net0.get(k, 0) if k != "netdev_max_backlog" else net1[k]) for k in net1}
+    res["host_limits"] = host_limits()
     res["server"] = kind
     res["placement"] = {"front_end_cores": list(cores) if cores else None, "client_cores": ([client_cores[0], client_cores[-1], len(client_cores)] if client_cores else None)}
     if hasattr(srv, "stats"):

@@ -149,6 +149,7 @@ struct Slot {
   int wbuf = -1, fill = 0;                // rx thread only
   uint8_t partial[PAIR_BYTES]; int npartial = 0;
   std::vector<uint8_t> backlog;           // bytes received while no buffer was free
+  int lowat = 0;                          // rx thread only: SO_RCVLOWAT currently set on fd_in (0 = the kernel default)
   std::atomic<bool> paused{false};        // written by the slot's rx / accept thread, read by whoever frees a buffer
   std::mutex lmu;                         // guards listeners
   std::vector<int> listeners;
@@ -226,6 +227,7 @@ struct vapx_ingest {
   std::atomic<int64_t> accept_fd_errors{0};   // accept4() failed for lack of descriptors (EMFILE / ENFILE): the process limit is below 2 x streams
   Hist lat;
   std::atomic<int64_t> late10{0};          // packets of the current latency window handed over > 10 ms after their frame was complete
+  bool no_lowat = false;                   // VAPX_INGEST_NO_LOWAT set at open: wake per packet as rounds 1-4 did (A/B measurements only)
   bool debug = false;                      // VAPX_INGEST_DEBUG set at open: per-call stall diagnostics (two clock reads per recv / sendmsg)
   std::string err;
   bool pinned_blocks = true;               // staging came from vapx_host_alloc (false: plain calloc, no HIP device)
@@ -386,6 +388,20 @@ size_t feed(vapx_ingest* g, int slot, const uint8_t* p, size_t n) {
   return used;
 }
 
+// Wake this socket's receive thread when the REST OF THE CURRENT FRAME is there, not for every 10 ms packet of it (SO_RCVLOWAT; epoll
+// honours it): a client sends hop / 160 packets per frame (vap_main.py:373-391) and nothing can be done with a part of a frame, so 4096
+// dialogues cost 82 k wake-ups + recv() calls per second instead of 410 k.  Less time on the host's cores is less exposure to whoever else
+// runs there (round 5: on a box with load average 60 from other tenants every front-end thread was losing ~10 ms slices).  Re-armed only
+// when the value changes: a sender that delivers whole frames never causes a setsockopt.
+void arm_lowat(vapx_ingest* g, Slot& s) {
+  long need = (long)(g->hop - (s.wbuf >= 0 ? s.fill : 0)) * (long)PAIR_BYTES - s.npartial;
+  if (need < 1) need = 1;
+  if (need > 65536) need = 65536;           // (5 Hz frames are 51 KB; stay well inside the receive buffer)
+  if ((int)need == s.lowat || s.fd_in < 0 || g->no_lowat) return;
+  int v = (int)need;
+  if (setsockopt(s.fd_in, SOL_SOCKET, SO_RCVLOWAT, &v, sizeof v) == 0) s.lowat = v;
+}
+
 void on_data(vapx_ingest* g, int r, int slot, uint8_t* scratch, size_t cap, uint32_t events) {
   Slot& s = g->slots[slot];
   if (s.fd_in < 0) return;
@@ -400,7 +416,7 @@ void on_data(vapx_ingest* g, int r, int slot, uint8_t* scratch, size_t cap, uint
     ssize_t n = recv(s.fd_in, scratch, cap, 0);
     if (g->debug) atomic_max(g->dbg_recv_us, (int64_t)((mono_now() - tr0) * 1e6));   // longest recv() call
     if (n < 0) {
-      if (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR) return;
+      if (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR) { arm_lowat(g, s); return; }
       drop_input(g, r, slot);
       return;
     }
@@ -425,8 +441,9 @@ void on_data(vapx_ingest* g, int r, int slot, uint8_t* scratch, size_t cap, uint
         }
       return;
     }
-    if ((size_t)n < cap) return;
+    if ((size_t)n < cap) { arm_lowat(g, s); return; }
   }
+  arm_lowat(g, s);
 }
 
 void do_resume(vapx_ingest* g, int r, int slot) {
@@ -479,7 +496,7 @@ bool adopt_in(vapx_ingest* g, int fd) {
   int one = 1;
   setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
   Slot& s = g->slots[slot];
-  s.wbuf = -1; s.fill = 0; s.npartial = 0; s.backlog.clear(); s.paused = false;
+  s.wbuf = -1; s.fill = 0; s.npartial = 0; s.backlog.clear(); s.paused = false; s.lowat = 0;
   {
     // the carry restarts from zeros for every connection (vap_main.py:368-369); reset_on_connect also clears the
     // model state, which the reference keeps.  Applied by the tick thread before its next step.
@@ -793,7 +810,11 @@ void pin_to(std::thread& t, const vapx_ingest_config& c, int k) {
   if (c.cpu_count <= 0 || !t.joinable()) return;
   cpu_set_t set;
   CPU_ZERO(&set);
-  CPU_SET((c.cpu_first + (k % c.cpu_count)) % CPU_SETSIZE, &set);
+  if (c.flags & VAPX_INGEST_CORE_SET) {
+    for (int i = 0; i < c.cpu_count; ++i) CPU_SET((c.cpu_first + i) % CPU_SETSIZE, &set);
+  } else {
+    CPU_SET((c.cpu_first + (k % c.cpu_count)) % CPU_SETSIZE, &set);
+  }
   (void)pthread_setaffinity_np(t.native_handle(), sizeof set, &set);
 }
 
@@ -811,6 +832,7 @@ int open_common(vapx_ingest* g, const vapx_ingest_config* cfg_in) {
   if (!read_config(cfg_in, &g->cfg)) return VAPX_E_INVAL;
   const vapx_ingest_config* cfg = &g->cfg;
   g->debug = getenv("VAPX_INGEST_DEBUG") != nullptr;
+  g->no_lowat = getenv("VAPX_INGEST_NO_LOWAT") != nullptr;
   if (g->cfg.gain == 0.0) g->cfg.gain = 1.0;
   g->R = cfg->rx_threads > 0 ? std::min(cfg->rx_threads, 16) : 2;
   g->X = cfg->tx_threads > 0 ? std::min(cfg->tx_threads, 16) : 2;

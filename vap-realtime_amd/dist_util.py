@@ -114,11 +114,20 @@ def gpu_node_cores(device_index: int = 0):
     return avail
 
 
+def _smt_siblings(cpu: int):
+    try:
+        with open(f"/sys/devices/system/cpu/cpu{cpu}/topology/thread_siblings_list") as f:
+            return set(_parse_cpulist(f.read().replace("-", "-")))
+    except Exception:                                             # noqa: BLE001
+        return {cpu}
+
+
 def front_end_placement(device_index: int, n_threads: int, skip: int = 0):
-    """((first, count) for vapx_ingest_config / NativeServer(cores=...), cores left for everybody else): ``n_threads`` consecutive cores of
-    the longest run on the GPU's NUMA node (fewer if the node is smaller; ``skip`` cores of that run belong to front-ends placed earlier on
-    the same node), and the allowed cores outside that range — preferring other NUMA nodes' cores first — for load generators.
-    (None, all cores) when there are not even two cores to tell apart."""
+    """((first, count) for vapx_ingest_config / NativeServer(cores=...), cores left for everybody else): ``n_threads`` consecutive cores at
+    the TOP of the longest run of the GPU's NUMA node (core 0 and its neighbours take the host's interrupts and housekeeping; ``skip`` cores
+    below the top belong to front-ends placed earlier on the same node), and the allowed cores outside that range AND outside its SMT
+    siblings — preferring other NUMA nodes' cores first — for load generators.  (None, all cores) when there are not even two cores to
+    tell apart."""
     avail = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
     node = gpu_node_cores(device_index)
     if len(avail) < 2 or not node:
@@ -131,14 +140,18 @@ def front_end_placement(device_index: int, n_threads: int, skip: int = 0):
             runs.append(cur)
             cur = [c]
     runs.append(cur)
-    run = max(runs, key=len)
+    run = max(runs, key=len)                                      # (ties: the first = the lower-numbered = the physical cores, not their SMT twins)
     if skip >= len(run):
-        skip = 0                                                  # (more front-ends than the node has cores for: share from the start)
-    run = run[skip:]
+        skip = 0                                                  # (more front-ends than the node has cores for: share from the top)
+    run = run[:len(run) - skip]
     count = max(1, min(len(run), n_threads, len(avail) - 1))
-    mine = set(run[:count])
-    others = [c for c in avail if c not in mine and c not in node] + [c for c in node if c not in mine and c in avail]
-    return (run[0], count), (others or avail)
+    mine = run[len(run) - count:]
+    blocked = set()
+    for c in mine:
+        blocked |= _smt_siblings(c)
+    blocked |= set(mine)
+    others = [c for c in avail if c not in blocked and c not in node] + [c for c in node if c not in blocked and c in avail]
+    return (mine[0], count), (others or avail)
 
 
 def barrier(dist, device_sync=None):

@@ -43,13 +43,13 @@ class NativeServer:
     def __init__(self, eng: "_engine.Engine", port_in: int = 50007, port_out: int = 50008, gain: float = 1.0, max_wait_s: float = 0.002,
                  min_batch: int = 0, reset_on_connect: bool = True, broadcast: Optional[bool] = None, rx_threads: int = 0,
                  tx_threads: int = 0, bind_any: bool = False, target_util: float = 0.9, cores: Optional[tuple] = None,
-                 keep_nofile: bool = False):
+                 keep_nofile: bool = False, core_set: bool = False):
         """``cores`` = (first, count): pin the front-end's tick / receive / sender threads to that core range (the GPU's NUMA node; keep
-        load generators and other tenants off it).  ``keep_nofile``: never raise the process's RLIMIT_NOFILE (include/vapx.h)."""
+        load generators and other tenants off it), one core each — or, with ``core_set``, all of them to the range as one affinity set.  ``keep_nofile``: never raise the process's RLIMIT_NOFILE (include/vapx.h)."""
         self.lib = _engine.load_library()
         self._keep = [eng]
         cfg = self._cfg(port_in, port_out, gain, max_wait_s, min_batch, reset_on_connect, broadcast, rx_threads, tx_threads, bind_any, target_util,
-                        cores, keep_nofile)
+                        cores, keep_nofile, core_set)
         h = C.c_void_p()
         rc = self.lib.vapx_ingest_open(eng._h, C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -59,11 +59,11 @@ class NativeServer:
 
     @staticmethod
     def _cfg(port_in, port_out, gain, max_wait_s, min_batch, reset_on_connect, broadcast, rx_threads, tx_threads, bind_any, target_util=0.9,
-             cores=None, keep_nofile=False):
+             cores=None, keep_nofile=False, core_set=False):
         first, count = (int(cores[0]), int(cores[1])) if cores else (0, 0)
         return _IngestConfig(C.sizeof(_IngestConfig), port_in, port_out, rx_threads, tx_threads, int(max_wait_s * 1e6), min_batch,
                              1 if reset_on_connect else 0, -1 if broadcast is None else int(bool(broadcast)), int(bool(bind_any)), gain,
-                             int(round(target_util * 100)), 1 if keep_nofile else 0, first, count)
+                             int(round(target_util * 100)), (1 if keep_nofile else 0) | (2 if core_set else 0), first, count)
 
     @classmethod
     def over_function(cls, step: Callable, n_streams: int, frame_hz: int = 20, mode: str = "vap", max_batch: Optional[int] = None,
