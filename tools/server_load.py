@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--backlog", type=int, default=0, help="try to raise net.core.netdev_max_backlog to this before the run (needs root; 0 = leave it)")
     ap.add_argument("--fake", action="store_true", help="native front-end over a trivial step function (plumbing only, no GPU)")
     ap.add_argument("--no-pin", action="store_true", help="do not place the front-end's threads / the load generator on disjoint cores")
-    ap.add_argument("--pin-mode", default="each", choices=["each", "set", "clients-only"],
+    ap.add_argument("--pin-mode", default="clients-only", choices=["each", "set", "clients-only"],
                     help="each: one core per front-end thread; set: the front-end's threads share the core range as one affinity set (16 cores); "
                          "clients-only: the front-end floats, only the load generator is kept off the GPU node's top cores")
     args = ap.parse_args()

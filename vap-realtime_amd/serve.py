@@ -91,8 +91,10 @@ def main(argv=None) -> int:
     ap.add_argument("--rx_threads", type=int, default=4)
     ap.add_argument("--tx_threads", type=int, default=4)
     ap.add_argument("--bind_any", action="store_true", help="listen on 0.0.0.0 instead of 127.0.0.1")
-    ap.add_argument("--no-pin", dest="no_pin", action="store_true",
-                    help="do not pin the front-end's threads (default: tick / receive / sender threads on consecutive cores of their GPU's NUMA node)")
+    ap.add_argument("--pin", dest="no_pin", action="store_false", default=True,
+                    help="pin every shard's tick / receive / sender threads to consecutive cores at the top of its GPU's NUMA node (default: the "
+                         "scheduler places them).  Worth it on a host you own — keep everything else off those cores; on a shared host it measured "
+                         "no better than floating threads (profiles/r05_frontend/README.md)")
     ap.add_argument("--stats_sec", type=float, default=10.0)
     ap.add_argument("--synthetic-weights", dest="synthetic_weights", type=int, default=None)
     args = ap.parse_args(argv)
