@@ -58,12 +58,14 @@ KERNEL_NAMES = {"ffn_block": "ffn_block_kernel", "ffn_proj": "ffn_block_kernel<.
                 "last_row": "last_block_kernel", "lstm": "lstm_kernel", "head": "head_kernel", "conv0": "conv0_kernel"}
 
 
-def model_macs(hz: int, T: int, mode: str = "vap", leader: bool = True) -> dict:
+def model_macs(hz: int, T: int, mode: str = "vap", leader: bool = True, qkv_in_attention: bool = False) -> dict:
     """EXECUTED multiply-accumulates per stream-frame (both channels) by kernel class for ONE weight set of the default path.
     vap / bc: exact last-layer pruning, absorbed last-layer K/V projections, cached layer-0 Q|K|V.  nod emits p_bc for every
     window row (vap_nod_main.py:276), so it runs the FULL last layer and the Combinator on all rows.  leader = False: a trunk
     follower (shares the leader's CPC CNN + LSTM, runs only its own downsample).  The attention classes count the DENSE T x T
-    products like SURVEY.md does (the kernels skip most of the causally masked tiles, see `attention_executed_fraction`)."""
+    products like SURVEY.md does (the kernels skip most of the causally masked tiles, see `attention_executed_fraction`).
+    qkv_in_attention (split path, long windows): the self-attention Q|K|V projections of the layers after layer 0 run inside the attention
+    kernel (csrc/attention_proj_f16x3.hip) instead of the previous layer's flat-row block — the same MACs, booked under "attention"."""
     hop = 16000 // hz
     L = hop + 320
     P0 = L // 5; P1 = P0 // 4; P2 = P1 // 2; P3 = P2 // 2; P4 = P3 // 2; ncpc = P4 - 2
@@ -76,6 +78,7 @@ def model_macs(hz: int, T: int, mode: str = "vap", leader: bool = True) -> dict:
     n_attn = 7 if full else 5                      # attention blocks on all rows (l0 self, l1.. self + cross)
     n_proj = n_attn + (3 if full else 2)           # attention output projections + cross-attention query projections
     attn = n_attn * 2 * 4 * (T * T * 64 * 2)
+    moved = rows * D * n_next * 768 if (qkv_in_attention and not fused) else 0
     m = {
         "conv0": 2 * P0 * D * 10 if leader else 0,
         "gemm_cn_relu": 2 * (P1 * 8 + P2 * 4 + P3 * 4 + ncpc * 4) * D * D if leader else 0,
@@ -89,25 +92,25 @@ def model_macs(hz: int, T: int, mode: str = "vap", leader: bool = True) -> dict:
         # the cross-attention query projections, which ride in the same flat-row blocks (fused_blocks.hip, modes 1 / 2)
         # (mode 1: one pre-projection per FFN block).  The mode-2 launches — attention output projection + LN_src + cross-attention query,
         # two per stereo layer executed on all rows — are a class of their own ("ffn_proj": csrc/engine.hip CLS_FFN_PROJ)
-        "ffn_block": rows * D * (n_ffn * 2 * 768 + n_next * (768 + 512) + (0 if fused else n_ffn * D)),
+        "ffn_block": rows * D * (n_ffn * 2 * 768 + n_next * (768 + 512) + (0 if fused else n_ffn * D)) - moved,
         "ffn_proj": 0 if fused else rows * D * (n_proj - n_ffn) * D,
         # pruned layer 3 on one row per channel: 14 contractions (q, Wk^T q, Wv, proj, their cross twins, FFN) + two
         # 4-head single-query attentions over T rows of 256 (score + weighted sum)
         "last_row": 0 if full else 2 * (14 * D * D + 2 * 4 * T * D * 2),
         "gemm_gelu": 0, "gemm_resid": 0,
         # dense T x T attention (+ in the fused block: output projections, cross-q projections)
-        "attention": attn + (rows * n_proj * D * D if fused else 0),
+        "attention": attn + (rows * n_proj * D * D if fused else 0) + moved,
         "head": 3 * D * D + 2 * D,
         "gather_ln": 0,
     }
     return m
 
 
-def macs_per_stream_frame(hz: int, T: int, mode: str = "vap") -> dict:
+def macs_per_stream_frame(hz: int, T: int, mode: str = "vap", qkv_in_attention: bool = False) -> dict:
     """Sum of `model_macs` over the weight sets of `mode` ("bc+nod": the first leads the shared CPC trunk)."""
     tot = {}
     for k, md in enumerate(mode.split("+")):
-        for c, v in model_macs(hz, T, md, leader=(k == 0)).items():
+        for c, v in model_macs(hz, T, md, leader=(k == 0), qkv_in_attention=qkv_in_attention).items():
             tot[c] = tot.get(c, 0) + v
     return tot
 
@@ -237,14 +240,17 @@ def model_weights(hz: int, mode: str):
     return cpc, sets
 
 
+ENGINE_KW = {}          # --engine-flag name (A/B runs of engine.Engine keyword switches, e.g. split_qkv_in_ffn): applied to every engine of the run
+
+
 def make_engines(cpc, sets, hz, ctx_sec, max_streams, device_id, groups=0, split_f16=False, max_batch=None):
     from vap_realtime_amd import engine, weights as W
     lead = engine.Engine(W.pack_blob(cpc, sets[0][1], sets[0][0]), hz, ctx_sec, max_streams=max_streams, max_batch=max_batch,
-                         device_id=device_id, groups=groups, mode=sets[0][0], split_f16=split_f16)
+                         device_id=device_id, groups=groups, mode=sets[0][0], split_f16=split_f16, **ENGINE_KW)
     followers = []
     for m, vap in sets[1:]:
         f = engine.Engine(W.pack_blob(cpc, vap, m), hz, ctx_sec, max_streams=max_streams, max_batch=max_batch, device_id=device_id,
-                          groups=groups, mode=m, split_f16=split_f16)
+                          groups=groups, mode=m, split_f16=split_f16, **ENGINE_KW)
         f.attach_trunk(lead)
         followers.append(f)
     return lead, followers
@@ -452,7 +458,7 @@ def run_workload(name, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=0, split
         assert not o[:, engine.OUT_STATUS].any(), "engine flagged non-finite rows"
 
     value = S * world * steps / dt
-    macs = macs_per_stream_frame(hz, T, mode)
+    macs = macs_per_stream_frame(hz, T, mode, qkv_in_attention=bool(split_f16 and T > 64 and not ENGINE_KW.get("split_qkv_in_ffn") and not ENGINE_KW.get("unfused_proj")))
     if "conv_tail" in breakdown:          # conv2-4 ran as the fused tail kernel (<= 512 streams): its MACs leave the GEMM class
         hop_ = 16000 // hz
         P1_ = (hop_ + 320) // 5 // 4
@@ -473,7 +479,7 @@ def run_workload(name, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=0, split
     peak = F16_MFMA_PEAK_TF / 3.0 if split_f16 else FP32_MFMA_PEAK_TF
     kernel = KERNEL_NAMES.get(dominant, f"gemm_f32_kernel ({dominant})")
     if dominant == "attention" and T > 64:
-        kernel = "attention_long2_kernel"
+        kernel = "attention_long_f16x3_kernel + attention_proj_f16x3_kernel" if split_f16 else "attention_long2_kernel"
     if dominant == "ffn_block" and split_f16:
         kernel = "ffn_block_f16x3_kernel"
     class_traffic, tick_traffic = load_traffic(f"{S}x{hz}hz_T{T}" + ("" if mode == "vap" else "_" + mode) + ("_split_f16" if split_f16 else ""), dominant)
@@ -880,6 +886,7 @@ def main():
     ap.add_argument("--split-f16", action="store_true",
                     help="opt-in: GEMM-shaped contractions as fp32-accurate 3-term f16 split products (VAPX_FLAG_SPLIT_F16)")
     ap.add_argument("--defer-join", action="store_true", help="with --groups > 1: let overlap groups free-run across ticks")
+    ap.add_argument("--engine-flag", action="append", default=[], help="A/B runs: boolean engine.Engine keyword to switch on (e.g. split_qkv_in_ffn); repeatable")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--share-gpu", action="store_true",
                     help="plumbing check on a 1-GPU box: every rank uses device 0 (combine with --backend gloo; RCCL cannot put two ranks on one device)")
@@ -887,6 +894,7 @@ def main():
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="multi-rank plumbing check without a GPU: spawn, rendezvous, shard the streams, barrier, print the ranks")
     args = ap.parse_args()
+    ENGINE_KW.update({k: True for k in args.engine_flag})
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # one process per GPU: re-execute under torch.distributed.run exactly as the driver would launch us

@@ -81,6 +81,9 @@ extern "C" {
                                          (VAPX_E_INVAL) for a checkpoint whose transformer weights break the static bounds (|w| >= 255) */
 #define VAPX_FLAG_UNFUSED_PROJ 1024    /* long windows (T > 64): attention output projections (+ residual + LN, + cross-attention query
                                          projection) as separate GEMM launches instead of riding in the fused blocks; kept for A/B tests */
+#define VAPX_FLAG_SPLIT_QKV_IN_FFN 2048 /* with VAPX_FLAG_SPLIT_F16 and windows longer than 64 frames: the self-attention Q|K|V of layers 1-2 come from the
+                                         previous layer's flat-row block through HBM (rounds 2-4) instead of being projected inside the attention
+                                         kernel (csrc/attention_proj_f16x3.hip); kept for A/B tests */
 #define VAPX_FLAG_UNFUSED_LAST_ROW 256 /* last layer's newest-row path as ten launches (gathers, M = 2B GEMMs, single-query
                                          attention) instead of the fused last_block_kernel; kept for A/B parity tests */
 #define VAPX_FLAG_UNFUSED_CONV 32     /* conv2-4 as three GEMM launches (materialises "h2","h3" for vapx_peek) */

@@ -190,3 +190,19 @@ def test_split_f16_hidden_scale_from_the_weight_bound():
     print(f"hidden scale < 1: split vs fp32 worst |diff| = {worst:.2e}")
     assert worst <= 1e-4
     f32.close(); f16.close()
+
+
+@pytest.mark.parametrize("name,kw", [("vap50", {}), ("vap20_10s", {}), ("vap50", {"full_last_layer": True}), ("vap50", {"unfused_last_row": True})])
+def test_qkv_projected_inside_the_attention_kernel_equals_qkv_from_the_ffn_block(name, kw):
+    """Round 5: on long windows the self-attention of layers 1-2 (and 3 when the last layer runs on all rows) projects its own Q|K|V
+    (csrc/attention_proj_f16x3.hip: the previous layer's flat-row block only writes LN_self(x)).  Both routes — and the A/B flag
+    VAPX_FLAG_SPLIT_QKV_IN_FFN that keeps the round-4 route — meet the reference goldens, and they differ only in summation order."""
+    c = Case(name)
+    w_new, l_new = _run(c, split_f16=True, **kw)
+    w_old, l_old = _run(c, split_f16=True, split_qkv_in_ffn=True, **kw)
+    for w in (w_new, w_old):
+        for k, v in w.items():
+            assert v <= TOL, (name, kw, k, v)
+    d = float(np.abs(l_new - l_old).max())
+    print(name, kw, "new", w_new["logits"], "old", w_old["logits"], "new vs old", d)
+    assert 0.0 < d <= 5e-5                               # the flag really switches kernels, and nothing but rounding moves

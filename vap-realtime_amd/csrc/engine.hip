@@ -31,6 +31,7 @@ struct Layer {
   const float *w0f, *w3f, *wqkvf, *wkvxf, *wprojf, *wqxf, *wprojxf;   // fragment-major copies (fused blocks)
   const float *w0h, *w3h, *wqkvh, *wkvxh, *wprojh, *wqxh, *wprojxh;                             // split-precision (f16 hi/lo) fragment copies
   const float *wproj8, *wqx8, *wprojx8;   // the attention projections in the 8-wave format of the 64-row flat-row blocks (long windows)
+  const float* wqkvp;                     // per-head Q|K|V weight stream of attention_proj_f16x3_kernel (layers >= 1)
   float hid_scale = 1.0f;   // split-precision path: static power-of-two scale of the GELU hidden row (1 unless the weights allow |gelu(h)| >= 2^15)
 };
 
@@ -356,6 +357,10 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
   const RowMap r256 = contiguous_rows(256), r768 = contiguous_rows(768), r512 = contiguous_rows(512);
   if (prune_last && (l_end != 4 || l_begin > 2)) prune_last = false;
   const int l_full_end = prune_last ? 3 : l_end;
+  // split path, long windows: the self-attention of a layer whose LN_self rows were written by the previous layer's flat-row block projects
+  // its own Q|K|V (attention_proj_f16x3_kernel); that block then skips the three contractions and never writes sc.qkv
+  const bool qkv_in_attn = (h->cfg.flags & VAPX_FLAG_SPLIT_F16) && !(h->cfg.flags & (VAPX_FLAG_SPLIT_QKV_IN_FFN | VAPX_FLAG_UNFUSED_PROJ)) && T > 64;
+  bool xn_ready = false;                   // sc.xn holds LN_self(layer l)(x) of every row, sc.qkv does NOT hold this layer's Q|K|V
   for (int l = l_begin; l < l_full_end; ++l) {
     const Layer& Lw = h->layer[l];
     const float* xin = sc.xl[l];
@@ -407,10 +412,18 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
         aa.q = rv->ring_qkv; aa.k = rv->ring_qkv + 256; aa.v = rv->ring_qkv + 512;
         aa.ring_rot = sc.rot; aa.ids = rv->ids;
       }
+      const bool proj_here = xn_ready && l > 0 && Lw.wqkvp;
 #ifdef VAPX_TRACE
       if (h->attn_trace && l == 1) { aa.trace = h->attn_trace; h->attn_trace_wgs = std::min<size_t>(16384, (size_t)B * 8); }
 #endif
-      { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, split ? launch_attention_f16x3(aa, B, st) : launch_attention(aa, B, st)); }
+      if (proj_here) {
+        AttnProjArgs ap{sc.xn, Lw.wqkvp, sc.att, sc.bn, T, 0};
+        ProfScope ps(h, CLS_ATTN, st);
+        HIPCHK(h, launch_attention_proj_f16x3(ap, B, st));
+      } else {
+        ProfScope ps(h, CLS_ATTN, st);
+        HIPCHK(h, split ? launch_attention_f16x3(aa, B, st) : launch_attention(aa, B, st));
+      }
       pre_att = sc.att; pre_w = split ? Lw.wproj8 : Lw.wprojf; pre_resid = ring0 ? rv->ring : xin;
       pre_ring = ring0;
       if (l > 0) {
@@ -451,11 +464,16 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
     if (pre_att) { fa.mode = 1; fa.att = pre_att; fa.wprojf = pre_w; fa.resid = pre_resid; fa.xmid_out = sc.xmid; }
     if (pre_ring) { fa.resid_rot = sc.rot; fa.resid_ids = rv->ids; fa.resid_T = T; }
     fa.w0f = split ? Lw.w0h : Lw.w0f; fa.w3f = split ? Lw.w3h : Lw.w3f; fa.hid_scale = Lw.hid_scale;
+    xn_ready = false;
     if (l + 1 < l_end) {
       const Layer& Ln = h->layer[l + 1];
       const float* nqkv = split ? Ln.wqkvh : Ln.wqkvf;
       fa.ln_g = Ln.ln_self_g; fa.ln_b = Ln.ln_self_b; fa.wqkvf = nqkv; fa.qkv = sc.qkv; fa.n_qkv_chunks = 3;
       fa.wkvxf = split ? Ln.wkvxh : Ln.wkvxf; fa.kvx = sc.kvx;
+      if (qkv_in_attn && pre_att && Ln.wqkvp && !(prune_last && l + 1 == 3)) {   // the next layer's self-attention projects Q|K|V itself
+        fa.wqkvf = nullptr; fa.n_qkv_chunks = 0; fa.xn_out = sc.xn;
+        xn_ready = true;
+      }
       if (prune_last && l + 1 == 3) {
         if (h->cfg.flags & VAPX_FLAG_UNFUSED_LAST_ROW) {   // the pruned layer needs K,V of every row but Q of one row only
           fa.wqkvf = nqkv + 65536; fa.n_qkv_chunks = 2;
@@ -869,6 +887,7 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
     Lw.w0h = get("w0h"); Lw.w3h = get("w3h"); Lw.wqkvh = get("wqkvh"); Lw.wkvxh = get("wkvxh");
     Lw.wprojh = get("wprojh"); Lw.wqxh = get("wqxh"); Lw.wprojxh = get("wprojxh");
     Lw.wproj8 = get("wproj8"); Lw.wqx8 = get("wqx8"); Lw.wprojx8 = get("wprojx8");
+    Lw.wqkvp = get("wqkvp");
   }
   if (cfg->flags & VAPX_FLAG_SPLIT_F16) {
     // Static guarantees of the split-precision path, from the weights alone (host copy of the blob):

@@ -69,6 +69,15 @@ struct AttnArgs {
 #endif
 };
 
+struct AttnProjArgs {   // attention_proj_f16x3.hip: long-window self-attention with the Q|K|V projection inside (split path, layers >= 1)
+  const float* xn;      // [B*2*T][256] LayerNorm(ln_self_attn)(x) rows of the layer (the previous layer's FFN block wrote them)
+  const float* wqkvp;   // the layer's per-head weight stream (weights.frag_pack_f16x3_qkv_heads)
+  float* out;           // [B*2*T][256] heads merged
+  const int* bn;        // [B] valid rows
+  int T;
+  int n_items;          // set by the launcher: B * 2 channels * 4 heads
+};
+
 struct LastRowArgs {
   const float* x;       // [B*2][T][256]
   const int* bn;
@@ -105,7 +114,8 @@ hipError_t launch_lstm(const LstmArgs& a, hipStream_t st);
 hipError_t launch_ring_append(const GatherArgs& a, hipStream_t st);
 hipError_t launch_gather_ln(const GatherArgs& a, hipStream_t st);
 hipError_t launch_attention(const AttnArgs& a, int B, hipStream_t st);
-hipError_t launch_attention_f16x3(const AttnArgs& a, int B, hipStream_t st);   // split-precision variant (attention_f16x3.hip), same arguments
+hipError_t launch_attention_f16x3(const AttnArgs& a, int B, hipStream_t st);
+hipError_t launch_attention_proj_f16x3(const AttnProjArgs& a, int B, hipStream_t st);   // split-precision variant (attention_f16x3.hip), same arguments
 hipError_t launch_gather_last_ln(const LastRowArgs& a, hipStream_t st);
 hipError_t launch_ln_rows(const float* x, float* y, const float* gamma, const float* beta, int rows, hipStream_t st);
 hipError_t launch_attention_last(const AttnArgs& a, int B, hipStream_t st);

@@ -188,7 +188,7 @@ class Engine:
                  max_streams: int = 1, max_batch: Optional[int] = None, mode: str = "vap", device_id: int = 0,
                  groups: int = 0, full_last_layer: bool = False, unfused_conv: bool = False,
                  materialize_x0: bool = False, unfused_last_row: bool = False, split_f16: bool = False,
-                 unfused_proj: bool = False):
+                 unfused_proj: bool = False, split_qkv_in_ffn: bool = False):
         self.lib = load_library()
         self.frame_hz = frame_hz
         self.T = int(context_len_sec * frame_hz)           # vap_main.py:221
@@ -200,7 +200,8 @@ class Engine:
         self.device_id = device_id
         blob = np.ascontiguousarray(blob, dtype=np.float32)
         flags = ((groups & 0xF) | (16 if full_last_layer else 0) | (32 if unfused_conv else 0)
-                 | (64 if materialize_x0 else 0) | (256 if unfused_last_row else 0) | (512 if split_f16 else 0) | (1024 if unfused_proj else 0))
+                 | (64 if materialize_x0 else 0) | (256 if unfused_last_row else 0) | (512 if split_f16 else 0) | (1024 if unfused_proj else 0)
+                 | (2048 if split_qkv_in_ffn else 0))
         cfg = _Config(C.sizeof(_Config), device_id, frame_hz, self.T, max_streams, self.max_batch, MODE[mode], flags)
         h = C.c_void_p()
         rc = self.lib.vapx_create(C.byref(cfg), _np_ptr(blob), blob.size, C.byref(h))

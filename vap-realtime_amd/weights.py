@@ -260,6 +260,9 @@ def blob_entries(K: int, mode: str) -> List[Tuple[str, int]]:
             e.append((f"{p}.wkvxh", 2 * DIM * DIM))                                                                  # w8 format
             e.append((f"{p}.wqxh", DIM * DIM)); e.append((f"{p}.wprojxh", DIM * DIM))
             e.append((f"{p}.wqx8", DIM * DIM)); e.append((f"{p}.wprojx8", DIM * DIM))
+            # self-attention with the Q|K|V projection INSIDE the split long-window attention kernel (csrc/attention_proj_f16x3.hip): per head the
+            # weight stream of its 192 projection rows in consumption order (frag_pack_f16x3_qkv_heads)
+            e.append((f"{p}.wqkvp", 3 * DIM * DIM))
     # fused last-row block (csrc/last_block.hip): fourteen 256x256 units of layer 3, 16x16x4-MFMA fragment-major
     # [unit][8 w][16 kc][2 ns][64 lane][4]: Wq, Wk^T per head, Wv, Wproj, Wq_x, Wk_x^T per head, Wv_x, Wproj_x,
     # W0 column chunks 0-2, W3 k-chunks 0-2
@@ -327,6 +330,24 @@ def frag_pack_f16x3_w8(W: np.ndarray, n0: int, k0: int) -> np.ndarray:
         return a.reshape(8, 32, 16, 2, 8).transpose(0, 2, 3, 1, 4)
     both = np.stack([lay(hi), lay(lo)], axis=2)           # [w][kc][hl][kh][l31][i]
     return np.ascontiguousarray(both).reshape(-1).view(np.float32)
+
+
+def frag_pack_f16x3_qkv_heads(wq: np.ndarray, wk: np.ndarray, wv: np.ndarray) -> np.ndarray:
+    """[256][256] query / key / value weights -> the per-head weight stream of csrc/attention_proj_f16x3.hip: a workgroup projects the
+    Q, K and V rows of ONE head (192 output features) for its (stream, channel) and reads the fragments from an LDS ring that LDS-DMA fills
+    linearly, so the stream is laid out exactly as consumed: [4 heads][16 kc][6 tiles = Q t0, Q t1, K t0, K t1, V t0, V t1][2 hi/lo][64 lane][8 s]
+    (12 KB per k-step of 16, 192 KB per head), w' = 2^8 w = hi + lo (f16),
+    value = w'_sel[64 h + 32 t + (lane & 31)][16 kc + 8 (lane >> 5) + s].  Returned as a float32 container (3 x 65536)."""
+    out = []
+    for W in (wq, wk, wv):
+        sub = np.clip(np.ascontiguousarray(W, dtype=np.float32) * np.float32(F16X3_WEIGHT_SCALE), -F16X3_SAT, F16X3_SAT)
+        hi = sub.astype(np.float16)
+        lo = (sub - hi.astype(np.float32)).astype(np.float16)
+        # [n = (h, t, i)][k = (kc, half, s)] -> [h][kc][t][hl][half][i][s]
+        both = np.stack([a.reshape(4, 2, 32, 16, 2, 8).transpose(0, 3, 1, 4, 2, 5) for a in (hi, lo)], axis=3)   # [h][kc][t][hl][half][i][s]
+        out.append(both)
+    allw = np.stack(out, axis=2)                                     # [h][kc][sel][t][hl][half][i][s]
+    return np.ascontiguousarray(allw).reshape(-1).view(np.float32)
 
 
 def split16_pack(W: np.ndarray) -> np.ndarray:
@@ -450,6 +471,8 @@ def pack_blob(cpc_sd: Dict[str, np.ndarray], vap_sd: Dict[str, np.ndarray], mode
             put(f"{p}.wprojxh", frag_pack_f16x3(A(vap_sd[f"{src}.mha_cross.proj.weight"]), 0, 0))
             put(f"{p}.wqx8", frag_pack_f16x3_w8(A(vap_sd[f"{src}.mha_cross.query.weight"]), 0, 0))
             put(f"{p}.wprojx8", frag_pack_f16x3_w8(A(vap_sd[f"{src}.mha_cross.proj.weight"]), 0, 0))
+            put(f"{p}.wqkvp", frag_pack_f16x3_qkv_heads(A(vap_sd[f"{src}.mha.query.weight"]), A(vap_sd[f"{src}.mha.key.weight"]),
+                                                          A(vap_sd[f"{src}.mha.value.weight"])))
             put(f"{p}.wqxf", frag_pack(A(vap_sd[f"{src}.mha_cross.query.weight"]), 0, 0))
             put(f"{p}.wprojxf", frag_pack(A(vap_sd[f"{src}.mha_cross.proj.weight"]), 0, 0))
     s3 = "ar.layers.2"
