@@ -15,7 +15,7 @@ PATH = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 def kernel_class(name: str) -> str:
     if name.startswith("ffn_block"):
         return "ffn_proj" if (name.endswith("2>(FfnArgs)")) else "ffn_block"
-    if name.startswith(("attn_block", "attention_long")):
+    if name.startswith(("attn_block", "attention_long", "attention_proj")):
         return "attention"
     for pre, cls in (("conv0", "conv0"), ("conv_tail", "conv_tail"), ("last_block", "last_row"), ("lstm", "lstm"), ("head", "head"),
                      ("ring_append", "gather_ln"), ("gather_ln", "gather_ln"), ("gemm_f32", "gemm"), ("add_kernel", "other"), ("ln_rows", "other"),
@@ -26,6 +26,7 @@ def kernel_class(name: str) -> str:
 
 
 C3_CHAIN = {"ffn_block": 3, "ffn_proj": 2, "attention": 5}    # launches per tick of the long-window chain; everything else once
+C3_SPLIT_R05 = {"attention_long_f16x3_kernel(AttnArgs)": 3, "attention_proj_f16x3_kernel(AttnProjArgs)": 2}   # round 5: Q|K|V projected inside the self-attention of layers 1-2
 
 
 def main():
@@ -43,6 +44,8 @@ def main():
         for k, v in kernels.items():
             cls = kernel_class(k)
             n = C3_CHAIN.get(cls, 1) if ticks is None else v["dispatches"] / ticks
+            if ticks is None and any("attention_proj" in kk for kk in kernels) and k in C3_SPLIT_R05:
+                n = C3_SPLIT_R05[k]
             launches[k] = n
             c = by_class.setdefault(cls, {"launches": 0.0, "bytes_corrected": 0.0, "bytes_raw": 0.0})
             c["launches"] += n

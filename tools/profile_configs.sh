@@ -24,15 +24,21 @@ pass() {  # name, counters...
   local name=$1; shift
   : > $OUT/$name.txt
   if [ "$WL" = "c3" ]; then
-    rocprofv3 --pmc "$@" --kernel-exclude-regex attention_long --kernel-iteration-range "[250-259]" -f csv -d $RAW/${name}_a -o run -- $BENCH > $OUT/$name.log 2>&1
-    rocprofv3 --pmc "$@" --kernel-include-regex attention_long --kernel-iteration-range "[1270-1295]" -f csv -d $RAW/${name}_b -o run -- $BENCH >> $OUT/$name.log 2>&1
+    rocprofv3 --pmc "$@" --kernel-exclude-regex "attention_(long|proj)" --kernel-iteration-range "[250-259]" -f csv -d $RAW/${name}_a -o run -- $BENCH > $OUT/$name.log 2>&1
+    case "$EXTRA" in
+      *split-f16*)   # split path (round 5): attention_long_f16x3 runs 3 x per tick (layer 0 + the two cross-attentions), attention_proj_f16x3 2 x
+        rocprofv3 --pmc "$@" --kernel-include-regex attention_long --kernel-iteration-range "[762-779]" -f csv -d $RAW/${name}_b -o run -- $BENCH >> $OUT/$name.log 2>&1
+        rocprofv3 --pmc "$@" --kernel-include-regex attention_proj --kernel-iteration-range "[508-519]" -f csv -d $RAW/${name}_c -o run -- $BENCH >> $OUT/$name.log 2>&1 ;;
+      *)
+        rocprofv3 --pmc "$@" --kernel-include-regex attention_long --kernel-iteration-range "[1270-1295]" -f csv -d $RAW/${name}_b -o run -- $BENCH >> $OUT/$name.log 2>&1 ;;
+    esac
   else
     rocprofv3 --pmc "$@" -f csv -d $RAW/${name}_a -o run -- $BENCH > $OUT/$name.log 2>&1
   fi
-  for csv in $(find $RAW/${name}_a $RAW/${name}_b -name "*counter_collection.csv" 2>/dev/null); do python $REPO/tools/pmc_summary.py $csv kernel >> $OUT/$name.txt; done
+  for csv in $(find $RAW/${name}_a $RAW/${name}_b $RAW/${name}_c -name "*counter_collection.csv" 2>/dev/null); do python $REPO/tools/pmc_summary.py $csv kernel >> $OUT/$name.txt; done
   [ -s $OUT/$name.txt ] || echo "no counter csv" > $OUT/$name.txt
   tail -3 $OUT/$name.log > $OUT/$name.log.tail; rm -f $OUT/$name.log
-  rm -rf $RAW/${name}_a $RAW/${name}_b
+  rm -rf $RAW/${name}_a $RAW/${name}_b $RAW/${name}_c
 }
 pass pmc_sq SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE
 pass pmc_mops SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVES

@@ -16,7 +16,7 @@ tag = sys.argv[1]
 wls = sys.argv[2:] or ["c2", "s4096_20hz", "c3", "c5"]
 KEY = {"c2": "256x20hz_T50", "s4096_20hz": "4096x20hz_T50", "c3": "4096x50hz_T250", "c5": "4096x20hz_T50_bc+nod"}
 CLASS = [("ffn_block_kernel", "ffn_block"), ("ffn_block_f16x3_kernel", "ffn_block"), ("attn_block_kernel", "attention"),
-         ("attention_long2_kernel", "attention"), ("attention_long_f16x3_kernel", "attention"), ("conv_tail_kernel", "conv_tail"), ("lstm_kernel", "lstm"), ("last_block_kernel", "last_row"),
+         ("attention_long2_kernel", "attention"), ("attention_long_f16x3_kernel", "attention"), ("attention_proj_f16x3_kernel", "attention_proj"), ("conv_tail_kernel", "conv_tail"), ("lstm_kernel", "lstm"), ("last_block_kernel", "last_row"),
          ("head_kernel", "head"), ("conv0_kernel", "conv0"), ("gather_ln_kernel", "gather_ln"), ("gemm_f32_kernel<2, 2, 4", "gemm_cn_relu"),
          ("gemm_f32_kernel<4, 1, 4", "gemm_cn_relu")]
 ours = lambda name: ("kernel" in name and "at::" not in name and "rocclr" not in name)
