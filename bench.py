@@ -811,7 +811,8 @@ def compact_line(result: dict, full_path: str = "") -> str:
     sp = result.get("split_f16")
     if isinstance(sp, dict) and "value" in sp:
         line["split_f16"] = {"value": _r(sp["value"]), "ms_per_step": _r(sp["ms_per_step"], 4), "frac": _r(sp["roofline"]["frac"], 3),
-                             "kernel": sp["roofline"]["kernel"], "parity_worst_abs": _r(sp["parity_gate"]["worst_abs"], 3)}
+                             "kernel": sp["roofline"]["kernel"], "parity_worst_abs": _r(sp["parity_gate"]["worst_abs"], 3),
+                             "traffic_ratio": _r(sp["roofline"].get("traffic_ratio"), 3)}
         if "concurrent_streams_at_10ms" in sp:
             line["split_f16"]["streams_at_10ms"] = sp["concurrent_streams_at_10ms"]
     elif isinstance(sp, dict) and "error" in sp:
