@@ -339,8 +339,16 @@ constexpr int ALD16 = 264;   // halves per sAtt row in SPLIT mode
 // QX: the launch also produces the cross-attention queries, qx = LayerNorm(x'; ln_src) . Wq_x^T (self-attention half of a stereo layer).
 // Without QX nothing in the launch consumes LayerNorm(x') — the FFN block normalises xmid itself when it stages its tile — so the
 // block stores x' straight from the accumulators and skips the LayerNorm altogether (3 of the 5 attention launches of a tick).
-template <bool SPLIT, bool QX>
+// R52 (round 5, fp32 path, T <= 52 — the reference's 2.5 s x 20 Hz window is T = 50): the projections run on 32 + 5 x 4 rows instead of
+// 2 x 32.  Rows 32.. of the window go through v_mfma_f32_4x4x1_16B_f32 (sixteen 4 x 4 blocks per instruction, the same 64 FLOP / clk /
+// SIMD as the 32x32x2 MFMA): block b of lane group 4 b .. 4 b + 3 pairs four ROWS (A: lane 4 b + i = row i) with four COLUMNS (B: lane
+// 4 b + j = column j) — and a lane's B value is exactly what the 32x32x2 weight fragment already holds in that lane (column 32 ns + (lane &
+// 31), k = 8 kc + 4 (lane >> 5) + s), so the SAME ring registers feed both shapes and nothing is streamed twice.  Lanes 0-31 and 32-63
+// accumulate the two k-halves of a k-step for the same 32 columns; one cross-half add at the end.  40 small MFMAs (320 clk) replace the 8
+// big ones (512 clk) of the second row tile in every k-step: -19 % of the projection's matrix-core time for T = 50 (14 of 64 rows were padding).
+template <bool SPLIT, bool QX, bool R52 = false>
 __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs a) {
+  static_assert(!(SPLIT && R52), "the 4-row tiles exist for the fp32 fragments only");
   __shared__ __attribute__((aligned(16))) float lds[4 * 64 * KV_LD2];
   __shared__ float vmx[4];                  // SPLIT: max |V| of each head's tile (bounds the attention output: a convex combination of V rows)
   float* sAtt = lds;                        // [64][260] (aliases the V tiles after a barrier)
@@ -521,12 +529,26 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
   const int ccol = SPLIT ? w * 64 + 2 * l31 : w * 64 + l31;
   constexpr int CS = SPLIT ? 1 : 32;   // column distance between acc[2 mt] and acc[2 mt + 1]
   f32x16 acc[4];
+  f32x4 g4[5][2];                      // R52: rows 32 + 4 g + r (r = register), column 64 w + 32 ns + l31; the two lane halves hold the two k-halves
   __builtin_amdgcn_sched_barrier(0);   // (the row offsets below must not be hoisted above the attention phase: 32 live registers)
   {
     const float* rbase = a.resid + slab_q * T * 256;           // workgroup-uniform base + 32-bit per-lane offsets
     const int h4 = opaque_vgpr(kh);
+    if constexpr (R52) {               // the residual rides in lane half 0 only (the halves are added at the end)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+      for (int gI = 0; gI < 5; ++gI)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int i = 32 + 4 * gI + r;
+          i = i < T ? i : T - 1;
+          const unsigned off = (unsigned)prow(i) * 256u + (unsigned)ccol;
+          const float v0 = rbase[off], v1 = rbase[off + CS];
+          g4[gI][0][r] = hi ? 0.f : v0;
+          g4[gI][1][r] = hi ? 0.f : v1;
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < (R52 ? 1 : 2); ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int i = mt * 32 + (r & 3) + 8 * (r >> 2) + h4;
@@ -620,6 +642,53 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
         for (int r = 0; r < 16; ++r) acc[t][r] *= split_inv;   // weights are packed as 2^8 w (and the operand rows may carry a power-of-two scale)
       return;
     }
+    if constexpr (R52) {
+      // row tile 0 as below (A fragment one k-step ahead); rows 32.. in five 4-row groups: lane L reads row 32 + 4 g + (L & 3) at the k-half
+      // (L >> 5) of the step — 8 distinct addresses per ds_read_b128 — at the top of the step, to land under tile 0's eight MFMAs
+      const float* pg = sAtt + (32 + (lane & 3)) * 260 + kh;
+      f32x4 q0, q1;
+      q0 = *(const f32x4*)(pa);
+#pragma unroll 1
+      for (int blk = 0; blk < 4; ++blk) {
+        const f32x4* nx = blk < 3 ? wf + (blk + 1) * 16 * 64 : wnext;
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) {
+          const int kc = blk * 8 + k8, kn = (kc + 1) & 31;
+          f32x4& ac = (k8 & 1) ? q1 : q0;
+          f32x4& an = (k8 & 1) ? q0 : q1;
+          an = *(const f32x4*)(pa + kn * 8);
+          f32x4 ag[5];
+#pragma unroll
+          for (int gI = 0; gI < 5; ++gI) ag[gI] = *(const f32x4*)(pg + gI * 4 * 260 + kc * 8);
+#pragma unroll
+          for (int sI = 0; sI < 4; ++sI) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[sI], ring[k8 * 2][sI], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[sI], ring[k8 * 2 + 1][sI], acc[1], 0, 0, 0);
+          }
+#pragma unroll
+          for (int sI = 0; sI < 4; ++sI)
+#pragma unroll
+            for (int gI = 0; gI < 5; ++gI) {
+              g4[gI][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(ag[gI][sI], ring[k8 * 2][sI], g4[gI][0], 0, 0, 0);
+              g4[gI][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(ag[gI][sI], ring[k8 * 2 + 1][sI], g4[gI][1], 0, 0, 0);
+            }
+          ring[k8 * 2] = nx[(k8 * 2) * 64 + lane];
+          ring[k8 * 2 + 1] = nx[(k8 * 2 + 1) * 64 + lane];
+          __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 48, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // the two k-halves of every 4-row group meet: afterwards BOTH lane halves hold the finished value of (row, column 32 ns + l31)
+#pragma unroll
+      for (int gI = 0; gI < 5; ++gI)
+#pragma unroll
+        for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) g4[gI][ns][r] += __shfl_xor(g4[gI][ns][r], 32);
+      return;
+    }
     // A fragments ping-pong between two register sets so the LDS reads of step k+1 fly under the
     // MFMAs of step k (see ffn_block_kernel)
     f32x4 p0[2], p1[2];
@@ -664,7 +733,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
     const unsigned o0 = (unsigned)h4 * 256u + (unsigned)ccol;
     const int T4 = T - h4;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < (R52 ? 1 : 2); ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = mt * 32 + (r & 3) + 8 * (r >> 2);
@@ -673,6 +742,18 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
           xbase[off] = acc[mt * 2][r]; xbase[off + CS] = acc[mt * 2 + 1][r];
         }
       }
+    if constexpr (R52) {               // rows 32..: lane half 0 stores (both halves hold the value): 32 lanes x 4 bytes = one 128-byte segment per row and tile
+#pragma unroll
+      for (int gI = 0; gI < 5; ++gI)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 32 + 4 * gI + r;
+          if (row < T && !hi) {
+            const unsigned off = (unsigned)row * 256u + (unsigned)ccol;
+            xbase[off] = g4[gI][0][r]; xbase[off + CS] = g4[gI][1][r];
+          }
+        }
+    }
     STAMP();   // 7: xmid stores issued
   } else {
     // x' tile -> LDS (fp32 rows), then ROW-PER-WAVE LayerNorm: wave w owns rows w, w + 4, ...; a lane holds 4 columns of the row, the
@@ -684,12 +765,19 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
       const int h4 = opaque_vgpr(kh);
       float* ps = sAtt + h4 * 260 + ccol;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < (R52 ? 1 : 2); ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int c = mt * 32 + (r & 3) + 8 * (r >> 2);
           ps[c * 260] = acc[mt * 2][r]; ps[c * 260 + CS] = acc[mt * 2 + 1][r];
         }
+      if constexpr (R52) {             // rows 32 .. 51 from the 4-row groups (lane half 0); rows 52 .. 63 keep the attention phase's finite bytes
+#pragma unroll
+        for (int gI = 0; gI < 5; ++gI)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (!hi) { sAtt[(32 + 4 * gI + r) * 260 + ccol] = g4[gI][0][r]; sAtt[(32 + 4 * gI + r) * 260 + ccol + CS] = g4[gI][1][r]; }
+      }
     }
     __syncthreads();
     float* xbase = a.xmid + (long)bc * T * 256 + lane * 4;
@@ -734,6 +822,10 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    if constexpr (R52) {
+#pragma unroll
+      for (int gI = 0; gI < 5; ++gI) { g4[gI][0] = f32x4{0.f, 0.f, 0.f, 0.f}; g4[gI][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
     mm(acc, a.wqxf, nullptr, 1.0f / 256.0f);
     STAMP();   // 8: cross-q projection MFMAs done
     const int h4 = opaque_vgpr(kh);
@@ -741,7 +833,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
     const unsigned o0 = (unsigned)h4 * 256u + (unsigned)ccol;
     const int T4 = T - h4;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < (R52 ? 1 : 2); ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = mt * 32 + (r & 3) + 8 * (r >> 2);
@@ -750,6 +842,18 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
           qbase[off] = acc[mt * 2][r]; qbase[off + CS] = acc[mt * 2 + 1][r];
         }
       }
+    if constexpr (R52) {
+#pragma unroll
+      for (int gI = 0; gI < 5; ++gI)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 32 + 4 * gI + r;
+          if (row < T && !hi) {
+            const unsigned off = (unsigned)row * 256u + (unsigned)ccol;
+            qbase[off] = g4[gI][0][r]; qbase[off + CS] = g4[gI][1][r];
+          }
+        }
+    }
   }
 #ifdef VAPX_TRACE
   STAMP();   // 8 or 9: stores issued
@@ -964,6 +1068,9 @@ hipError_t launch_attn_block(const AttnBlockArgs& a, int B, hipStream_t st) {
   if (a.split) {
     if (a.wqxf) hipLaunchKernelGGL((attn_block_kernel<true, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((attn_block_kernel<true, false>), grid, block, 0, st, a);
+  } else if (a.T <= 52 && a.T > 32) {   // 32 + 5 x 4 row tiles (the reference's T = 50)
+    if (a.wqxf) hipLaunchKernelGGL((attn_block_kernel<false, true, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((attn_block_kernel<false, false, true>), grid, block, 0, st, a);
   } else {
     if (a.wqxf) hipLaunchKernelGGL((attn_block_kernel<false, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((attn_block_kernel<false, false>), grid, block, 0, st, a);
