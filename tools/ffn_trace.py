@@ -17,6 +17,15 @@ if SPLIT:       # ffn_block_f16x3_kernel<0>: coarser stamps (VAPX_FLAG_SPLIT_F16
              "LN->LDS + q mm+store", "k mm+store", "v mm+store"]
 NST = len(NAMES)
 t = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 32).astype(np.int64)
+if SPLIT and (t[:, 30] > 0).any() and int(np.median(t[t[:, 30] > 0, 30])) != NST:
+    # the kernel records how many stamps it wrote: mode 1 without Q|K|V chunks (round 5: the next layer's attention kernel projects them)
+    NST = int(np.median(t[t[:, 30] > 0, 30]))
+    head = ["entry", "attention rows staged (scaled, split)", "proj mm", "residual add", "barrier (rows read)", "park + barrier", "row stats (LDS reads, reductions)", "LN + split -> sX + barrier"]
+    woven = ["ffn1.0 mm", "gelu.0 -> sH under ffn1.1 mm", "ffn2.0 mm", "gelu.1 -> sH under ffn1.2 mm", "ffn2.1 mm", "gelu.2 -> sH", "ffn2.2 mm"]
+    apart = ["ffn1.0 mm", "gelu.0 -> sH", "ffn2.0 mm", "ffn1.1 mm", "gelu.1 -> sH", "ffn2.1 mm", "ffn1.2 mm", "gelu.2 -> sH", "ffn2.2 mm"]      # VAPX_F16X3_WOVEN_GELU=0
+    tail = ["resid (+ x_out store)", "row stats + x_out / xn_out rows", "kvx0 mm+store", "kvx1 mm", "kvx1 scale + stores issued"]
+    m1 = head + (apart if NST >= len(head) + len(apart) + len(tail) else woven) + tail
+    NAMES = (m1 + [f"stamp {k}" for k in range(len(m1), NST)])[:NST]
 tick_ns = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
 n = t.shape[0]
 valid = (t[:, :NST] > 0).all(axis=1)

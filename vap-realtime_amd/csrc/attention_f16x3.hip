@@ -57,14 +57,6 @@ __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, float s
 __device__ __forceinline__ float max4abs(float mx, const f32x4& v) {
   return fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
 }
-// p[idx] for a wave-uniform idx through the SCALAR cache.  Inside the persistent item loop hipcc reads the per-stream metadata (bn, ring_rot,
-// ids) with vector loads — global stores precede them, so it cannot prove the words unclobbered — and waits vmcnt(0) for each: three
-// dependent round trips per item that also sit out every store and prefetch in flight.
-__device__ __forceinline__ int uniform_load(const int* p, int idx) {
-  int v;
-  asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p), "s"(idx * 4) : "memory");
-  return v;
-}
 __global__ __launch_bounds__(512, 1) void attention_long_f16x3_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   _Float16* Kh = (_Float16*)lds_raw;          // [256][LDK] K hi

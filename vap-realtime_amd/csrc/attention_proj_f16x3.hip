@@ -51,20 +51,8 @@ __device__ __forceinline__ float max16abs(float mx, const f32x16& v) {
   return mx;
 }
 __device__ __forceinline__ f32x4 quad(const f32x16& a, int q) { return f32x4{a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]}; }
-__device__ __forceinline__ int uniform_load(const int* p, int idx) {   // p[idx] for a wave-uniform idx through the scalar cache (attention_f16x3.hip)
-  int v;
-  asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p), "s"(idx * 4) : "memory");
-  return v;
-}
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// workgroup barrier for LDS hand-offs WITHOUT the vmcnt(0) that __syncthreads' release fence brings: waiting for this wave's outstanding
-// global STORES at a barrier is exactly what the deferred output stores are there to avoid
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
 
 #ifdef AP_TRACE   // timeline build of tools/microbench/attn_proj_bench: s_memtime stamps of wave AP_TRACE_WAVE at the phase boundaries of every item
 __device__ unsigned long long* ap_trace_buf;

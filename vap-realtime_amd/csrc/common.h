@@ -117,6 +117,22 @@ __device__ __forceinline__ float lane_bcast(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
+// p[idx] for a wave-uniform idx through the SCALAR cache.  Inside the persistent item loop hipcc reads the per-stream metadata (bn, ring_rot,
+// ids) with vector loads — global stores precede them, so it cannot prove the words unclobbered — and waits vmcnt(0) for each: three
+// dependent round trips per item that also sit out every store and prefetch in flight.
+__device__ __forceinline__ int uniform_load(const int* p, int idx) {
+  int v;
+  asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p), "s"(idx * 4) : "memory");
+  return v;
+}
+// workgroup barrier for LDS hand-offs WITHOUT the vmcnt(0) that __syncthreads' release fence brings: waiting for this wave's outstanding
+// global STORES at a barrier (and for weight fragments fetched ahead) at every LDS hand-off serialises what the kernels work to overlap
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // 64-lane all-reduce (max; the sum is below, built on the DPP half_sum) without the LDS crossbar: four DPP steps make every 16-lane row
 // uniform (xor 1 / 2 via quad_perm, then row_half_mirror and row_mirror), v_readlane fetches the four rows.  (Round 2 used six
 // __shfl_xor = ds_bpermute round trips; the row statistics of a 64-row tile call this 8 times per wave.)

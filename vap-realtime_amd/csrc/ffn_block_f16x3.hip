@@ -36,6 +36,15 @@
 // immaterial.
 #include "fused_blocks.h"
 
+#include <algorithm>
+#include <cstdlib>
+
+#ifndef VAPX_F16X3_WOVEN_GELU
+#define VAPX_F16X3_WOVEN_GELU 1   // 1: the GELU of hidden chunk c woven into the FFN1 contraction of chunk c + 1; 0: a phase of its own (32 registers less)
+#endif
+#ifndef VAPX_F16X3_PERSIST
+#define VAPX_F16X3_PERSIST 0       // 1: mode 1 without Q|K|V chunks walks its tiles in a persistent loop, the next tile's rows fetched behind the last contraction
+#endif
 #ifndef VAPX_F16X3_RING
 #define VAPX_F16X3_RING 4      // k-chunks of weight fragments in flight per wave (4: 1.5 k cycles of cover, as fast as 8 and 32 registers cheaper)
 #endif
@@ -47,13 +56,16 @@ constexpr int LD16 = 264;                  // halves per LDS row: 256 + 8 pad (5
 constexpr float kWScaleInv = 1.0f / 256.0f;   // weights are packed as 2^8 w
 
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // MODE as FfnArgs::mode (0: xmid from global; 1: attention-output projection + the whole block; 2: projection + LN + wqkvf chunks only)
 // MODE 2 (projection + LayerNorm + cross-query projection: two contractions per tile, no FFN) never touches the X tile: it is launched with
 // ONE (hi, lo) tile of LDS (68 KB) and compiled for 4 waves per SIMD, so that TWO workgroups share a CU and one's staging / statistics / store
 // phases run under the other's contractions (round 4: 22 us per tile with 5 us of MFMA in it when it ran alone on its CU).  Each workgroup
 // still feeds 64 rows per weight fragment, so the pair needs no more of the CU's vector-memory path per MFMA than one workgroup does.
-template <int MODE>
+// TAILQ: the tile ends with the next layer's Q|K|V chunks (short windows; long windows only with VAPX_FLAG_SPLIT_QKV_IN_FFN).  Without them
+// (mode 1 by default since round 5: the attention kernel projects its own Q|K|V) the kernel is PERSISTENT — see the tile loop.
+template <int MODE, bool TAILQ = true>
 __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel(const FfnArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr int BM = 64;
@@ -63,22 +75,31 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
   _Float16* sHl = sHh + BM * LD16;
   float* sHf = (float*)sHh;               // the same bytes as ONE fp32 tile [BM][LD16] (2 x BM x LD16 halves = BM x LD16 floats)
   float* rinv = (float*)(sHl + BM * LD16);   // [BM] 1 / s_row of the rows staged with a power-of-two scale
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..7
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int m0 = blockIdx.x * BM;
+  const int tid = threadIdx.x;
+  int lane = tid & 63;
+  int w = __builtin_amdgcn_readfirstlane(tid >> 6);            // 0..7
+  int l31 = lane & 31, hi = lane >> 5;
+  int m0 = blockIdx.x * BM;             // mode 1 is PERSISTENT: a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, .. (see the loop below)
 #ifdef VAPX_TRACE
   int stamp_k = 0;
   auto STAMP = [&]() {   // phase time stamps of wave 0 (debug build `make trace`: tools/ffn_trace.py --split)
-    if (g.trace && tid == 0 && stamp_k < 28) g.trace[(long)blockIdx.x * 32 + stamp_k] = __builtin_amdgcn_s_memtime();
+    if (g.trace && tid == 0 && stamp_k < 28) g.trace[(long)(m0 / BM) * 32 + stamp_k] = __builtin_amdgcn_s_memtime();
     ++stamp_k;
   };
-  STAMP();
-  if (g.trace && tid == 0) g.trace[(long)blockIdx.x * 32 + 28] = __builtin_amdgcn_s_memrealtime();
+  auto TILE_BEGIN = [&]() {
+    stamp_k = 0;
+    STAMP();
+    if (g.trace && tid == 0) g.trace[(long)(m0 / BM) * 32 + 28] = __builtin_amdgcn_s_memrealtime();
+  };
+  auto TILE_END = [&]() {
+    if (g.trace && tid == 0) { g.trace[(long)(m0 / BM) * 32 + 29] = __builtin_amdgcn_s_memrealtime(); g.trace[(long)(m0 / BM) * 32 + 30] = (unsigned long long)stamp_k; }
+  };
   auto FINE = [&]() { __builtin_amdgcn_sched_barrier(0); STAMP(); __builtin_amdgcn_sched_barrier(0); };   // (tools/ffn_trace.py --split --fine)
 #else
   auto STAMP = [] {};
   auto FINE = [] {};
+  auto TILE_BEGIN = [] {};
+  auto TILE_END = [] {};
 #endif
 
   // weight fragments of this wave's 32 columns: ring of RD k-chunks (hi, lo) ahead, running on into the next unit
@@ -90,6 +111,20 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
 #pragma unroll
     for (int i = 0; i < 2 * RD; ++i) ring[i] = wf[i * 64 + lane];
   };
+  // layer 0 (mode 1): the residual rows live in the per-stream embedding rings.  A 64-row tile of a long window (T >= 64, which is where mode 1
+  // runs) touches at most TWO (stream, channel) slabs, so their slots and rotations are four SCALAR loads (no vmcnt, no per-lane chain)
+  int bc0 = 0, slot0 = 0, slot1 = 0, rot0 = 0, rot1 = 0;
+  auto load_slots = [&]() {
+    if (MODE == 1 && g.resid_rot) {
+      bc0 = m0 / g.resid_T;
+      const int nb = (g.M / g.resid_T) >> 1;                     // streams in the batch
+      const int b0 = bc0 >> 1, b1 = ((bc0 + 1) >> 1) < nb ? (bc0 + 1) >> 1 : b0;
+      slot0 = g.resid_ids ? uniform_load(g.resid_ids, b0) : b0;
+      slot1 = g.resid_ids ? uniform_load(g.resid_ids, b1) : b1;
+      rot0 = uniform_load(g.resid_rot, b0);
+      rot1 = uniform_load(g.resid_rot, b1);
+    }
+  };
   fetch(MODE == 0 ? g.w0f : g.wprojf);   // the first weight fragments fly while the tile is staged
 
   // wave w stages rows w, w + 8, ..: a lane holds 4 columns of a whole row, row statistics are wave reductions
@@ -99,8 +134,8 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
     *(h16x4*)&dh[row * LD16 + lane * 4] = hh;
     *(h16x4*)&dl[row * LD16 + lane * 4] = ll;
   };
-  {
-    f32x4 xr[BM / 8];
+  f32x4 xr[BM / 8];
+  auto load_rows = [&]() {
     const float* src = MODE == 0 ? g.xmid : g.att;
 #pragma unroll
     for (int k = 0; k < BM / 8; ++k) {
@@ -108,6 +143,63 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
       m = m < g.M ? m : g.M - 1;
       xr[k] = *(const f32x4*)(src + (long)m * 256 + lane * 4);
     }
+  };
+  // The residual rows of the output projection (modes 1, 2) are HBM misses — the layer input was written a whole launch ago: their loads go out
+  // HERE, with the tile's own rows, and land while the tile is staged (round 5: issued behind the contraction they cost 2.4 us of latency
+  // plus 3.2 us of barrier skew per tile; issued just ahead of it they would stall its weight ring instead — one in-order vmcnt).
+  // (Mode 2 keeps them behind its contraction: 32 more live registers would cost it the second workgroup per CU, which hides the latency anyway.)
+  f32x4 rs[2][4];
+  auto load_resid = [&]() {
+    const int rcol = w * 32 + 4 * hi;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int lr = rt * 32 + l31;
+      int m = m0 + lr;
+      m = m < g.M ? m : g.M - 1;
+      const float* rp;
+      if (MODE == 1 && g.resid_rot) {   // layer 0: residual rows straight from the embedding ring
+        const int T = g.resid_T;
+        const bool second = m >= (bc0 + 1) * T;                  // (m < (bc0 + 2) T: the tile is no longer than a window)
+        const int bc = bc0 + (second ? 1 : 0), i = m - bc * T;
+        const long slab = (long)(second ? slot1 : slot0) * 2 + (bc & 1);
+        int rr = i + (second ? rot1 : rot0);
+        rr = rr >= T ? rr - T : rr;
+        rp = g.resid + (slab * T + rr) * 256 + rcol;
+      } else {
+        rp = g.resid + (long)m * 256 + rcol;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rs[rt][j] = *(const f32x4*)(rp + 8 * j);
+    }
+  };
+  // every global load of a tile's own rows: issued at kernel entry for the first tile and, in mode 1, behind the LAST contraction of a tile
+  // for the next one — the rows arrive under the closing stores / LayerNorm instead of costing a whole HBM latency with nothing else to run
+  auto issue_tile_loads = [&]() {
+    load_slots();
+    load_rows();
+    if constexpr (MODE == 1) load_resid();
+  };
+  constexpr bool PERSIST = VAPX_F16X3_PERSIST && MODE == 1 && !TAILQ;
+  const int m_step = (int)gridDim.x * BM;
+  // (xr / rs are dead from the staging / the projection's residual add on.)  The tile's own rows go first, right behind the last contraction; the
+  // residual rows — not needed before the NEXT tile's projection has run — follow at the very end of the tile, when the closing phases' row
+  // registers are free (asked for together they push the kernel into scratch spills, and a spill reload waits vmcnt(0): every load and store in flight).
+  auto prefetch_next_tile = [&]() {
+    if (PERSIST && m0 + m_step < g.M) { m0 += m_step; load_slots(); load_rows(); m0 -= m_step; }
+  };
+  auto prefetch_next_resid = [&]() {
+    if (PERSIST && m0 + m_step < g.M) { m0 += m_step; load_resid(); m0 -= m_step; }
+  };
+  const float* wrap = PERSIST ? g.wprojf : nullptr;   // the weight ring runs on into the next tile's first contraction
+  issue_tile_loads();
+#pragma unroll 1
+  for (;;) {
+  // Everything below hangs off these four values.  Re-defining them (no instruction) at the top of every tile keeps the address arithmetic of the
+  // whole tile OUT of the loop pre-header: hoisted there it stays live around the loop and the kernel spills (256 registers + 219 spilled
+  // against 208 for the single-tile form).
+  asm volatile("" : "+v"(lane), "+v"(l31), "+v"(hi), "+s"(w));
+  TILE_BEGIN();
+  {
     if constexpr (MODE == 0) {   // A operand of FFN1 = LayerNorm(xmid; ln_ffn), normalised and split while the tile is staged
       const f32x4 lg = *(const f32x4*)(g.lnf_g + lane * 4), lb = *(const f32x4*)(g.lnf_b + lane * 4);
       float sm[BM / 8];
@@ -134,7 +226,7 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
   STAMP();   // 1: tile staged
 
   // acc[rt] += (A[rows 32 rt ..][256 k] (LDS hi / lo) . W^T for this wave's 32 columns)^T: the WEIGHT fragment is the MFMA's A operand
@@ -183,6 +275,7 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
     }
     __builtin_amdgcn_s_setprio(0);
   };
+#if VAPX_F16X3_WOVEN_GELU
   // the same contraction, fully unrolled, with `side(q)` — a slice of VALU / LDS-store work that does not depend on it: one of the eight
   // 4-value groups of the PREVIOUS hidden chunk's GELU — woven into every pair of k-chunks: behind each of the 12 MFMAs come five VALU
   // instructions, one transcendental and one memory instruction (sched_group_barrier), which is what fits in an MFMA's shadow with two
@@ -218,6 +311,7 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
       }
     }
   };
+#endif
   auto zero = [](f32x16(&acc)[2]) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
@@ -292,52 +386,46 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
     for (int k = 0; k < BM / 8; ++k) var[k] = wave_sum(var[k]) * (1.0f / 256.0f);
   };
 
-  const int nq = g.wqkvf ? g.n_qkv_chunks : 0;
-  const float* after_ffn = g.wkvxf ? g.wkvxf : (nq ? g.wqkvf : nullptr);
+  const int nq = TAILQ ? (g.wqkvf ? g.n_qkv_chunks : 0) : 0;
+  const float* after_ffn = g.wkvxf ? g.wkvxf : (nq ? g.wqkvf : wrap);
+  // When the tile's rows go through the row-per-wave pass at the end (statistics for the next projections / LayerNorm), the block's own
+  // output (x, or mode 2's xmid) leaves FROM THAT PASS: a wave holds whole rows there — 1 KB contiguous per store instruction, and no trip
+  // through the transposition tile (round 5: the separate store phase was 2.2 us of a 62 us tile).
+  const bool rows_follow = g.wkvxf || nq || g.xn_out;
   f32x16 out[2];
   if constexpr (MODE != 0) {
     // ---- attention output projection + residual: xmid = resid + att . Wproj^T (the separate GEMM of the long-window path) ----
     zero(out);
     mm(out, sHh, sHl, g.wprojf, MODE == 1 ? g.w0f : after_ffn);
+    FINE();
+    if constexpr (MODE == 2) load_resid();
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
-      const int lr = rt * 32 + l31;
-      int m = m0 + lr;
-      m = m < g.M ? m : g.M - 1;
-      const float* rp;
-      if (MODE == 1 && g.resid_rot) {   // layer 0: residual rows straight from the embedding ring
-        const int T = g.resid_T;
-        const int bc = m / T, i = m - bc * T, b = bc >> 1;
-        const long slab = (long)(g.resid_ids ? g.resid_ids[b] : b) * 2 + (bc & 1);
-        int rr = i + g.resid_rot[b];
-        rr = rr >= T ? rr - T : rr;
-        rp = g.resid + (slab * T + rr) * 256 + ccol;
-      } else {
-        rp = g.resid + (long)m * 256 + ccol;
-      }
-      const float sc = rinv[lr] * kWScaleInv;     // undo the row scale of the staged attention row and the weights' 2^8
+      const float sc = rinv[rt * 32 + l31] * kWScaleInv;     // undo the row scale of the staged attention row and the weights' 2^8
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f32x4 rs = *(const f32x4*)(rp + 8 * j);
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) out[rt][4 * j + e] = out[rt][4 * j + e] * sc + rs[e];
-      }
+        for (int e = 0; e < 4; ++e) out[rt][4 * j + e] = out[rt][4 * j + e] * sc + rs[rt][j][e];
     }
     // mode 2 hands xmid to the next block through HBM; in mode 1 its only consumer is this workgroup (the residual of the FFN), so it
     // stays in the accumulators the FFN2 products are added to (below) and never travels
-    if constexpr (MODE == 2) store_global(out, g.xmid_out, 256, 0);
+    if constexpr (MODE == 2) { if (!rows_follow) store_global(out, g.xmid_out, 256, 0); }
     STAMP();   // 2: projection + residual
     if constexpr (MODE == 1) {   // A operand of FFN1 = LayerNorm(xmid; ln_ffn): parked in sH (the attention rows are consumed), normalised into sX
-      __syncthreads();           // every wave is done reading the attention rows
+      lds_barrier();           // every wave is done reading the attention rows
+      FINE();
       park(out);
-      __syncthreads();
+      lds_barrier();
+      FINE();
       f32x4 x[BM / 8];
       float mean[BM / 8], var[BM / 8], amax[BM / 8];
       parked_stats(x, mean, var, amax);
+      FINE();
       const f32x4 lg = *(const f32x4*)(g.lnf_g + lane * 4), lb = *(const f32x4*)(g.lnf_b + lane * 4);
 #pragma unroll
       for (int k = 0; k < BM / 8; ++k) split_row(sXh, sXl, w + 8 * k, (x[k] - mean[k]) * rsqrtf(var[k] + 1e-5f) * lg + lb);
-      __syncthreads();
+      lds_barrier();
+      FINE();
     }
   }
   if constexpr (MODE != 2) {
@@ -353,36 +441,45 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[rt][r] *= up;
     }
-    // gelu + f16 split of one 4-value group (q = 4 rt + j) of a hidden chunk's accumulators -> sH.  The operand scale 2^-8, the result
-    // scale hs, the 1 / sqrt 2 of erf's argument and the log2 e of v_exp_f32 are folded into three constants: gelu_fast (common.h, A&S 7.1.26) as
-    //   z' = |a| k1 (z'^2 = log2 e x^2 / 2),  t = 1 / (1 + k2 z'),  e = 1 - poly(t) t 2^(-z'^2),  result = hc + copysign(e, a) hc,  hc = a k3
-    // — 11 plain VALU operations + rcp + exp2 per element instead of 19 + 2 (the same formula, other rounding points).  (Measured: the phase
-    // does not get shorter — it is not bound by the operation count; profiles/r04_experiments.)
-    constexpr double kSqrtLog2e = 1.2011224087864498;
-    const float k1 = (float)(0.70710678118654752440 * kSqrtLog2e) * kWScaleInv;
-    constexpr float k2 = (float)(0.3275911 / kSqrtLog2e);
+    // gelu + f16 split of one 4-value group (q = 4 rt + j) of a hidden chunk's accumulators -> sH.  These VALU instructions are NOT free under
+    // the contraction they are woven into: a SIMD issues them and the MFMAs from the same port (tools/microbench/mfma_valu_overlap: ten
+    // independent v_fma_f32 per 32-clk MFMA stretch it to 46 clk with two waves on the SIMD; the woven phase measures as the SUM of its MFMA
+    // and VALU time), so the cost of a hidden chunk is its instruction count.  Round 5: ONE transcendental per element instead of two —
+    //   gelu(h) = (h + |h| - |h| erfc(|h| / sqrt 2)) / 2,   erfc(z) = 2^(z q(z)),  q = degree-6 minimax fit of log2(erfc(z)) / z on [0, 4.2]
+    // (tools/fit_erfc_exp2.py: max |erf error| 1.8e-7 in float32 arithmetic — A&S 7.1.26, used by the fp32 path, has 1.5e-7; beyond
+    // z = 4.2 erfc < 3e-9 and the clamp holds it there).  With the operand scale 2^-8 and the result scale hs folded into k1 / k3: 13 plain
+    // operations + exp2 per element instead of 18 + rcp + exp2 (written on pairs; hipcc un-packs most v_pk_fma_f32 next to MFMAs on purpose).
+    const float k1 = 0.70710678118654752440f * kWScaleInv;
     const float k3 = 0.5f * kWScaleInv * hs;
+    const f32x2 C6 = f32x2{1.0022112e-4f, 1.0022112e-4f}, C5 = f32x2{-4.6157415e-4f, -4.6157415e-4f}, C4 = f32x2{-2.3022329e-3f, -2.3022329e-3f},
+                C3 = f32x2{2.9452506e-2f, 2.9452506e-2f}, C2 = f32x2{-1.4896366e-1f, -1.4896366e-1f}, C1 = f32x2{-9.1832864e-1f, -9.1832864e-1f},
+                C0 = f32x2{-1.6279137f, -1.6279137f}, ZMAX = f32x2{4.2f, 4.2f};
     auto gelu_group = [&](const f32x16(&h)[2], int q) {
       const int rt = q >> 2, j = q & 3;
       f32x4 y;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float a = h[rt][4 * j + e];
-        const float z = fabsf(a) * k1;
-        const float t = __builtin_amdgcn_rcpf(fmaf(k2, z, 1.0f));
-        float pl = fmaf(1.061405429f, t, -1.453152027f);
-        pl = fmaf(pl, t, 1.421413741f);
-        pl = fmaf(pl, t, -0.284496736f);
-        pl = fmaf(pl, t, 0.254829592f);
-        const float er = fmaf(-(pl * t), __builtin_amdgcn_exp2f(-z * z), 1.0f);     // erf(|x| / sqrt 2)
-        const float hc = a * k3;
-        y[e] = fmaf(copysignf(er, a), hc, hc);
+      for (int e2 = 0; e2 < 2; ++e2) {   // two elements per instruction wherever a packed form exists (v_pk_mul / v_pk_fma / v_pk_add)
+        const f32x2 a = f32x2{h[rt][4 * j + 2 * e2], h[rt][4 * j + 2 * e2 + 1]};
+        const f32x2 aa = f32x2{fabsf(a[0]), fabsf(a[1])};
+        f32x2 z = aa * k1;
+        z = __builtin_elementwise_min(z, ZMAX);
+        f32x2 pl = __builtin_elementwise_fma(C6, z, C5);
+        pl = __builtin_elementwise_fma(pl, z, C4);
+        pl = __builtin_elementwise_fma(pl, z, C3);
+        pl = __builtin_elementwise_fma(pl, z, C2);
+        pl = __builtin_elementwise_fma(pl, z, C1);
+        pl = __builtin_elementwise_fma(pl, z, C0);
+        pl = pl * z;
+        const f32x2 ec = f32x2{__builtin_amdgcn_exp2f(pl[0]), __builtin_amdgcn_exp2f(pl[1])};   // erfc(|h| / sqrt 2), arguments <= 0
+        const f32x2 r = __builtin_elementwise_fma(-aa, ec, a + aa) * k3;
+        y[2 * e2] = r[0]; y[2 * e2 + 1] = r[1];
       }
       const h16x4 hh = __builtin_convertvector(y, h16x4);
       const h16x4 ll = __builtin_convertvector(y - __builtin_convertvector(hh, f32x4), h16x4);
       *(h16x4*)&sHh[(rt * 32 + l31) * LD16 + ccol + 8 * j] = hh;
       *(h16x4*)&sHl[(rt * 32 + l31) * LD16 + ccol + 8 * j] = ll;
     };
+#if VAPX_F16X3_WOVEN_GELU
     // weight order: W0.0, W0.1, W3.0, W0.2, W3.1, W3.2 — the GELU of chunk c rides in the FFN1 contraction of chunk c + 1 (mm_side)
     f32x16 hacc[2][2];
     zero(hacc[0]);
@@ -390,7 +487,7 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
     STAMP();   // FFN1 chunk 0
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      if (c > 0) __syncthreads();   // every wave is done reading the previous chunk from sH
+      if (c > 0) lds_barrier();   // every wave is done reading the previous chunk from sH
       if (c < 2) {
         zero(hacc[(c + 1) & 1]);
         mm_side(hacc[(c + 1) & 1], sXh, sXl, g.w0f + (long)(c + 1) * 65536, g.w3f + (long)c * 65536, [&](int q) { gelu_group(hacc[c & 1], q); });
@@ -398,9 +495,37 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
 #pragma unroll
         for (int q = 0; q < 8; ++q) gelu_group(hacc[c & 1], q);
       }
-      __syncthreads();
+      lds_barrier();
       STAMP();   // gelu(c) -> sH  (+ FFN1 chunk c + 1)
       mm(out, sHh, sHl, g.w3f + (long)c * 65536, c == 0 ? g.w0f + 2 * 65536 : (c == 1 ? g.w3f + 2 * 65536 : after_ffn));
+#else
+    // weight order W0.0, W3.0, W0.1, W3.1, W0.2, W3.2; the GELU of a chunk is a phase of its own between its two contractions.  (Rounds 3-4 wove
+    // the GELU of chunk c into the FFN1 contraction of chunk c + 1.  With the round-5 GELU the woven pair measures 6.7 us
+    // against 2.6 + 3.4 apart: the SIMD issues MFMA and VALU from one port, so the weave only ever bought the barrier skew, and apart the
+    // second set of hidden accumulators — 32 registers — is gone.)
+    f32x16 hacc[1][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      zero(hacc[0]);
+      mm(hacc[0], sXh, sXl, g.w0f + (long)c * 65536, g.w3f + (long)c * 65536);
+      STAMP();   // FFN1 chunk c
+      if (c > 0) lds_barrier();   // every wave is done reading the previous chunk from sH
+#pragma unroll
+      for (int q = 0; q < 8; ++q) gelu_group(hacc[0], q);
+      lds_barrier();
+      STAMP();   // gelu(c) -> sH
+      mm(out, sHh, sHl, g.w3f + (long)c * 65536, c < 2 ? g.w0f + (long)(c + 1) * 65536 : after_ffn);
+#endif
+      if (PERSIST && c == 2) {
+        // The next tile's rows are loaded at ONE of three places further down (whichever contraction is the tile's last).  To the compiler a
+        // conditional definition keeps the PREVIOUS tile's xr / rs alive around the whole loop — 64 registers through the GELU phases.  These
+        // empty definitions end that live range here, where there is room.
+#pragma unroll
+        for (int k = 0; k < BM / 8; ++k) asm volatile("" : "=v"(xr[k]));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) asm volatile("" : "=v"(rs[k >> 2][k & 3]));
+      }
+      if (c == 2 && !g.wkvxf && !nq) prefetch_next_tile();   // that was the tile's last contraction
       STAMP();   // FFN2 chunk c
     }
     {
@@ -426,19 +551,38 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
           for (int r = 0; r < 16; ++r) out[rt][r] *= inv;
       }
     }
-    store_global(out, g.xout, 256, 0);
-    STAMP();   // residual + x_out store
+    if (!rows_follow) store_global(out, g.xout, 256, 0);
+    STAMP();   // residual (+ x_out store)
   }
   // ---- next layer's projections: cross K,V from the RAW layer output, self Q,K,V from LayerNorm(x) ----
-  if (g.wkvxf || nq || g.xn_out) {
-    __syncthreads();            // every wave is done reading sH in the previous contraction
+  if (rows_follow) {
+    lds_barrier();            // every wave is done reading sH in the previous contraction
     park(out);
-    __syncthreads();
+    lds_barrier();
     f32x4 x[BM / 8];
     float mean[BM / 8], var[BM / 8], amax[BM / 8];
     parked_stats(x, mean, var, amax);
+    if (rows_follow) {
+      float* dst = (MODE == 2 ? g.xmid_out : g.xout) + (long)m0 * 256 + lane * 4;
+#pragma unroll
+      for (int k = 0; k < BM / 8; ++k)
+        if (m0 + w + 8 * k < g.M) *(f32x4*)(dst + (w + 8 * k) * 256) = x[k];
+    }
+    auto ln_rows = [&]() {     // LayerNorm(x; next layer's ln_self) of the wave's rows: to xn_out, and to sH when the Q|K|V chunks follow
+      const f32x4 lg = *(const f32x4*)(g.ln_g + lane * 4), lb = *(const f32x4*)(g.ln_b + lane * 4);
+#pragma unroll
+      for (int k = 0; k < BM / 8; ++k) {
+        const f32x4 y = (x[k] - mean[k]) * rsqrtf(var[k] + 1e-5f) * lg + lb;
+        if (nq) split_row(sHh, sHl, w + 8 * k, y);   // (A operand of the Q|K|V chunks; without them only xn_out wants the rows)
+        const int m = m0 + w + 8 * k;
+        if (g.xn_out && m < g.M) *(f32x4*)(g.xn_out + (long)m * 256 + lane * 4) = y;
+      }
+    };
+    // Without Q|K|V chunks nothing needs the normalised rows in LDS: they leave for xn_out NOW, and the row registers (x, mean, var: 48) are free
+    // through the cross K|V contractions — which is what lets the next tile's rows be fetched behind the last of them.
+    if constexpr (!TAILQ) ln_rows();
     STAMP();   // row statistics
-    __syncthreads();            // the (hi, lo) rows written next alias OTHER waves' fp32 rows: every row is in registers first
+    lds_barrier();            // the (hi, lo) rows written next alias OTHER waves' fp32 rows: every row is in registers first
     if (MODE != 2 && g.wkvxf) {
       // raw rows, each scaled by a power of two so that the f16 operand stays below 2^14 (exact row maximum: the wave holds the row)
 #pragma unroll
@@ -447,11 +591,12 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
         if (lane == 0) rinv[w + 8 * k] = __builtin_amdgcn_rcpf(s);
         split_row(sHh, sHl, w + 8 * k, x[k] * s);
       }
-      __syncthreads();
+      lds_barrier();
       for (int nc = 0; nc < 2; ++nc) {
         f32x16 acc[2];
         zero(acc);
-        mm(acc, sHh, sHl, g.wkvxf + (long)nc * 65536, nc == 0 ? g.wkvxf + 65536 : (nq ? g.wqkvf : nullptr));
+        mm(acc, sHh, sHl, g.wkvxf + (long)nc * 65536, nc == 0 ? g.wkvxf + 65536 : (nq ? g.wqkvf : wrap));
+        if (nc == 1 && !nq) prefetch_next_tile();
         if (nc == 1) FINE();    // kvx1 mm done (stores follow)
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
@@ -462,23 +607,17 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
         store_global(acc, g.kvx, 512, nc * 256);
         STAMP();   // kvx mm + store
       }
-      __syncthreads();          // every wave is done reading the raw rows: the tile becomes the LayerNorm rows
+      lds_barrier();          // every wave is done reading the raw rows: the tile becomes the LayerNorm rows
     }
-    {
-      const f32x4 lg = *(const f32x4*)(g.ln_g + lane * 4), lb = *(const f32x4*)(g.ln_b + lane * 4);
-#pragma unroll
-      for (int k = 0; k < BM / 8; ++k) {
-        const f32x4 y = (x[k] - mean[k]) * rsqrtf(var[k] + 1e-5f) * lg + lb;
-        split_row(sHh, sHl, w + 8 * k, y);
-        const int m = m0 + w + 8 * k;
-        if (g.xn_out && m < g.M) *(f32x4*)(g.xn_out + (long)m * 256 + lane * 4) = y;
-      }
+    if constexpr (TAILQ) {
+      ln_rows();
+      lds_barrier();
     }
-    __syncthreads();
     for (int nc = 0; nc < nq; ++nc) {
       f32x16 acc[2];
       zero(acc);
-      mm(acc, sHh, sHl, g.wqkvf + (long)nc * 65536, nc + 1 < nq ? g.wqkvf + (long)(nc + 1) * 65536 : nullptr);
+      mm(acc, sHh, sHl, g.wqkvf + (long)nc * 65536, nc + 1 < nq ? g.wqkvf + (long)(nc + 1) * 65536 : wrap);
+      if (nc + 1 == nq) prefetch_next_tile();
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -487,9 +626,12 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
       STAMP();   // q / k / v mm + store
     }
   }
-#ifdef VAPX_TRACE
-  if (g.trace && tid == 0) { g.trace[(long)blockIdx.x * 32 + 29] = __builtin_amdgcn_s_memrealtime(); g.trace[(long)blockIdx.x * 32 + 30] = (unsigned long long)stamp_k; }
-#endif
+  prefetch_next_resid();
+  TILE_END();
+  if (!PERSIST || m0 + m_step >= g.M) break;
+  m0 += m_step;
+  lds_barrier();   // every wave is done with this tile's LDS (the staging of the next tile overwrites sH / rinv)
+  }
 }
 
 }  // namespace
@@ -499,14 +641,24 @@ hipError_t launch_ffn_block_f16x3(const FfnArgs& a, hipStream_t st) {
   static PerDeviceOnce attr_set;
   attr_set.run([] {
     (void)hipFuncSetAttribute((const void*)ffn_block_f16x3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)ffn_block_f16x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_block_f16x3_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_block_f16x3_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ffn_block_f16x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   const size_t lds = (size_t)(a.mode == 2 ? 2 : 4) * 64 * LD16 * sizeof(_Float16) + 64 * sizeof(float);   // mode 2: one (hi, lo) tile, two workgroups per CU
   const dim3 grid((a.M + 63) / 64), block(512);
   if (a.mode == 1 || a.mode == 2) {
     if (!a.att || !a.wprojf || !a.resid || !a.xmid_out) return hipErrorInvalidValue;
-    if (a.mode == 1) hipLaunchKernelGGL(ffn_block_f16x3_kernel<1>, grid, block, lds, st, a);
+    if (a.mode == 1 && a.resid_rot && a.resid_T < 64) return hipErrorInvalidValue;   // a tile spans at most two windows (see the kernel's scalar slot / rotation loads)
+    if (a.mode == 1) {   // persistent: one workgroup per CU (136 KB of LDS each) walks the tiles with a stride of the grid
+      static const int persist_env = [] { const char* e = getenv("VAPX_FFN_PERSIST"); return e ? atoi(e) : 1; }();   // 0: one tile per workgroup (A/B runs)
+      int dev = 0, cus = 256;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      const dim3 pgrid(VAPX_F16X3_PERSIST && persist_env ? std::min<unsigned>(grid.x, (unsigned)cus) : grid.x);
+      if (a.wqkvf && a.n_qkv_chunks > 0) hipLaunchKernelGGL((ffn_block_f16x3_kernel<1, true>), grid, block, lds, st, a);   // one tile per workgroup
+      else hipLaunchKernelGGL((ffn_block_f16x3_kernel<1, false>), pgrid, block, lds, st, a);
+    }
     else hipLaunchKernelGGL(ffn_block_f16x3_kernel<2>, grid, block, lds, st, a);
   } else {
     hipLaunchKernelGGL(ffn_block_f16x3_kernel<0>, grid, block, lds, st, a);
