@@ -37,19 +37,23 @@ static inline RowMap contiguous_rows(long ld) {
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-// Branch-free GELU for the FFN hot loop (98 k evaluations per stream-frame): erf by Abramowitz-Stegun
-// 7.1.26 (|error| <= 1.5e-7, i.e. fp32-rounding level; multiplied by x it is a 1.5e-7 RELATIVE error
-// of gelu for small x) with v_rcp / v_exp instead of libm's two-branch erff (~4x fewer instructions,
-// no divergence).  gelu(x) = 0.5 x (1 + erf(x / sqrt 2)).
+// Branch-free GELU for the FFN hot loop (98 k evaluations per stream-frame), ONE transcendental per value (round 5; rounds 1-4 used
+// Abramowitz-Stegun 7.1.26: a reciprocal AND an exponential, |error| <= 1.5e-7):
+//   gelu(x) = (x + |x| - |x| erfc(|x| / sqrt 2)) / 2,   erfc(z) = 2^(z q(z)),  q = degree-6 minimax fit of log2(erfc(z)) / z on [0, 4.2]
+// (tools/fit_erfc_exp2.py: max |erf error| 1.8e-7 in float32 arithmetic, fp32-rounding level; beyond z = 4.2 erfc < 3e-9 and the clamp
+// holds it there).  12 plain VALU operations + v_exp_f32 instead of 13 + v_rcp_f32 + v_exp_f32, no libm branches.  A NaN stays a NaN
+// (v_min drops it from z, the final fma puts it back).
 __device__ __forceinline__ float gelu_fast(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = 1.0f - p * t * __expf(-z * z);     // erf(|x| / sqrt 2)
-  return 0.5f * x * (1.0f + copysignf(e, x));
+  const float ax = fabsf(x);
+  const float z = fminf(ax * 0.70710678118654752440f, 4.2f);
+  float q = fmaf(1.0022112e-4f, z, -4.6157415e-4f);
+  q = fmaf(q, z, -2.3022329e-3f);
+  q = fmaf(q, z, 2.9452506e-2f);
+  q = fmaf(q, z, -1.4896366e-1f);
+  q = fmaf(q, z, -9.1832864e-1f);
+  q = fmaf(q, z, -1.6279137f);
+  const float ec = __builtin_amdgcn_exp2f(q * z);     // erfc(|x| / sqrt 2)
+  return 0.5f * fmaf(-ax, ec, x + ax);
 }
 // ReLU as torch.relu computes it (encoder_components.py:103): a NaN stays a NaN (fmaxf(NaN, 0) would return 0 and hide a poisoned
 // sample that the reference carries into the LSTM state for good; tests/golden/poison20.npz pins that behaviour).
