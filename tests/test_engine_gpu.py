@@ -535,6 +535,35 @@ def test_long_window_fused_projections_equal_the_gemm_chain():
     fused.close(); plain.close()
 
 
+@pytest.mark.parametrize("T", [32, 33, 36, 37, 44, 49, 52, 53, 64])
+def test_short_windows_around_the_small_tile_projection(T):
+    """The fused attention block runs its projections on 32 + 5 x 4 rows for windows of 33..52 frames (csrc/fused_blocks.hip, round 5) and on two
+    32-row tiles otherwise: every boundary (32 | 33, 52 | 53), a window that fills a 4-row group exactly (36, 44, 52) and one that leaves one
+    to three rows of a group empty (33, 37, 49), plus the 64-row limit of the fused path — window filling, full and sliding, against the oracle."""
+    from oracle.vap_oracle import ServerFramer, VapOracle
+    from vap_realtime_amd import engine, synth, weights as W
+    hz = 20
+    ctx = T / hz
+    cpc, vap = W.synthetic_weights(17, hz, "vap")
+    o = VapOracle(cpc, vap, hz, ctx)
+    hop = 16000 // hz
+    S, F_ = 3, T + 4
+    audio = synth.dialogue_batch([80, 81, 82], hop * F_)
+    st, fr = o.new_state(S), ServerFramer(S, hop)
+    eng = engine.Engine(W.pack_blob(cpc, vap), hz, ctx, max_streams=S)
+    assert eng.T == T
+    worst = 0.0
+    for f in range(F_):
+        new = audio[:, :, f * hop:(f + 1) * hop]
+        want = o.step(fr.frame(new), st)
+        got = engine.split_outputs(eng.step(new))
+        for k in ("p_now", "p_future", "vad", "logits"):
+            worst = max(worst, float(np.abs(got[k] - want[k]).max()))
+    print(f"T={T}: worst |hip - oracle| = {worst:.2e}")
+    assert worst <= TOL
+    eng.close()
+
+
 @pytest.mark.parametrize("split", [False, True], ids=["fp32", "split_f16"])
 @pytest.mark.parametrize("hz,ctx", [(20, 5.0), (20, 7.5), (10, 10.0)])
 def test_mid_length_windows_against_the_oracle(hz, ctx, split):

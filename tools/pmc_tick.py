@@ -13,7 +13,9 @@ PATH = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
 def kernel_class(name: str) -> str:
-    if name.startswith("ffn_block"):
+    if name.startswith("ffn_block_f16x3_kernel<"):      # <MODE, TAILQ> (round 5; <MODE> before)
+        return "ffn_proj" if name[len("ffn_block_f16x3_kernel<")] == "2" else "ffn_block"
+    if name.startswith("ffn_block"):                    # ffn_block_kernel<.., MODE>
         return "ffn_proj" if (name.endswith("2>(FfnArgs)")) else "ffn_block"
     if name.startswith(("attn_block", "attention_long", "attention_proj")):
         return "attention"
