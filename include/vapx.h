@@ -110,10 +110,11 @@ typedef struct vapx_config {
   int32_t struct_size;  /* sizeof(vapx_config), for ABI evolution */
   int32_t device_id;    /* HIP device ordinal */
   int32_t frame_hz;     /* 5, 10, 20 or 50: VAPRealTime frame_rate   vap_main.py:192,219 */
-  int32_t ctx_frames;   /* T = int(context_len_sec*frame_rate)        vap_main.py:221.  1 <= T <= 256 (vapx_create returns VAPX_E_INVAL beyond):
-                         * every published checkpoint fits (largest: 20 Hz x 10 s = 200 rows, README.md; BASELINE configs[2]: 50 Hz x 5 s = 250);
-                         * the reference's ALiBi transformer itself takes any T (modules.py:303-308) — longer windows need more key tiles than
-                         * the long-window attention kernels hold on chip and are not built */
+  int32_t ctx_frames;   /* T = int(context_len_sec*frame_rate)        vap_main.py:221.  1 <= T <= 512 (vapx_create returns VAPX_E_INVAL beyond).
+                         * Every published checkpoint fits in 256 (largest: 20 Hz x 10 s = 200 rows, README.md; BASELINE configs[2]: 50 Hz x 5 s = 250)
+                         * and that is what the long-window attention kernels are tuned for; the reference's ALiBi transformer itself takes any T
+                         * (modules.py:303-308), so windows of 257 .. 512 rows run too — through a plain fp32 attention kernel (K / V from L2, no
+                         * on-chip tile; on the split-precision path as well) that is correct, tested against the oracle, and not tuned */
   int32_t max_streams;  /* stream slots whose state lives in HBM */
   int32_t max_batch;    /* max streams per vapx_step call (sizes scratch) */
   int32_t mode;         /* VAPX_MODE_* */

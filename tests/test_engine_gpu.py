@@ -593,6 +593,58 @@ def test_mid_length_windows_against_the_oracle(hz, ctx, split):
     eng.close()
 
 
+@pytest.mark.parametrize("hz,ctx,split", [(50, 6.0, False), (50, 6.0, True), (50, 10.24, False)], ids=["T300_fp32", "T300_split", "T512_fp32"])
+def test_windows_beyond_256_frames_against_the_oracle(hz, ctx, split):
+    """The reference's ALiBi transformer takes any T (modules.py:303-308); windows of 257 .. 512 frames run through attention_xl_kernel
+    (csrc/vap_kernels.hip: K / V from L2, online softmax over up to 16 key tiles) on both precision paths: T = 300 (a partly used tenth key
+    tile) and the limit T = 512, window filling, full and sliding."""
+    from oracle.vap_oracle import ServerFramer, VapOracle
+    from vap_realtime_amd import engine, synth, weights as W
+    cpc, vap = W.synthetic_weights(19, hz, "vap")
+    o = VapOracle(cpc, vap, hz, ctx)
+    T, hop = int(ctx * hz), 16000 // hz
+    S, F_ = 2, T + 3
+    audio = synth.dialogue_batch([90, 91], hop * F_)
+    st, fr = o.new_state(S), ServerFramer(S, hop)
+    eng = engine.Engine(W.pack_blob(cpc, vap), hz, ctx, max_streams=S, split_f16=split)
+    assert eng.T == T and T > 256
+    worst = 0.0
+    check = set(range(0, F_, 37)) | set(range(T - 3, F_))        # the oracle recomputes the whole window per frame: compare a sample of the fill, then full + sliding
+    for f in range(F_):
+        new = audio[:, :, f * hop:(f + 1) * hop]
+        want = o.step(fr.frame(new), st)
+        got = engine.split_outputs(eng.step(new))
+        if f in check:
+            for k in ("p_now", "p_future", "vad", "logits"):
+                worst = max(worst, float(np.abs(got[k] - want[k]).max()))
+    print(f"T={T} @ {hz} Hz: worst |hip - oracle| = {worst:.2e}")
+    assert worst <= TOL
+    eng.close()
+
+
+def test_xl_attention_kernel_equals_the_long_window_kernel(monkeypatch):
+    """attention_xl_kernel on a window the tuned kernel also takes (T = 250): the same outputs to rounding (the key tiles are visited in the
+    same order with the same arithmetic; only where K / V come from differs)."""
+    from vap_realtime_amd import engine, synth, weights as W
+    hz, ctx = 50, 5.0
+    cpc, vap = W.synthetic_weights(23, hz, "vap")
+    blob = W.pack_blob(cpc, vap)
+    T, hop = int(ctx * hz), 16000 // hz
+    S, F_ = 3, T + 2
+    audio = synth.dialogue_batch([5, 6, 7], hop * F_)
+    outs = []
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv("VAPX_FORCE_ATTENTION_XL", "1")
+        eng = engine.Engine(blob, hz, ctx, max_streams=S)
+        got = [eng.step(audio[:, :, f * hop:(f + 1) * hop]).copy() for f in range(F_)]
+        outs.append(np.stack(got))
+        eng.close()
+    worst = float(np.abs(outs[0][:, :, :272] - outs[1][:, :, :272]).max())
+    print("attention_xl vs attention_long2: worst |diff| =", worst)
+    assert worst <= 2e-5
+
+
 @pytest.mark.parametrize("mode,hz,ctx", [("nod", 10, 10.0), ("bc", 20, 5.0)])
 def test_published_bc_and_nod_settings_against_the_oracle(mode, hz, ctx):
     """The reference's README settings for the fine-tuned heads — vap_bc_main at 20 Hz / 5 s and vap_nod_main at 10 Hz / 10 s,

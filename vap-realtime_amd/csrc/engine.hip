@@ -359,7 +359,8 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
   const int l_full_end = prune_last ? 3 : l_end;
   // split path, long windows: the self-attention of a layer whose LN_self rows were written by the previous layer's flat-row block projects
   // its own Q|K|V (attention_proj_f16x3_kernel); that block then skips the three contractions and never writes sc.qkv
-  const bool qkv_in_attn = (h->cfg.flags & VAPX_FLAG_SPLIT_F16) && !(h->cfg.flags & (VAPX_FLAG_SPLIT_QKV_IN_FFN | VAPX_FLAG_UNFUSED_PROJ)) && T > 64;
+  // (windows of 257 .. 512 frames: attention_xl_kernel — fp32, Q|K|V from the flat-row blocks — on both paths)
+  const bool qkv_in_attn = (h->cfg.flags & VAPX_FLAG_SPLIT_F16) && !(h->cfg.flags & (VAPX_FLAG_SPLIT_QKV_IN_FFN | VAPX_FLAG_UNFUSED_PROJ)) && T > 64 && T <= 256;
   bool xn_ready = false;                   // sc.xn holds LN_self(layer l)(x) of every row, sc.qkv does NOT hold this layer's Q|K|V
   for (int l = l_begin; l < l_full_end; ++l) {
     const Layer& Lw = h->layer[l];
@@ -422,7 +423,7 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
         HIPCHK(h, launch_attention_proj_f16x3(ap, B, st));
       } else {
         ProfScope ps(h, CLS_ATTN, st);
-        HIPCHK(h, split ? launch_attention_f16x3(aa, B, st) : launch_attention(aa, B, st));
+        HIPCHK(h, split && T <= 256 ? launch_attention_f16x3(aa, B, st) : launch_attention(aa, B, st));
       }
       pre_att = sc.att; pre_w = split ? Lw.wproj8 : Lw.wprojf; pre_resid = ring0 ? rv->ring : xin;
       pre_ring = ring0;
@@ -434,13 +435,13 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
         fp.ln_g = Lw.ln_src_g; fp.ln_b = Lw.ln_src_b; fp.wqkvf = split ? Lw.wqx8 : Lw.wqxf; fp.n_qkv_chunks = 1; fp.qkv = sc.qx;
         { ProfScope ps(h, CLS_FFN_PROJ, st); HIPCHK(h, split ? launch_ffn_block_f16x3(fp, st) : launch_ffn_block(fp, st)); }
         AttnArgs ax{sc.qx, sc.kvx, sc.kvx + 256, sc.att, sc.bn, T, 256, 512, 1};
-        { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, split ? launch_attention_f16x3(ax, B, st) : launch_attention(ax, B, st)); }
+        { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, split && T <= 256 ? launch_attention_f16x3(ax, B, st) : launch_attention(ax, B, st)); }
         pre_w = split ? Lw.wprojx8 : Lw.wprojxf; pre_resid = sc.xmid;
       }
     } else {
     // self attention
       AttnArgs aa{sc.qkv, sc.qkv + 256, sc.qkv + 512, sc.att, sc.bn, T, 768, 768, 0};
-      { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, split ? launch_attention_f16x3(aa, B, st) : launch_attention(aa, B, st)); }
+      { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, split && T <= 256 ? launch_attention_f16x3(aa, B, st) : launch_attention(aa, B, st)); }
       g = gemm_args(sc.att, r256, Lw.wproj, M, 256, 256, sc.xmid, r256);
       g.resid = xin; g.C2 = sc.xn;
       if (l == 0) { g.gamma = Lw.ln_ffn_g; g.beta = Lw.ln_ffn_b; }
@@ -451,7 +452,7 @@ int run_layers(vapx_engine* h, const Scratch& sc, int B, hipStream_t st, int l_b
         g = gemm_args(sc.xn, r256, Lw.wq_x, M, 256, 256, sc.qx, r256);
         HIPCHK(h, gemm(h, g, EPI_STORE, st));
         AttnArgs ax{sc.qx, sc.kvx, sc.kvx + 256, sc.att, sc.bn, T, 256, 512, 1};
-        { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, split ? launch_attention_f16x3(ax, B, st) : launch_attention(ax, B, st)); }
+        { ProfScope ps(h, CLS_ATTN, st); HIPCHK(h, split && T <= 256 ? launch_attention_f16x3(ax, B, st) : launch_attention(ax, B, st)); }
         g = gemm_args(sc.att, r256, Lw.wproj_x, M, 256, 256, sc.xmid, r256);
         g.resid = sc.xmid; g.C2 = sc.xn; g.gamma = Lw.ln_ffn_g; g.beta = Lw.ln_ffn_b;
         HIPCHK(h, gemm(h, g, EPI_RESID_LN, st, /*bounded_A=*/false));
@@ -837,7 +838,7 @@ int vapx_create(const vapx_config* cfg, const float* blob, size_t n_floats, vapx
   if (!cfg || !blob || !out) return fail(nullptr, VAPX_E_INVAL, "null argument");
   if (cfg->struct_size != (int32_t)sizeof(vapx_config)) return fail(nullptr, VAPX_E_INVAL, "vapx_config.struct_size mismatch");
   if (!rate_ok(cfg->frame_hz)) return fail(nullptr, VAPX_E_INVAL, "frame_hz must be 5, 10, 20 or 50");
-  if (cfg->ctx_frames < 1 || cfg->ctx_frames > 256) return fail(nullptr, VAPX_E_INVAL, "ctx_frames must be in [1,256]");
+  if (cfg->ctx_frames < 1 || cfg->ctx_frames > 512) return fail(nullptr, VAPX_E_INVAL, "ctx_frames must be in [1,512]");
   if (cfg->max_streams < 1 || cfg->max_batch < 1 || cfg->max_batch > cfg->max_streams)
     return fail(nullptr, VAPX_E_INVAL, "need 1 <= max_batch <= max_streams");
   if (cfg->mode < 0 || cfg->mode > 2) return fail(nullptr, VAPX_E_INVAL, "bad mode");

@@ -640,6 +640,123 @@ __global__ __launch_bounds__(256, 2) void attention_long2_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// 4a'. windows of 257 .. 512 frames (round 5).  The reference's ALiBi transformer takes any T (modules.py:303-308: the mask is rebuilt
+//      for the sequence at hand); no published checkpoint goes beyond 10 s x 20 Hz = 200 frames, so this kernel is the plain form of the
+//      one above, built to be right rather than tuned: one workgroup per (stream, channel, head), four waves, wave w takes the query
+//      tiles w, w + 4, w + 8, w + 12; K fragments AND the V rows come straight from global / L2 (512 keys x 64 features would be 128 KB
+//      of LDS), the softmax is online per 32-key tile exactly as above.  Same operand layouts, same masking, same arithmetic order per
+//      tile — a window of <= 256 frames run through this kernel gives attention_long2_kernel's results (tests/test_engine_gpu.py).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attention_xl_kernel(AttnArgs a) {
+  const int T = a.T;
+  const int n_tiles = (T + 31) >> 5;                 // <= 16
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = (int)(blockIdx.x & 3), bc = (int)(blockIdx.x >> 2), b = bc >> 1;
+  const int n = a.bn[b];
+  const int kvbc = a.swap_kv ? (bc ^ 1) : bc;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const bool ringed = a.ring_rot != nullptr;
+  const int rot = ringed ? a.ring_rot[b] : 0;
+  const long slab_q = ringed ? ((long)(a.ids ? a.ids[b] : b) * 2 + (bc & 1)) : (long)bc;
+  const long slab_kv = ringed ? slab_q : (long)kvbc;
+  auto prow = [&](int i) { int r = i + rot; return r >= T ? r - T : r; };
+  const float* kp = a.k + slab_kv * T * a.ldkv + h * 64;
+  const float* vp = a.v + slab_kv * T * a.ldkv + h * 64;
+  const int nt_valid = (n + 31) >> 5;
+  const float slope = exp2f(-2.0f * (float)(h + 1));  // [1/4, 1/16, 1/64, 1/256]
+  const float hi4f = (float)(4 * hi);
+  for (int it = w; it < n_tiles; it += 4) {
+    const int i = it * 32 + l31;
+    float* op = a.out + ((long)bc * T + i) * 256 + h * 64;
+    if (it >= nt_valid) {                             // whole tile beyond the valid rows: deterministic zeros
+      if (i < T)
+#pragma unroll
+        for (int d = 0; d < 8; ++d) *(f32x4*)(op + hi * 32 + d * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      continue;
+    }
+    f32x4 qf[8];
+    {
+      const int ic = i < n ? i : n - 1;
+      const float* qp = a.q + (slab_q * T + prow(ic)) * a.ldq + h * 64 + hi * 4;
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc) qf[kc] = *(const f32x4*)(qp + kc * 8);
+    }
+    float m = -1e30f, l = 0.f;
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+#pragma unroll 1
+    for (int jt = 0; jt <= it; ++jt) {
+      f32x4 kf[8];
+      {
+        int j = jt * 32 + l31;
+        j = j < n ? j : n - 1;                         // rows beyond the window: clamped, masked below
+        const float* kr = kp + (long)prow(j) * a.ldkv + hi * 4;
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) kf[kc] = *(const f32x4*)(kr + kc * 8);
+      }
+      float v0[16], v1[16];                            // V^T operands of the 16 MFMA steps: key 32 jt + C_r + 4 hi, features l31 and l31 + 32
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        j = j < n ? j : n - 1;                         // (its P is exactly 0)
+        const float* va = vp + (long)prow(j) * a.ldkv + l31;
+        v0[r] = va[0]; v1[r] = va[32];
+      }
+      f32x16 sc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[kc][s], qf[kc][s], sc, 0, 0, 0);
+      float cm = -1e30f;
+      const float jb = (float)(jt * 32) + hi4f;
+      const int i4 = i - jt * 32 - 4 * hi, n4 = n - jt * 32 - 4 * hi;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = (r & 3) + 8 * (r >> 2);
+        float v = fmaf(sc[r], 0.0625f, slope * ((float)c + jb));
+        v = ((c <= i4) && (c < n4)) ? v : -1e30f;
+        sc[r] = v;
+        cm = fmaxf(cm, v);
+      }
+      cm = fmaxf(cm, __shfl_xor(cm, 32));
+      const float mn = fmaxf(m, cm);
+      const float alpha = __expf(m - mn);
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pr = sc[r] > -1e29f ? __expf(sc[r] - mn) : 0.f;
+        sc[r] = pr;
+        sum += pr;
+      }
+      sum += __shfl_xor(sum, 32);
+      l = l * alpha + sum;
+      m = mn;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[r], sc[r], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[r], sc[r], o1, 0, 0, 0);
+      }
+    }
+    if (i < T) {
+      const float scl = i < n ? 1.0f / l : 0.f;         // rows beyond the valid window: deterministic zeros
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        f32x4 x0 = {o0[rr * 4 + 0], o0[rr * 4 + 1], o0[rr * 4 + 2], o0[rr * 4 + 3]};
+        f32x4 x1 = {o1[rr * 4 + 0], o1[rr * 4 + 1], o1[rr * 4 + 2], o1[rr * 4 + 3]};
+        *(f32x4*)(op + rr * 8 + hi * 4) = x0 * scl;
+        *(f32x4*)(op + 32 + rr * 8 + hi * 4) = x1 * scl;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 4b. last-row path of the final layer.  Only the newest row of the last stereo layer reaches the
 //     heads (vap_main.py:316-317 takes [-1]); its K/V still need every row, but Q, the attention
 //     output, both projections and the FFN are needed for ONE row per (stream, channel).  Exact.
@@ -941,7 +1058,11 @@ hipError_t launch_gather_ln(const GatherArgs& a, hipStream_t st) {
 }
 hipError_t launch_attention(const AttnArgs& a, int B, hipStream_t st) {
   const int n_tiles = (a.T + 31) / 32;
-  if (n_tiles > 8) return hipErrorInvalidValue;          // T <= 256 (vapx_create enforces it)
+  if (n_tiles > 16) return hipErrorInvalidValue;         // T <= 512 (vapx_create enforces it)
+  if (n_tiles > 8 || getenv("VAPX_FORCE_ATTENTION_XL")) {   // 257 .. 512 frames (the env switch: tests hold the kernel against attention_long2_kernel)
+    hipLaunchKernelGGL(attention_xl_kernel, dim3(B * 2 * 4), dim3(256), 0, st, a);
+    return hipGetLastError();
+  }
   static PerDeviceOnce attr_set;
   attr_set.run([] { (void)hipFuncSetAttribute((const void*)attention_long2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); });
   hipLaunchKernelGGL(attention_long2_kernel, dim3(B * 2 * 4), dim3(256), (size_t)n_tiles * 32 * 64 * sizeof(float), st, a);
