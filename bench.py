@@ -41,6 +41,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+NOMINAL_SCLK_MHZ = 2400.0   # the clock the MFMA peaks of MI355X_MICROARCH.md are quoted at
 FP32_MFMA_PEAK_TF = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact f32
 F16_MFMA_PEAK_TF = 2516.6     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16, dense
 HBM_PEAK_GBS = 8000.0
@@ -574,6 +575,11 @@ def run_workload(name, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=0, split
     if split_f16:
         roof["peak_note"] = ("every GEMM-shaped contraction = 3 f16 MFMA products (hi.hi + lo.hi + hi.lo), fp32 accumulate: peak = dense f16 MFMA / 3 "
                              f"= {peak:.1f} fp32-equivalent TFLOP/s; frac_of_fp32_mfma_peak = {achieved_tf / FP32_MFMA_PEAK_TF:.3f}")
+    board = watch.record()
+    if board and board.get("sclk_mhz_median"):
+        # the peaks above are quoted at the part's 2.4 GHz boost clock; under the board's power limit the kernels run slower than that
+        roof["sclk_mhz"] = board["sclk_mhz_median"]
+        roof["frac_at_sclk"] = roof["frac"] * NOMINAL_SCLK_MHZ / board["sclk_mhz_median"]
     rec = {
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
         "timed_seconds": dt,
@@ -589,7 +595,7 @@ def run_workload(name, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=0, split
         "executed_tflops_dense_attention": value * exec_gflop / 1e3,
         "executed_frac_of_fp32_mfma_peak": value * exec_gflop_causal / 1e3 / (FP32_MFMA_PEAK_TF * world),
         "roofline": roof,
-        "board": watch.record(),                                     # watts and shader clock during the timed steps (None: no hwmon files)
+        "board": board,                                              # watts and shader clock during the timed steps (None: no hwmon files)
         "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1])},
         # every kernel class against the same roof (algorithmic FLOPs of the class per step / its time in the profiled pass;
         # attention classes on the dense T x T count): shows which kernel is furthest below the fp32-MFMA peak
@@ -868,7 +874,8 @@ def compact_line(result: dict, full_path: str = "") -> str:
                         "tolerance_abs": result["parity_gate"]["tolerance_abs"]},
         "roofline": {"bound": roof["bound"], "kernel": roof["kernel"], "achieved": _r(roof["achieved"]), "peak": _r(roof["peak"]),
                      "unit": roof["unit"], "frac": _r(roof["frac"], 4), "traffic": _r(roof.get("traffic")), "avg_launch_us": _r(roof["avg_launch_us"]),
-                     "launches_per_step": _r(roof["launches_per_step"], 3), "traffic_ratio": _r(roof.get("traffic_ratio"), 3)},
+                     "launches_per_step": _r(roof["launches_per_step"], 3), "traffic_ratio": _r(roof.get("traffic_ratio"), 3),
+                     "frac_at_sclk": _r(roof.get("frac_at_sclk"), 4)},
     }
     if "executed_frac_of_fp32_mfma_peak" in result:
         line["executed_tflops"] = _r(result["executed_tflops"], 4)

@@ -116,6 +116,17 @@ def test_roofline_bookkeeping_describes_one_set_of_launches():
     assert line["roofline"]["traffic_ratio"] == pytest.approx(ratio, rel=1e-2) and len(json.dumps(line)) < 4096
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert '"executed_tflops": value * exec_gflop_causal / 1e3' in src
+    # round 5: the board's watts and shader clock during the timed steps, and the roofline fraction at that clock, ride in the line
+    full["board"] = {"watts_median": 1325.0, "watts_max": 1337.0, "sclk_mhz_median": 2321.0, "sclk_mhz_min": 2313.0, "samples": 31}
+    full["roofline"]["frac_at_sclk"] = full["roofline"]["frac"] * bench.NOMINAL_SCLK_MHZ / 2321.0
+    if isinstance(full.get("split_f16"), dict) and "value" in full["split_f16"]:
+        full["split_f16"]["board"] = {"watts_median": 1372.0, "sclk_mhz_median": 1957.0}
+    line = strict(bench.compact_line(full))
+    assert line["board"] == {"watts": 1325.0, "sclk_mhz": 2321.0}
+    assert line["roofline"]["frac_at_sclk"] == pytest.approx(full["roofline"]["frac"] * 2400.0 / 2321.0, rel=1e-3)
+    if "split_f16" in line and "value" in line["split_f16"]:
+        assert line["split_f16"]["watts"] == 1372.0 and line["split_f16"]["sclk_mhz"] == 1957.0
+    assert len(json.dumps(line)) < 4096
 
 
 def test_bench_main_prints_only_the_compact_line():
