@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void attention_long2_kernel(AttnArgs a) {
 // 4a'. windows of 257 .. 512 frames (round 5).  The reference's ALiBi transformer takes any T (modules.py:303-308: the mask is rebuilt
 //      for the sequence at hand); no published checkpoint goes beyond 10 s x 20 Hz = 200 frames, so this kernel is the plain form of the
 //      one above, built to be right rather than tuned: one workgroup per (stream, channel, head), four waves, wave w takes the query
-//      tiles w, w + 4, w + 8, w + 12; K fragments AND the V rows come straight from global / L2 (512 keys x 64 features would be 128 KB
+//      tiles w, 7 - w, 8 + w, 15 - w (balanced); K fragments AND the V rows come straight from global / L2 (512 keys x 64 features would be 128 KB
 //      of LDS), the softmax is online per 32-key tile exactly as above.  Same operand layouts, same masking, same arithmetic order per
 //      tile — a window of <= 256 frames run through this kernel gives attention_long2_kernel's results (tests/test_engine_gpu.py).
 // ------------------------------------------------------------------------------------------------
@@ -666,7 +666,9 @@ __global__ __launch_bounds__(256, 2) void attention_xl_kernel(AttnArgs a) {
   const int nt_valid = (n + 31) >> 5;
   const float slope = exp2f(-2.0f * (float)(h + 1));  // [1/4, 1/16, 1/64, 1/256]
   const float hi4f = (float)(4 * hi);
-  for (int it = w; it < n_tiles; it += 4) {
+  for (int pass = 0; pass < 4; ++pass) {
+    const int it = pass * 4 + ((pass & 1) ? 3 - w : w);   // zig-zag over the waves: 34 causal key tiles for every wave of a full 512-frame window
+    if (it >= n_tiles) continue;
     const int i = it * 32 + l31;
     float* op = a.out + ((long)bc * T + i) * 256 + h * 64;
     if (it >= nt_valid) {                             // whole tile beyond the valid rows: deterministic zeros
