@@ -417,11 +417,11 @@ class BoardWatch:
     The split-precision path runs at the board's power limit: a frame rate without the clock it was measured at says
     little about the kernel.  The rank's own card is found by PCI address; failing that, the busiest visible card is reported."""
 
-    def __init__(self, device_index=0, period=0.05):
+    def __init__(self, device_index=0, period=0.05, root="/sys/class/drm"):
         import glob
         self.period = period
         self.cards = []
-        hwmons = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+        hwmons = sorted(glob.glob(os.path.join(root, "card*/device/hwmon/hwmon*")))
         try:      # this rank's own card by PCI address (a node's other GPUs — other tenants' — are visible in sysfs too)
             import torch
             pr = torch.cuda.get_device_properties(device_index)

@@ -133,3 +133,21 @@ def test_bench_main_prints_only_the_compact_line():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert src.count("print(compact_line(") == 1
     assert "print(json.dumps(result))" not in src
+
+
+def test_board_watch_reads_hwmon_power_and_clock(tmp_path):
+    """bench.BoardWatch against a stand-in sysfs tree: microwatts / hertz in, watts / MHz medians out; no hwmon files -> no record."""
+    import time
+    hw = tmp_path / "card3" / "device" / "hwmon" / "hwmon7"
+    hw.mkdir(parents=True)
+    (hw / "power1_input").write_text("1325000000\n")
+    (hw / "freq1_input").write_text("2321000000\n")
+    w = bench.BoardWatch(period=0.005, root=str(tmp_path))
+    with w:
+        time.sleep(0.15)
+    rec = w.record()
+    assert rec and rec["watts_median"] == 1325.0 and rec["sclk_mhz_median"] == 2321.0 and rec["samples"] >= 3
+    empty = bench.BoardWatch(root=str(tmp_path / "nothing"))
+    with empty:
+        pass
+    assert empty.record() is None
