@@ -421,6 +421,7 @@ class BoardWatch:
         import glob
         self.period = period
         self.cards = []
+        self.caps = []
         hwmons = sorted(glob.glob(os.path.join(root, "card*/device/hwmon/hwmon*")))
         try:      # this rank's own card by PCI address (a node's other GPUs — other tenants' — are visible in sysfs too)
             import torch
@@ -436,6 +437,8 @@ class BoardWatch:
             fq = hw + "/freq1_input"
             if pw:
                 self.cards.append((pw, fq if os.path.exists(fq) else None))
+                cap = self._read(hw + "/power1_cap")
+                self.caps.append(cap * 1e-6 if cap else None)
         self.samples = [[] for _ in self.cards]
         self._stop = None
 
@@ -471,15 +474,17 @@ class BoardWatch:
             self._thr.join()
 
     def record(self):
-        best = max(self.samples, key=lambda xs: (sum(x[0] for x in xs) / len(xs)) if xs else 0.0, default=[])
+        k = max(range(len(self.samples)), key=lambda i: (sum(x[0] for x in self.samples[i]) / len(self.samples[i])) if self.samples[i] else 0.0, default=None)
+        best = self.samples[k] if k is not None else []
         if len(best) < 3:
             return None
+        cap = self.caps[k] if k < len(self.caps) else None
         best = best[len(best) // 5:]                                   # drop the ramp at the start of the region
         ws = sorted(x[0] for x in best)
         fs = sorted(x[1] for x in best if x[1])
         return {"watts_median": round(ws[len(ws) // 2], 1), "watts_max": round(ws[-1], 1),
                 "sclk_mhz_median": round(fs[len(fs) // 2], 0) if fs else None, "sclk_mhz_min": round(fs[0], 0) if fs else None,
-                "samples": len(ws), "card_matched_by_pci_address": self.matched,
+                "power_cap_w": round(cap, 0) if cap else None, "samples": len(ws), "card_matched_by_pci_address": self.matched,
                 "source": "amdgpu hwmon power1_input / freq1_input of this rank's card, 20 Hz, during the timed steps"}
 
 
