@@ -387,6 +387,11 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
   // are masked below) and the Q fragments of BOTH query tiles.  V goes first: loads return in order, so the LDS stores that wait
   // for V leave the 32 K / Q loads in flight.  (Round 2 fetched the second tile's K / Q fragments inside its MFMA loop: ten exposed
   // L2 / HBM latencies per workgroup, the largest single cost of the block.)
+  // SPLIT (round 5): the attention phase runs on the f16 matrix cores too — S^T = K.Q^T and O^T = V^T.P^T as 3-term split products (12
+  // v_mfma_f32_32x32x16_f16 per 32 x 32 tile pair instead of 32 v_mfma_f32_32x32x2_f32 of twice the length).  A lane half then holds 8 consecutive
+  // features of its row per 16-feature chunk c: d = 16 c + 8 hi + 0..7, fetched as the two f32x4 of fragment slots 2 c, 2 c + 1.
+  auto koff = [&](int kc) { return SPLIT ? (kc >> 1) * 16 + hi * 8 + (kc & 1) * 4 : kc * 8 + kh; };
+  float vmax_h = 0.f;                       // SPLIT: max |V| of this head's tile
   f32x4 kf0[8], qf0[8], kf1[8], qf1[8];
   {
     f32x4 vv[16];
@@ -399,21 +404,21 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
     }
     {
       const int j0 = l31 < n ? l31 : n - 1;
-      const float* k0 = kp + (long)prow(j0) * a.ldkv + kh;
+      const float* k0 = kp + (long)prow(j0) * a.ldkv;
 #pragma unroll
-      for (int kc = 0; kc < 8; ++kc) kf0[kc] = *(const f32x4*)(k0 + kc * 8);
-      const float* qp = a.q + (slab_q * T + prow(j0)) * a.ldq + h * 64 + kh;
+      for (int kc = 0; kc < 8; ++kc) kf0[kc] = *(const f32x4*)(k0 + koff(kc));
+      const float* qp = a.q + (slab_q * T + prow(j0)) * a.ldq + h * 64;
 #pragma unroll
-      for (int kc = 0; kc < 8; ++kc) qf0[kc] = *(const f32x4*)(qp + kc * 8);
+      for (int kc = 0; kc < 8; ++kc) qf0[kc] = *(const f32x4*)(qp + koff(kc));
     }
     if (two) {
       const int j1 = 32 + l31 < n ? 32 + l31 : n - 1;
-      const float* k1 = kp + (long)prow(j1) * a.ldkv + kh;
+      const float* k1 = kp + (long)prow(j1) * a.ldkv;
 #pragma unroll
-      for (int kc = 0; kc < 8; ++kc) kf1[kc] = *(const f32x4*)(k1 + kc * 8);
-      const float* qp = a.q + (slab_q * T + prow(j1)) * a.ldq + h * 64 + kh;
+      for (int kc = 0; kc < 8; ++kc) kf1[kc] = *(const f32x4*)(k1 + koff(kc));
+      const float* qp = a.q + (slab_q * T + prow(j1)) * a.ldq + h * 64;
 #pragma unroll
-      for (int kc = 0; kc < 8; ++kc) qf1[kc] = *(const f32x4*)(qp + kc * 8);
+      for (int kc = 0; kc < 8; ++kc) qf1[kc] = *(const f32x4*)(qp + koff(kc));
     }
     __builtin_amdgcn_sched_barrier(0);      // keep the K / Q loads above the LDS stores that wait for V
 #pragma unroll
@@ -427,6 +432,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
       for (int u = 0; u < 16; ++u) m = fmaxf(m, fmaxf(fmaxf(fabsf(vv[u][0]), fabsf(vv[u][1])), fmaxf(fabsf(vv[u][2]), fabsf(vv[u][3]))));
       m = wave_max(m);
       if (lane == 0) vmx[h] = m;
+      vmax_h = m;
     }
   }
   STAMP();   // 1: V tile in LDS (first memory latency)
@@ -446,12 +452,14 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
   // (key j = C_r + 4 hi with C_r a compile-time constant: the causal / window tests compare C_r with the per-lane i - 4 hi, n - 4 hi, so no
   // per-element index register exists)
   const float hi4f = (float)kh;
-  auto masked = [&](f32x16& s, int jt, int i, float& mx) {
+  // (SPLIT: the scores carry the power-of-two scales of their K and Q tiles; uk un-scales the accumulator, uq rides with the 1/16 — both exact)
+  auto masked = [&](f32x16& s, int jt, int i, float& mx, float uk = 1.0f, float uq = 1.0f) {
     const int i4 = i - kh, n4 = n - kh;
+    const float sixteenth = SPLIT ? 0.0625f * uq : 0.0625f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int c = jt * 32 + (r & 3) + 8 * (r >> 2);
-      float v = fmaf(s[r], 0.0625f, slope * ((float)c + hi4f));
+      float v = fmaf(SPLIT ? s[r] * uk : s[r], sixteenth, slope * ((float)c + hi4f));
       v = ((c <= i4) && (c < n4)) ? v : -1e30f;
       s[r] = v;
       mx = fmaxf(mx, v);
@@ -479,7 +487,109 @@ __global__ __launch_bounds__(256, 2) void attn_block_kernel(const AttnBlockArgs 
   f32x16 oa0, oa1, ob0, ob1;   // query tile 0 / 1, feature tile 0 / 1 (O^T, scaled by 1 / rowsum)
 #pragma unroll
   for (int r = 0; r < 16; ++r) { oa0[r] = 0.f; oa1[r] = 0.f; ob0[r] = 0.f; ob1[r] = 0.f; }
-  {
+  if constexpr (SPLIT) {
+    // ---- f16 (hi, lo) operands of the three score tiles, each tile scaled by a power of two from its own maximum ----
+    auto split8s = [](const f32x4& x0, const f32x4& x1, float sc, h16x8& fh, h16x8& fl) {
+      const f32x4 y0 = x0 * sc, y1 = x1 * sc;
+      const h16x4 h0 = __builtin_convertvector(y0, h16x4), h1 = __builtin_convertvector(y1, h16x4);
+      const h16x4 l0 = __builtin_convertvector(y0 - __builtin_convertvector(h0, f32x4), h16x4);
+      const h16x4 l1 = __builtin_convertvector(y1 - __builtin_convertvector(h1, f32x4), h16x4);
+      fh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+      fl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto tile_scale = [&](const f32x4 (&f)[8]) {
+      float m = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc) m = fmaxf(m, fmaxf(fmaxf(fabsf(f[kc][0]), fabsf(f[kc][1])), fmaxf(fabsf(f[kc][2]), fabsf(f[kc][3]))));
+      return pow2_scale_for(wave_max(m));
+    };
+    auto conv = [&](const f32x4 (&f)[8], float sc, h16x8 (&fh)[4], h16x8 (&fl)[4]) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) split8s(f[2 * c], f[2 * c + 1], sc, fh[c], fl[c]);
+    };
+    auto scores16 = [&](f32x16& s, const h16x8 (&Kh)[4], const h16x8 (&Kl)[4], const h16x8 (&Qh)[4], const h16x8 (&Ql)[4]) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(Kh[c], Qh[c], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(Kl[c], Qh[c], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(Kh[c], Ql[c], s, 0, 0, 0);
+      }
+    };
+    h16x8 K0h[4], K0l[4], Q0h[4], Q0l[4], K1h[4], K1l[4], Q1h[4], Q1l[4];
+    const float sK0 = tile_scale(kf0), sQ0 = tile_scale(qf0);
+    conv(kf0, sK0, K0h, K0l);
+    conv(qf0, sQ0, Q0h, Q0l);
+    float sK1 = 1.0f, sQ1 = 1.0f;
+    if (two) {
+      sK1 = tile_scale(kf1); sQ1 = tile_scale(qf1);
+      conv(kf1, sK1, K1h, K1l);
+      conv(qf1, sQ1, Q1h, Q1l);
+    }
+    const float uK0 = __builtin_amdgcn_rcpf(sK0), uQ0 = __builtin_amdgcn_rcpf(sQ0), uK1 = __builtin_amdgcn_rcpf(sK1), uQ1 = __builtin_amdgcn_rcpf(sQ1);   // exact: powers of two
+    f32x16 sa, sb0, sb1;
+    scores16(sa, K0h, K0l, Q0h, Q0l);
+    if (two) { scores16(sb0, K0h, K0l, Q1h, Q1l); scores16(sb1, K1h, K1l, Q1h, Q1l); }
+    // ---- O^T = V^T . P^T: the accumulator registers 8 c .. 8 c + 7 of a score tile are the 8 k-slots of this lane half in key chunk c, i.e. the
+    // keys 32 jt + 16 c + 8 (e >> 2) + 4 hi + (e & 3), e = 0 .. 7; the V^T operand of lane (feature d, hi) gathers exactly those keys from the fp32
+    // tile in LDS (the k order inside a chunk is free as long as both operands agree), scaled by a power of two from the head's max |V| ----
+    const float sV = pow2_scale_for(vmax_h), uV = __builtin_amdgcn_rcpf(sV);
+    auto vt_frags = [&](int jt, h16x8 (&Vh)[2][2], h16x8 (&Vl)[2][2]) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const float* vb = &Vs[(jt * 32 + c * 16 + 4 * hi) * KV_LD2 + dt * 32 + l31];
+          const f32x4 v0 = {vb[0], vb[KV_LD2], vb[2 * KV_LD2], vb[3 * KV_LD2]};
+          const f32x4 v1 = {vb[8 * KV_LD2], vb[9 * KV_LD2], vb[10 * KV_LD2], vb[11 * KV_LD2]};
+          split8s(v0, v1, sV, Vh[c][dt], Vl[c][dt]);
+        }
+    };
+    auto pv16 = [&](f32x16& o0, f32x16& o1, const f32x16& pr, const h16x8 (&Vh)[2][2], const h16x8 (&Vl)[2][2]) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const f32x4 p0 = {pr[8 * c], pr[8 * c + 1], pr[8 * c + 2], pr[8 * c + 3]}, p1 = {pr[8 * c + 4], pr[8 * c + 5], pr[8 * c + 6], pr[8 * c + 7]};
+        h16x8 ph, pl;
+        split8s(p0, p1, 1.0f, ph, pl);          // P in [0, 1]: no scale
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Vh[c][0], ph, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Vh[c][1], ph, o1, 0, 0, 0);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Vl[c][0], ph, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Vl[c][1], ph, o1, 0, 0, 0);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Vh[c][0], pl, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Vh[c][1], pl, o1, 0, 0, 0);
+      }
+    };
+    h16x8 Vh[2][2], Vl[2][2];
+    vt_frags(0, Vh, Vl);
+    {
+      const int i = l31;
+      float mx = -1e30f;
+      masked(sa, 0, i, mx, uK0, uQ0);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sum = expsum(sa, mx);
+      sum += __shfl_xor(sum, 32);
+      pv16(oa0, oa1, sa, Vh, Vl);
+      const float inv = i < n ? uV / sum : 0.f;    // rows beyond the window -> zeros
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { oa0[r] *= inv; oa1[r] *= inv; }
+    }
+    if (two) {
+      const int i = 32 + l31;
+      float mx = -1e30f;
+      masked(sb0, 0, i, mx, uK0, uQ1);
+      masked(sb1, 1, i, mx, uK1, uQ1);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sum = expsum(sb0, mx) + expsum(sb1, mx);
+      sum += __shfl_xor(sum, 32);
+      pv16(ob0, ob1, sb0, Vh, Vl);
+      vt_frags(1, Vh, Vl);
+      pv16(ob0, ob1, sb1, Vh, Vl);
+      const float inv = i < n ? uV / sum : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { ob0[r] *= inv; ob1[r] *= inv; }
+    }
+  } else {
     // the three score tiles back to back (96 MFMAs): the softmax VALU of tile 0 then overlaps the matrix pipe draining
     f32x16 sa, sb0, sb1;
     scores(sa, kf0, qf0);
