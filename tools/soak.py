@@ -26,7 +26,8 @@ c = engine.Engine(blob, HZ, CTX, max_streams=S, split_f16=True)
 NF = 16
 # bit-identity of the overlap-group engine holds while both batch sizes select the same kernel variants: up to 512 streams x 50 rows x 2
 # channels of transformer rows (measured); beyond that the GEMM tile heuristics differ between S and S / 2 and only the tolerance applies
-STRICT = S * 2 * a.T <= 512 * 2 * 50
+# (and at 20 / 50 Hz only: at 10 and 5 Hz the encoder's GEMM tile choice already differs between S and S / 2 streams — measured on the round-4 tree too)
+STRICT = S * 2 * a.T <= 512 * 2 * 50 and HZ >= 20
 audio = torch.from_numpy(np.concatenate([synth.dialogue_batch(list(range(64)), HOP * NF)] * ((S + 63) // 64))[:S]).cuda()
 # one resident tensor per frame: with VAPX_DEFER_JOIN the group streams of engine b may still be reading a tick's audio when the
 # next tick is enqueued, so the inputs must not be temporaries the caching allocator recycles under them
