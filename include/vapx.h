@@ -217,10 +217,16 @@ int vapx_transformer(vapx_handle h, int32_t n, int32_t rows, const float* x, flo
 /* The head callables process_vap applies to tensors of any row count (vap_main.py:290-307); device pointers, rows x 256 fp32:
  *   vapx_vap_head       logits = vap_head(x)            Linear(256, 256) + bias   (vap_main.py:131,290)   [rows][256]
  *   vapx_va_classifier  y = va_classifier(x)            Linear(256, 1) + bias, BEFORE the sigmoid (:142,292-293)   [rows]
+ *   vapx_aux_head       y = bc_head(x) / nod_head(x)    the bc / nod variants' extra Linear heads as vap_realtime/model.py:197,217-218
+ *                       applies them to out["x"] (vap_realtime/vap_models.py:220 Linear(256, 3); :328-329 Linear(256, 4) + Linear(256, 1));
+ *                       which = VAPX_AUX_BC_HEAD | VAPX_AUX_NOD_HEAD; raw outputs BEFORE softmax / sigmoid   [rows][3 | 1 | 4]
  *   vapx_softmax256     probs = logits.softmax(-1)      (:295)
  *   vapx_aggregate      objective.probs_next_speaker_aggregate(probs, from_bin, to_bin) (objective.py:186-206)   [rows][2] */
 int vapx_vap_head(vapx_handle h, int64_t rows, const float* x, float* logits, void* hip_stream);
 int vapx_va_classifier(vapx_handle h, int64_t rows, const float* x, float* y, void* hip_stream);
+#define VAPX_AUX_BC_HEAD 0
+#define VAPX_AUX_NOD_HEAD 1
+int vapx_aux_head(vapx_handle h, int32_t which, int64_t rows, const float* x, float* y, void* hip_stream);
 int vapx_softmax256(int64_t rows, const float* x, float* y, void* hip_stream);
 int vapx_aggregate(int64_t rows, const float* probs, int32_t from_bin, int32_t to_bin, float* out, void* hip_stream);
 

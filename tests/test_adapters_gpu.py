@@ -45,7 +45,7 @@ def test_level1_model_surface_under_reference_style_orchestration():
     import torch
     from vap_realtime_amd.realtime import VapGPT
     c = Case("vap20")
-    vap = VapGPT(c.cpc_sd, c.vap_sd, c.frame_hz, c.ctx_sec).to("cuda").eval()
+    vap = VapGPT.from_state_dicts(c.cpc_sd, c.vap_sd, c.frame_hz, c.ctx_sec).to("cuda").eval()
     e1_context, e2_context = [], []
     carry = np.zeros((2, 320), np.float32)
     for f in range(c.n_frames):
@@ -74,6 +74,142 @@ def test_level1_model_surface_under_reference_style_orchestration():
             rows = c.z[f"inter.f{f}.rows"]
             np.testing.assert_allclose(out["x"][0].cpu().numpy()[rows], c.z[f"inter.f{f}.comb"], rtol=0, atol=TOL)
             np.testing.assert_allclose(out["x1"][0].cpu().numpy()[rows], c.z[f"inter.f{f}.stereo2"][0], rtol=3e-5, atol=1e-3)
+
+
+class _ReferenceShapedRealTime:
+    """``VAPRealTime`` with the reference's construction statements (vap_main.py:194-215; vap_bc_main.py:188-209, vap_nod_main.py:187-208 and
+    the library twin vap_realtime/model.py:25-49 are the same lines) and its per-frame orchestration (vap_main.py:249-320 /
+    vap_realtime/model.py:126-240).  Only the two class names are rebound to vap_realtime_amd.realtime; tests/test_level1_construction.py
+    executes the reference's own ``__init__`` text the same way where the reference tree exists."""
+
+    BINS_P_NOW = [0, 1]
+    BINS_PFUTURE = [2, 3]
+
+    def __init__(self, VapConfig, VapGPT, mode, vap_model, cpc_model, device, frame_rate, context_len_sec):
+        import torch
+        from torch import nn
+        conf = VapConfig()
+        self.vap = VapGPT(conf)
+
+        self.device = device
+
+        sd = torch.load(vap_model, map_location=torch.device('cpu'))
+        self.vap.load_encoder(cpc_model=cpc_model)
+        self.vap.load_state_dict(sd, strict=False)
+
+        self.vap.encoder1.downsample[1].weight = nn.Parameter(sd['encoder.downsample.1.weight'])
+        self.vap.encoder1.downsample[1].bias = nn.Parameter(sd['encoder.downsample.1.bias'])
+        self.vap.encoder1.downsample[2].ln.weight = nn.Parameter(sd['encoder.downsample.2.ln.weight'])
+        self.vap.encoder1.downsample[2].ln.bias = nn.Parameter(sd['encoder.downsample.2.ln.bias'])
+
+        self.vap.encoder2.downsample[1].weight = nn.Parameter(sd['encoder.downsample.1.weight'])
+        self.vap.encoder2.downsample[1].bias = nn.Parameter(sd['encoder.downsample.1.bias'])
+        self.vap.encoder2.downsample[2].ln.weight = nn.Parameter(sd['encoder.downsample.2.ln.weight'])
+        self.vap.encoder2.downsample[2].ln.bias = nn.Parameter(sd['encoder.downsample.2.ln.bias'])
+
+        self.vap.to(self.device)
+        self.vap = self.vap.eval()
+
+        self.mode = mode
+        self.audio_context_len = int(context_len_sec * frame_rate)
+        self.e1_context = []
+        self.e2_context = []
+
+    def process_vap(self, x1, x2):
+        import torch
+        with torch.no_grad():
+            x1_ = torch.tensor([[x1]], dtype=torch.float32, device=self.device)
+            x2_ = torch.tensor([[x2]], dtype=torch.float32, device=self.device)
+            e1, e2 = self.vap.encode_audio(x1_, x2_)
+            self.e1_context.append(e1)
+            self.e2_context.append(e2)
+            if len(self.e1_context) > self.audio_context_len:
+                self.e1_context = self.e1_context[-self.audio_context_len:]
+            if len(self.e2_context) > self.audio_context_len:
+                self.e2_context = self.e2_context[-self.audio_context_len:]
+            x1_ = torch.cat(self.e1_context, dim=1).to(self.device)
+            x2_ = torch.cat(self.e2_context, dim=1).to(self.device)
+            o1 = self.vap.ar_channel(x1_, attention=False)
+            o2 = self.vap.ar_channel(x2_, attention=False)
+            out = self.vap.ar(o1["x"], o2["x"], attention=False)
+            r = {}
+            if self.mode == "vap":
+                logits = self.vap.vap_head(out["x"])
+                vad1 = self.vap.va_classifier(o1["x"])
+                vad2 = self.vap.va_classifier(o2["x"])
+                probs = logits.softmax(dim=-1)
+                p_now = self.vap.objective.probs_next_speaker_aggregate(probs, from_bin=self.BINS_P_NOW[0], to_bin=self.BINS_P_NOW[-1])
+                p_future = self.vap.objective.probs_next_speaker_aggregate(probs, from_bin=self.BINS_PFUTURE[0], to_bin=self.BINS_PFUTURE[1])
+                r["p_now"] = p_now.to('cpu').tolist()[0][-1]
+                r["p_future"] = p_future.to('cpu').tolist()[0][-1]
+                r["vad"] = [float(vad1.sigmoid().to('cpu')[::, -1]), float(vad2.sigmoid().to('cpu')[::, -1])]
+                r["logits"] = logits.to('cpu')[0, -1].numpy()
+            elif self.mode == "bc":
+                bc = self.vap.bc_head(out["x"])
+                r["p_bc_react"] = float(bc.softmax(dim=-1)[:, -1, 1].to('cpu'))
+                r["p_bc_emo"] = float(bc.softmax(dim=-1)[:, -1, 2].to('cpu'))
+            else:
+                p_bc = self.vap.bc_head(out["x"])
+                nod = self.vap.nod_head(out["x"])
+                r["p_bc"] = p_bc.sigmoid()[-1].to('cpu').numpy().reshape(-1)            # every row of the window (vap_nod_main.py:276)
+                r["p_nod_short"] = float(nod.softmax(dim=-1)[:, -1, 1].to('cpu'))
+                r["p_nod_long"] = float(nod.softmax(dim=-1)[:, -1, 2].to('cpu'))
+                r["p_nod_long_p"] = float(nod.softmax(dim=-1)[:, -1, 3].to('cpu'))
+            return r
+
+
+@pytest.mark.parametrize("name", ["vap20", "bc20", "nod20", "vap50", "nod20_10s"])
+def test_reference_constructor_lines_then_level1_orchestration(name, tmp_path):
+    """``VapGPT(VapConfig())`` -> ``load_encoder`` -> ``load_state_dict(strict=False)`` -> eight downsample assignments ->
+    ``.to(device)`` -> ``.eval()`` against a lazily built libvapx engine, then the reference's per-frame calls; checkpoint FILES in the
+    reference's format.  ``vap50`` (T = 250) and ``nod20_10s`` (T = 200) outgrow the engine's first window capacity (64 rows) during warm-up:
+    the rebuild must carry the LSTM state over (any loss shows as a jump at frame 65)."""
+    import argparse
+    import torch
+    from vap_realtime_amd import realtime as R
+    c = Case(name)
+    vap_t = {k: torch.from_numpy(np.asarray(v)) for k, v in c.vap_sd.items()}
+    vap_t["encoder.encoder.gEncoder.conv0.weight"] = torch.zeros(256, 1, 10)
+    vap_p, cpc_p = str(tmp_path / "vap_state_dict.pt"), str(tmp_path / "60k_epoch4-d0f474de.pt")
+    torch.save(vap_t, vap_p)
+    torch.save({"weights": {k: torch.from_numpy(np.asarray(v)) for k, v in c.cpc_sd.items()},
+                "config": argparse.Namespace(hiddenGar=256, hiddenEncoder=256)}, cpc_p)
+    klass = {"vap": R.VapGPT, "bc": R.VapGPT_bc, "nod": R.VapGPT_nod}[c.mode]
+    rt = _ReferenceShapedRealTime(R.VapConfig, klass, c.mode, vap_p, cpc_p, torch.device("cuda", 0), c.frame_hz, c.ctx_sec)
+    assert rt.vap._engine is None                                # lazily built
+    cur = np.zeros((2, 320))
+    capacities = set()
+    for f in range(c.n_frames):
+        cur = np.concatenate([cur, c.new_samples(f)[0].astype(np.float64)], axis=1)
+        r = rt.process_vap(cur[0].tolist(), cur[1].tolist())
+        cur = cur[:, -320:]
+        capacities.add(rt.vap._engine.T)
+        if c.mode == "vap":
+            np.testing.assert_allclose(r["logits"], c.z["logits"][f][0], rtol=0, atol=TOL, err_msg=f"frame {f}")
+            np.testing.assert_allclose(r["p_now"], c.z["p_now"][f][0], rtol=0, atol=TOL)
+            np.testing.assert_allclose(r["p_future"], c.z["p_future"][f][0], rtol=0, atol=TOL)
+            np.testing.assert_allclose(r["vad"], c.z["vad"][f][0], rtol=0, atol=TOL)
+        elif c.mode == "bc":
+            np.testing.assert_allclose(r["p_bc_react"], c.z["p_bc_react"][f][0], rtol=0, atol=TOL)
+            np.testing.assert_allclose(r["p_bc_emo"], c.z["p_bc_emo"][f][0], rtol=0, atol=TOL)
+        else:
+            n = min(f + 1, c.T)
+            np.testing.assert_allclose(r["p_bc"], c.z["p_bc"][f][0, :n], rtol=0, atol=TOL, err_msg=f"frame {f}")
+            np.testing.assert_allclose(r["p_nod_short"], c.z["p_nod_short"][f][0], rtol=0, atol=TOL)
+            np.testing.assert_allclose(r["p_nod_long"], c.z["p_nod_long"][f][0], rtol=0, atol=TOL)
+            np.testing.assert_allclose(r["p_nod_long_p"], c.z["p_nod_long_p"][f][0], rtol=0, atol=TOL)
+    assert capacities == ({64} if c.T <= 64 else {64, 256})
+    assert rt.vap.frame_hz == c.frame_hz                          # read off the downsample kernel, not off VapConfig (50)
+    # a weight assigned after the engine exists takes effect on the next call (the stale engine is rebuilt)
+    if c.mode == "vap":
+        x = torch.randn(1, 3, 256, device="cuda")
+        before = rt.vap.va_classifier(x)
+        sd = torch.load(vap_p, map_location="cpu")
+        sd["va_classifier.bias"] = sd["va_classifier.bias"] + 1.0
+        rt.vap.load_state_dict(sd, strict=False)
+        np.testing.assert_allclose((rt.vap.va_classifier(x) - before).cpu().numpy(), 1.0, rtol=0, atol=1e-5)
+    with pytest.raises(NotImplementedError):
+        rt.vap.ar_channel(torch.zeros(1, 4, 256, device="cuda"), attention=True)
 
 
 def test_tcp_front_end_end_to_end_on_gpu():
@@ -157,7 +293,7 @@ def test_vapgpt_forward_signature_with_realtime_semantics():
     import torch
     from vap_realtime_amd import realtime
     c = Case("multi3")
-    m = realtime.VapGPT(c.cpc_sd, c.vap_sd, c.frame_hz, c.ctx_sec, max_batch=3)
+    m = realtime.VapGPT.from_state_dicts(c.cpc_sd, c.vap_sd, c.frame_hz, c.ctx_sec, max_batch=3)
     wav = torch.from_numpy(c.audio[:, :, :c.hop * c.n_frames].copy())
     for _ in range(2):
         ret = m(wav)

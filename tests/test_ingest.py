@@ -228,6 +228,43 @@ def test_a_sender_that_outruns_the_engine_is_paused_not_dropped():
         srv.close()
 
 
+def test_a_partial_frame_after_an_overrun_pause_is_still_delivered():
+    """Round-5 advisor finding: SO_RCVLOWAT stayed at its pre-pause value across pause -> resume, so the tail of the frame that was open
+    when the connection resumed could sit unread in the socket.  Deterministic form: 1 byte (arms a whole-frame threshold), then a burst
+    of nine frames + 4000 bytes into a slow model (overrun -> pause), then the missing 1120 bytes — fewer than the stale threshold.  All
+    ten frames must be answered."""
+    hop = 800
+
+    class Slow(Model):
+        def step(self, ids, audio, out):
+            time.sleep(0.03)
+            return super().step(ids, audio, out)
+
+    for _ in range(3):
+        m = Slow()
+        srv = ingest.NativeServer.over_function(m.step, 1, 20, max_wait_s=0.001)
+        try:
+            i = socket.create_connection(("127.0.0.1", srv.port_in))
+            i.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            o = socket.create_connection(("127.0.0.1", srv.port_out))
+            _wait(lambda: srv.stats()["out_connections"] == 1 and srv.stats()["in_connections"] == 1)
+            level = [0.1 * (k + 1) for k in range(10)]
+            blob = b"".join(wire.encode_input(np.full(hop, v), np.full(hop, v)) for v in level)
+            frame = len(blob) // 10
+            i.sendall(blob[:1])
+            time.sleep(0.05)
+            i.sendall(blob[1:9 * frame + 4000])
+            _wait(lambda: srv.stats()["overruns"] >= 1)
+            time.sleep(0.05)
+            i.sendall(blob[9 * frame + 4000:])
+            for v in level:
+                _, r = _read_result(o)
+                np.testing.assert_allclose(r["p_now"], [np.float32(v)] * 2, rtol=1e-6)
+            assert srv.stats()["frames_done"] == 10
+        finally:
+            srv.close()
+
+
 def test_connection_burst_and_reconnect_reuse_slots():
     S, hop = 300, 800
     m = Model()

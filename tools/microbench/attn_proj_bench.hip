@@ -1,6 +1,6 @@
 // Micro-benchmark of attention_proj_f16x3_kernel (csrc/attention_proj_f16x3.hip) on synthetic LN rows: times the launch for B streams at window T
-// and, built with -DAP_TRACE, prints the median phase timeline of one wave over all items.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Ivap-realtime_amd/csrc [-DAP_TRACE] -o tools/microbench/attn_proj_bench tools/microbench/attn_proj_bench.hip
+// and, built with -DVAPX_TRACE, prints the median phase timeline of one wave over all items.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Ivap-realtime_amd/csrc [-DVAPX_TRACE [-DAP_TRACE_WAVE=k]] -o tools/microbench/attn_proj_bench tools/microbench/attn_proj_bench.hip
 #include "../../vap-realtime_amd/csrc/attention_proj_f16x3.hip"
 
 #include <algorithm>
@@ -25,11 +25,16 @@ int main(int argc, char** argv) {
   std::vector<int> hn(B, T);
   hipMemcpy(bn, hn.data(), B * 4, hipMemcpyHostToDevice);
   AttnProjArgs a{xn, wq, out, bn, T, 0};
-#ifdef AP_TRACE
+#ifdef VAPX_TRACE
+#ifndef AP_TRACE_WAVE
+#define AP_TRACE_WAVE 0
+#endif
   unsigned long long* tb;
   hipMalloc(&tb, (size_t)256 * 128 * 16 * 8);
   hipMemset(tb, 0, (size_t)256 * 128 * 16 * 8);
   hipMemcpyToSymbol(HIP_SYMBOL(ap_trace_buf), &tb, sizeof tb);
+  const int tw = AP_TRACE_WAVE;
+  hipMemcpyToSymbol(HIP_SYMBOL(ap_trace_wave), &tw, sizeof tw);
 #endif
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
@@ -44,7 +49,7 @@ int main(int argc, char** argv) {
   ms /= iters;
   const int items = B * 8, per_cu = (items + 255) / 256;
   printf("B=%d T=%d: %.3f ms per launch, %.2f us per (stream, channel, head) item per CU\n", B, T, ms, ms * 1e3 / per_cu);
-#ifdef AP_TRACE
+#ifdef VAPX_TRACE
   {
     hipMemset(tb, 0, (size_t)256 * 128 * 16 * 8);
     launch_attention_proj_f16x3(a, B, 0);

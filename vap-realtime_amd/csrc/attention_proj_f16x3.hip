@@ -54,11 +54,9 @@ __device__ __forceinline__ f32x4 quad(const f32x16& a, int q) { return f32x4{a[4
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-#ifdef AP_TRACE   // timeline build of tools/microbench/attn_proj_bench: s_memtime stamps of wave AP_TRACE_WAVE at the phase boundaries of every item
+#ifdef VAPX_TRACE   // debug build only (tools/microbench/attn_proj_bench sets the two symbols): s_memtime stamps of wave ap_trace_wave at the phase boundaries of every item
 __device__ unsigned long long* ap_trace_buf;
-#ifndef AP_TRACE_WAVE
-#define AP_TRACE_WAVE 0
-#endif
+__device__ int ap_trace_wave;
 #endif
 
 __global__ __launch_bounds__(512, 1) void attention_proj_f16x3_kernel(AttnProjArgs a) {
@@ -107,11 +105,11 @@ __global__ __launch_bounds__(512, 1) void attention_proj_f16x3_kernel(AttnProjAr
     }
   };
 
-#ifdef AP_TRACE
+#ifdef VAPX_TRACE
   int stamp_k = 0, stamp_item = 0;
   auto STAMP = [&]() {
     __builtin_amdgcn_sched_barrier(0);
-    if (w == AP_TRACE_WAVE && lane == 0 && stamp_k < 16 && stamp_item < 128) ap_trace_buf[((long)blockIdx.x * 128 + stamp_item) * 16 + stamp_k] = __builtin_amdgcn_s_memtime();
+    if (ap_trace_buf && w == ap_trace_wave && lane == 0 && stamp_k < 16 && stamp_item < 128) ap_trace_buf[((long)blockIdx.x * 128 + stamp_item) * 16 + stamp_k] = __builtin_amdgcn_s_memtime();
     ++stamp_k;
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -131,7 +129,7 @@ __global__ __launch_bounds__(512, 1) void attention_proj_f16x3_kernel(AttnProjAr
     const int l31 = opaque_vgpr(lane & 31), hi = opaque_vgpr(lane >> 5);
     const float hi4f = (float)(4 * hi);
     const int i = it * 32 + l31;                                 // this lane pair's row of the window
-#ifdef AP_TRACE
+#ifdef VAPX_TRACE
     stamp_k = 0;
 #endif
     STAMP();           // 0: item start
@@ -145,7 +143,7 @@ __global__ __launch_bounds__(512, 1) void attention_proj_f16x3_kernel(AttnProjAr
 #pragma unroll
       for (int r = 0; r < 16; ++r) { accQ[t][r] = 0.f; accK[t][r] = 0.f; accV[t][r] = 0.f; }
     {
-      const int ic = i < n ? i : n - 1;                          // rows beyond the window: the last valid row (finite; masked / zeroed below)
+      const int ic = i < n ? i : (n > 0 ? n - 1 : 0);           // rows beyond the window: the last valid row (finite; masked / zeroed below); an empty window reads row 0 of its own slab
       const float* xp = a.xn + ((long)cur * T + ic) * 256 + hi * 8;
       const char* wsrc = (const char*)a.wqkvp + (size_t)h * (16 * 12288);
       auto dma_slot = [&](int s) {                               // this wave's three 1 KB pieces of slot s -> ring position s & 3
@@ -154,15 +152,8 @@ __global__ __launch_bounds__(512, 1) void attention_proj_f16x3_kernel(AttnProjAr
           unsigned keep;
           const char* src = wsrc + (size_t)s * kSlotBytes + e * 1024;
           const unsigned d = ring_base + (unsigned)(s & 3) * kSlotBytes + w * 3072 + e * 1024;
-#ifndef AP_EXP_NO_DMA
-#ifdef AP_EXP_M0_NOSAVE
-          (void)keep;
-          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"(dma_voff), "s"(d), "s"(src) : "memory");
-#else
           asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
                        : "=&s"(keep) : "v"(dma_voff), "s"(d), "s"(src) : "memory");
-#endif
-#endif
         }
       };
       f32x4 rowbuf[2][2][2];                                     // [slot parity][k-step of the slot][first / second 16 bytes]
@@ -186,12 +177,8 @@ __global__ __launch_bounds__(512, 1) void attention_proj_f16x3_kernel(AttnProjAr
       auto slot = [&](auto Sc) {
         constexpr int s = decltype(Sc)::value;
         // the pieces of slot s + 1 have landed (this wave's: vmcnt(0); everyone's: the barrier) and every wave is done reading slot s - 1
-#if !defined(AP_EXP_NO_DMA) && !defined(AP_EXP_NO_WAIT)
         if constexpr (s < 7) wait_vm<0>();
-#endif
-#ifndef AP_EXP_NO_BARRIER
         if constexpr (s < 7) __builtin_amdgcn_s_barrier();
-#endif
         if constexpr (s + 1 < 8) load_rows(s + 1);
         asm volatile("" ::: "memory");
         if constexpr (s + 2 < 8) dma_slot(s + 2);
@@ -209,9 +196,6 @@ __global__ __launch_bounds__(512, 1) void attention_proj_f16x3_kernel(AttnProjAr
           const unsigned char* fp = lds_raw + (s & 3) * kSlotBytes + kk * 12288 + lane * 16;
           const unsigned char* fn = kk == 0 ? fp + 12288 : lds_raw + ((s + 1) & 3) * kSlotBytes + lane * 16;   // the next k-step's fragments
           auto pair_read = [&](f16x8 (&f)[4], const unsigned char* p) {
-#ifdef AP_EXP_NO_LDS
-            return;
-#endif
             f[0] = *(const f16x8*)p; f[1] = *(const f16x8*)(p + 1024); f[2] = *(const f16x8*)(p + 2048); f[3] = *(const f16x8*)(p + 3072);
           };
           // Q (weights = A, rows = B) from fr[0]; K's fragments go to fr[1]
@@ -414,7 +398,7 @@ __global__ __launch_bounds__(512, 1) void attention_proj_f16x3_kernel(AttnProjAr
     }
     asm volatile("" ::"v"(pf[0] + pf[1] + pf[2] + pf[3]));   // (the prefetch loads end here)
     STAMP();           // 7: attention done
-#ifdef AP_TRACE
+#ifdef VAPX_TRACE
     ++stamp_item;
 #endif
     // this item's output: accumulator r of o0 / o1 <-> feature (r&3) + 8 (r>>2) + 4 hi (+ 32) of query row i; kept in registers until the

@@ -586,6 +586,19 @@ __global__ void rowdot_kernel(const float* x, const float* w, const float* bias,
   const float d = wave_sum(xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3]);
   if (lane == 0) y[r] = d + bias[0];
 }
+// y[r][o] = x[r] . w[o] + b[o], o < nout <= 4   (bc_head: Linear(256, 3) / Linear(256, 1), nod_head: Linear(256, 4);
+// vap_realtime/vap_models.py:220,328-329, applied to out["x"] of ANY row count at vap_realtime/model.py:197,217-218)
+__global__ void rowheads_kernel(const float* x, const float* w, const float* bias, float* y, long rows, int nout) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const f32x4 xv = *(const f32x4*)(x + r * 256 + lane * 4);
+  for (int o = 0; o < nout; ++o) {
+    const f32x4 wv = *(const f32x4*)(w + o * 256 + lane * 4);
+    const float d = wave_sum(xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3]);
+    if (lane == 0) y[r * nout + o] = d + bias[o];
+  }
+}
 // softmax over the 256 classes of a row (probs = logits.softmax(-1), vap_main.py:295)
 __global__ void softmax256_kernel(const float* x, float* y, long rows) {
   const int lane = threadIdx.x & 63;
@@ -1418,6 +1431,22 @@ int vapx_va_classifier(vapx_handle h, int64_t rows, const float* x, float* y, vo
   (void)hipGetLastError();   // a stale error of an earlier, unrelated HIP call (this library's or anyone's) is not this call's
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)hip_stream, x, h->W("vad.w"), h->W("vad.b"), y, (long)rows);
+  HIPCHK(h, hipGetLastError());
+  return VAPX_OK;
+}
+
+int vapx_aux_head(vapx_handle h, int32_t which, int64_t rows, const float* x, float* y, void* hip_stream) {
+  if (!h || !x || !y || rows < 1) return VAPX_E_INVAL;
+  // aux.w rows: bc variant = bc_head rows 0..2; nod variant = nod_head rows 0..3, bc_head row 4 (weights.pack_blob)
+  int row0, nout;
+  if (h->cfg.mode == VAPX_MODE_BC && which == VAPX_AUX_BC_HEAD) { row0 = 0; nout = 3; }
+  else if (h->cfg.mode == VAPX_MODE_NOD && which == VAPX_AUX_BC_HEAD) { row0 = 4; nout = 1; }
+  else if (h->cfg.mode == VAPX_MODE_NOD && which == VAPX_AUX_NOD_HEAD) { row0 = 0; nout = 4; }
+  else return fail(h, VAPX_E_INVAL, "this weight set has no such head (bc_head: bc / nod variants, nod_head: nod variant)");
+  (void)hipGetLastError();
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  hipLaunchKernelGGL(rowheads_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)hip_stream, x, h->W("aux.w") + row0 * 256,
+                     h->W("aux.b") + row0, y, (long)rows, nout);
   HIPCHK(h, hipGetLastError());
   return VAPX_OK;
 }

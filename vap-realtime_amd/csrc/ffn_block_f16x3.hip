@@ -39,15 +39,10 @@
 #include <algorithm>
 #include <cstdlib>
 
-#ifndef VAPX_F16X3_WOVEN_GELU
-#define VAPX_F16X3_WOVEN_GELU 1   // 1: the GELU of hidden chunk c woven into the FFN1 contraction of chunk c + 1; 0: a phase of its own (32 registers less)
-#endif
-#ifndef VAPX_F16X3_PERSIST
-#define VAPX_F16X3_PERSIST 0       // 1: mode 1 without Q|K|V chunks walks its tiles in a persistent loop, the next tile's rows fetched behind the last contraction
-#endif
-#ifndef VAPX_F16X3_RING
-#define VAPX_F16X3_RING 4      // k-chunks of weight fragments in flight per wave (4: 1.5 k cycles of cover, as fast as 8 and 32 registers cheaper)
-#endif
+// Variants measured in round 5 and NOT in this file (one code path in the product; tools/microbench/patches/ffn_block_f16x3_knobs.patch re-creates
+// them): a persistent tile loop for mode 1 without Q|K|V chunks (next tile's rows fetched behind the last contraction: staging 9.2 -> 2.1 us, frame
+// rate +-1 % on a power-limited board), the GELU as a phase of its own instead of woven into the next FFN1 contraction (32 registers less, same
+// time), a weight ring of 8 k-chunks instead of 4 (as fast, 32 registers dearer).  profiles/r05_experiments/README.md section 4.
 
 namespace {
 
@@ -64,7 +59,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // phases run under the other's contractions (round 4: 22 us per tile with 5 us of MFMA in it when it ran alone on its CU).  Each workgroup
 // still feeds 64 rows per weight fragment, so the pair needs no more of the CU's vector-memory path per MFMA than one workgroup does.
 // TAILQ: the tile ends with the next layer's Q|K|V chunks (short windows; long windows only with VAPX_FLAG_SPLIT_QKV_IN_FFN).  Without them
-// (mode 1 by default since round 5: the attention kernel projects its own Q|K|V) the kernel is PERSISTENT — see the tile loop.
+// (mode 1 by default since round 5: the attention kernel projects its own Q|K|V) the normalised rows leave straight for xn_out.
 template <int MODE, bool TAILQ = true>
 __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel(const FfnArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -79,7 +74,7 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
   int lane = tid & 63;
   int w = __builtin_amdgcn_readfirstlane(tid >> 6);            // 0..7
   int l31 = lane & 31, hi = lane >> 5;
-  int m0 = blockIdx.x * BM;             // mode 1 is PERSISTENT: a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, .. (see the loop below)
+  const int m0 = blockIdx.x * BM;
 #ifdef VAPX_TRACE
   int stamp_k = 0;
   auto STAMP = [&]() {   // phase time stamps of wave 0 (debug build `make trace`: tools/ffn_trace.py --split)
@@ -103,7 +98,7 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
 #endif
 
   // weight fragments of this wave's 32 columns: ring of RD k-chunks (hi, lo) ahead, running on into the next unit
-  constexpr int RD = VAPX_F16X3_RING;
+  constexpr int RD = 4;   // k-chunks of weight fragments in flight per wave (1.5 k cycles of cover)
   f32x4 ring[2 * RD];
   auto wbase = [&](const float* wfrag) { return (const f32x4*)wfrag + (long)w * 16 * 2 * 64; };   // wave-uniform
   auto fetch = [&](const float* wfrag) {
@@ -172,32 +167,10 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
       for (int j = 0; j < 4; ++j) rs[rt][j] = *(const f32x4*)(rp + 8 * j);
     }
   };
-  // every global load of a tile's own rows: issued at kernel entry for the first tile and, in mode 1, behind the LAST contraction of a tile
-  // for the next one — the rows arrive under the closing stores / LayerNorm instead of costing a whole HBM latency with nothing else to run
-  auto issue_tile_loads = [&]() {
-    load_slots();
-    load_rows();
-    if constexpr (MODE == 1) load_resid();
-  };
-  constexpr bool PERSIST = VAPX_F16X3_PERSIST && MODE == 1 && !TAILQ;
-  const int m_step = (int)gridDim.x * BM;
-  // (xr / rs are dead from the staging / the projection's residual add on.)  The tile's own rows go first, right behind the last contraction; the
-  // residual rows — not needed before the NEXT tile's projection has run — follow at the very end of the tile, when the closing phases' row
-  // registers are free (asked for together they push the kernel into scratch spills, and a spill reload waits vmcnt(0): every load and store in flight).
-  auto prefetch_next_tile = [&]() {
-    if (PERSIST && m0 + m_step < g.M) { m0 += m_step; load_slots(); load_rows(); m0 -= m_step; }
-  };
-  auto prefetch_next_resid = [&]() {
-    if (PERSIST && m0 + m_step < g.M) { m0 += m_step; load_resid(); m0 -= m_step; }
-  };
-  const float* wrap = PERSIST ? g.wprojf : nullptr;   // the weight ring runs on into the next tile's first contraction
-  issue_tile_loads();
-#pragma unroll 1
-  for (;;) {
-  // Everything below hangs off these four values.  Re-defining them (no instruction) at the top of every tile keeps the address arithmetic of the
-  // whole tile OUT of the loop pre-header: hoisted there it stays live around the loop and the kernel spills (256 registers + 219 spilled
-  // against 208 for the single-tile form).
-  asm volatile("" : "+v"(lane), "+v"(l31), "+v"(hi), "+s"(w));
+  // every global load of the tile's own rows is issued at kernel entry (mode 1: the projection's residual rows with them)
+  load_slots();
+  load_rows();
+  if constexpr (MODE == 1) load_resid();
   TILE_BEGIN();
   {
     if constexpr (MODE == 0) {   // A operand of FFN1 = LayerNorm(xmid; ln_ffn), normalised and split while the tile is staged
@@ -275,7 +248,6 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
     }
     __builtin_amdgcn_s_setprio(0);
   };
-#if VAPX_F16X3_WOVEN_GELU
   // the same contraction, fully unrolled, with `side(q)` — a slice of VALU / LDS-store work that does not depend on it: one of the eight
   // 4-value groups of the PREVIOUS hidden chunk's GELU — woven into every pair of k-chunks: behind each of the 12 MFMAs come five VALU
   // instructions, one transcendental and one memory instruction (sched_group_barrier), which is what fits in an MFMA's shadow with two
@@ -311,7 +283,6 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
       }
     }
   };
-#endif
   auto zero = [](f32x16(&acc)[2]) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
@@ -387,7 +358,7 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
   };
 
   const int nq = TAILQ ? (g.wqkvf ? g.n_qkv_chunks : 0) : 0;
-  const float* after_ffn = g.wkvxf ? g.wkvxf : (nq ? g.wqkvf : wrap);
+  const float* after_ffn = g.wkvxf ? g.wkvxf : (nq ? g.wqkvf : nullptr);
   // When the tile's rows go through the row-per-wave pass at the end (statistics for the next projections / LayerNorm), the block's own
   // output (x, or mode 2's xmid) leaves FROM THAT PASS: a wave holds whole rows there — 1 KB contiguous per store instruction, and no trip
   // through the transposition tile (round 5: the separate store phase was 2.2 us of a 62 us tile).
@@ -479,7 +450,6 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
       *(h16x4*)&sHh[(rt * 32 + l31) * LD16 + ccol + 8 * j] = hh;
       *(h16x4*)&sHl[(rt * 32 + l31) * LD16 + ccol + 8 * j] = ll;
     };
-#if VAPX_F16X3_WOVEN_GELU
     // weight order: W0.0, W0.1, W3.0, W0.2, W3.1, W3.2 — the GELU of chunk c rides in the FFN1 contraction of chunk c + 1 (mm_side)
     f32x16 hacc[2][2];
     zero(hacc[0]);
@@ -498,34 +468,6 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
       lds_barrier();
       STAMP();   // gelu(c) -> sH  (+ FFN1 chunk c + 1)
       mm(out, sHh, sHl, g.w3f + (long)c * 65536, c == 0 ? g.w0f + 2 * 65536 : (c == 1 ? g.w3f + 2 * 65536 : after_ffn));
-#else
-    // weight order W0.0, W3.0, W0.1, W3.1, W0.2, W3.2; the GELU of a chunk is a phase of its own between its two contractions.  (Rounds 3-4 wove
-    // the GELU of chunk c into the FFN1 contraction of chunk c + 1.  With the round-5 GELU the woven pair measures 6.7 us
-    // against 2.6 + 3.4 apart: the SIMD issues MFMA and VALU from one port, so the weave only ever bought the barrier skew, and apart the
-    // second set of hidden accumulators — 32 registers — is gone.)
-    f32x16 hacc[1][2];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      zero(hacc[0]);
-      mm(hacc[0], sXh, sXl, g.w0f + (long)c * 65536, g.w3f + (long)c * 65536);
-      STAMP();   // FFN1 chunk c
-      if (c > 0) lds_barrier();   // every wave is done reading the previous chunk from sH
-#pragma unroll
-      for (int q = 0; q < 8; ++q) gelu_group(hacc[0], q);
-      lds_barrier();
-      STAMP();   // gelu(c) -> sH
-      mm(out, sHh, sHl, g.w3f + (long)c * 65536, c < 2 ? g.w0f + (long)(c + 1) * 65536 : after_ffn);
-#endif
-      if (PERSIST && c == 2) {
-        // The next tile's rows are loaded at ONE of three places further down (whichever contraction is the tile's last).  To the compiler a
-        // conditional definition keeps the PREVIOUS tile's xr / rs alive around the whole loop — 64 registers through the GELU phases.  These
-        // empty definitions end that live range here, where there is room.
-#pragma unroll
-        for (int k = 0; k < BM / 8; ++k) asm volatile("" : "=v"(xr[k]));
-#pragma unroll
-        for (int k = 0; k < 8; ++k) asm volatile("" : "=v"(rs[k >> 2][k & 3]));
-      }
-      if (c == 2 && !g.wkvxf && !nq) prefetch_next_tile();   // that was the tile's last contraction
       STAMP();   // FFN2 chunk c
     }
     {
@@ -595,8 +537,7 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
       for (int nc = 0; nc < 2; ++nc) {
         f32x16 acc[2];
         zero(acc);
-        mm(acc, sHh, sHl, g.wkvxf + (long)nc * 65536, nc == 0 ? g.wkvxf + 65536 : (nq ? g.wqkvf : wrap));
-        if (nc == 1 && !nq) prefetch_next_tile();
+        mm(acc, sHh, sHl, g.wkvxf + (long)nc * 65536, nc == 0 ? g.wkvxf + 65536 : (nq ? g.wqkvf : nullptr));
         if (nc == 1) FINE();    // kvx1 mm done (stores follow)
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
@@ -616,8 +557,7 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
     for (int nc = 0; nc < nq; ++nc) {
       f32x16 acc[2];
       zero(acc);
-      mm(acc, sHh, sHl, g.wqkvf + (long)nc * 65536, nc + 1 < nq ? g.wqkvf + (long)(nc + 1) * 65536 : wrap);
-      if (nc + 1 == nq) prefetch_next_tile();
+      mm(acc, sHh, sHl, g.wqkvf + (long)nc * 65536, nc + 1 < nq ? g.wqkvf + (long)(nc + 1) * 65536 : nullptr);
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -626,12 +566,7 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 1) void ffn_block_f16x3_kernel
       STAMP();   // q / k / v mm + store
     }
   }
-  prefetch_next_resid();
   TILE_END();
-  if (!PERSIST || m0 + m_step >= g.M) break;
-  m0 += m_step;
-  lds_barrier();   // every wave is done with this tile's LDS (the staging of the next tile overwrites sH / rinv)
-  }
 }
 
 }  // namespace
@@ -650,14 +585,9 @@ hipError_t launch_ffn_block_f16x3(const FfnArgs& a, hipStream_t st) {
   if (a.mode == 1 || a.mode == 2) {
     if (!a.att || !a.wprojf || !a.resid || !a.xmid_out) return hipErrorInvalidValue;
     if (a.mode == 1 && a.resid_rot && a.resid_T < 64) return hipErrorInvalidValue;   // a tile spans at most two windows (see the kernel's scalar slot / rotation loads)
-    if (a.mode == 1) {   // persistent: one workgroup per CU (136 KB of LDS each) walks the tiles with a stride of the grid
-      static const int persist_env = [] { const char* e = getenv("VAPX_FFN_PERSIST"); return e ? atoi(e) : 1; }();   // 0: one tile per workgroup (A/B runs)
-      int dev = 0, cus = 256;
-      (void)hipGetDevice(&dev);
-      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      const dim3 pgrid(VAPX_F16X3_PERSIST && persist_env ? std::min<unsigned>(grid.x, (unsigned)cus) : grid.x);
-      if (a.wqkvf && a.n_qkv_chunks > 0) hipLaunchKernelGGL((ffn_block_f16x3_kernel<1, true>), grid, block, lds, st, a);   // one tile per workgroup
-      else hipLaunchKernelGGL((ffn_block_f16x3_kernel<1, false>), pgrid, block, lds, st, a);
+    if (a.mode == 1) {
+      if (a.wqkvf && a.n_qkv_chunks > 0) hipLaunchKernelGGL((ffn_block_f16x3_kernel<1, true>), grid, block, lds, st, a);
+      else hipLaunchKernelGGL((ffn_block_f16x3_kernel<1, false>), grid, block, lds, st, a);
     }
     else hipLaunchKernelGGL(ffn_block_f16x3_kernel<2>, grid, block, lds, st, a);
   } else {

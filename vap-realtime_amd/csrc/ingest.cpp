@@ -430,7 +430,7 @@ void on_data(vapx_ingest* g, int r, int slot, uint8_t* scratch, size_t cap, uint
         s.paused = true;
       }
       g->overruns.fetch_add(1);
-      ep_mod(g->ep[r], s.fd_in, K_DATA | (uint32_t)slot, false);
+      ep_mod(g->ep[r], s.fd_in, K_DATA | (uint32_t)slot, false);   // (SO_RCVLOWAT is re-armed by do_resume, from the state the backlog leaves)
       // a buffer may have been released between pick_free and `paused = true`
       for (int b = 0; b < NBUF; ++b)
         if (s.state[b].load() == B_FREE) {
@@ -459,6 +459,10 @@ void do_resume(vapx_ingest* g, int r, int slot) {
     std::lock_guard<std::mutex> lk(g->resume_mu[r]);
     s.paused = false;
   }
+  // The backlog moved `fill` / `npartial`: the socket's SO_RCVLOWAT still holds what the frame open BEFORE the pause lacked, and the rest
+  // of the frame open NOW may be fewer bytes than that - they would sit in the socket unread (a finite stream lost its last frame, a
+  // live one got it a frame period late).  Set the threshold first, then re-enable EPOLLIN: EPOLL_CTL_MOD polls the socket against it.
+  arm_lowat(g, s);
   ep_mod(g->ep[r], s.fd_in, K_DATA | (uint32_t)slot, true);
 }
 

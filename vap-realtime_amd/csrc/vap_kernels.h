@@ -114,8 +114,8 @@ hipError_t launch_lstm(const LstmArgs& a, hipStream_t st);
 hipError_t launch_ring_append(const GatherArgs& a, hipStream_t st);
 hipError_t launch_gather_ln(const GatherArgs& a, hipStream_t st);
 hipError_t launch_attention(const AttnArgs& a, int B, hipStream_t st);
-hipError_t launch_attention_f16x3(const AttnArgs& a, int B, hipStream_t st);
-hipError_t launch_attention_proj_f16x3(const AttnProjArgs& a, int B, hipStream_t st);   // split-precision variant (attention_f16x3.hip), same arguments
+hipError_t launch_attention_f16x3(const AttnArgs& a, int B, hipStream_t st);   // split-precision variant (attention_f16x3.hip), same arguments
+hipError_t launch_attention_proj_f16x3(const AttnProjArgs& a, int B, hipStream_t st);   // split path, layers >= 1: Q|K|V projected inside (attention_proj_f16x3.hip)
 hipError_t launch_gather_last_ln(const LastRowArgs& a, hipStream_t st);
 hipError_t launch_ln_rows(const float* x, float* y, const float* gamma, const float* beta, int rows, hipStream_t st);
 hipError_t launch_attention_last(const AttnArgs& a, int B, hipStream_t st);

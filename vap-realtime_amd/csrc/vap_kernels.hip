@@ -1061,7 +1061,8 @@ hipError_t launch_gather_ln(const GatherArgs& a, hipStream_t st) {
 hipError_t launch_attention(const AttnArgs& a, int B, hipStream_t st) {
   const int n_tiles = (a.T + 31) / 32;
   if (n_tiles > 16) return hipErrorInvalidValue;         // T <= 512 (vapx_create enforces it)
-  if (n_tiles > 8 || getenv("VAPX_FORCE_ATTENTION_XL")) {   // 257 .. 512 frames (the env switch: tests hold the kernel against attention_long2_kernel)
+  static const bool force_xl = getenv("VAPX_FORCE_ATTENTION_XL") != nullptr;   // read once: getenv on the serving path races a host's setenv
+  if (n_tiles > 8 || force_xl) {   // 257 .. 512 frames (the env switch: tests hold the kernel against attention_long2_kernel)
     hipLaunchKernelGGL(attention_xl_kernel, dim3(B * 2 * 4), dim3(256), 0, st, a);
     return hipGetLastError();
   }

@@ -15,6 +15,7 @@ No CPU fallback anywhere: constructing any of these without libvapx.so / a gfx95
 from __future__ import annotations
 
 import time
+from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -261,23 +262,334 @@ def _logits_cls():
     return _LOGITS_CLS
 
 
-class VapGPT:
-    """``self.vap`` replacement: torch CUDA tensors in/out, HIP kernels inside (stage-level C ABI)."""
+BIN_TIMES: list = [0.2, 0.4, 0.6, 0.8]     # vap_main.py:33
 
-    def __init__(self, cpc_sd, vap_sd, frame_rate: int = 20, context_len_sec: float = 2.5, max_batch: int = 1,
-                 mode: str = "vap", device_id: int = 0):
-        import torch
-        self._torch = torch
-        self.engine = _engine.Engine(_weights.pack_blob(cpc_sd, vap_sd, mode), frame_rate, context_len_sec,
-                                     max_streams=max_batch, mode=mode, device_id=device_id)
-        self.device = torch.device("cuda", device_id)
-        self.objective = _Objective(self.engine.lib)
 
-    def to(self, device):
-        return self
+@dataclass
+class VapConfig:
+    """Fields and defaults of the reference's ``VapConfig`` (vap_main.py:35-85; the bc / nod programs and the library twin carry the
+    same class: vap_realtime/vap_models.py:19-69).  The engine is built for the one architecture every published checkpoint has;
+    ``VapGPT(conf)`` rejects a ``conf`` that asks for another one (see ``_check_conf``)."""
+    sample_rate: int = 16000
+    frame_hz: int = 50
+    bin_times: List[float] = field(default_factory=lambda: BIN_TIMES)
+    encoder_type: str = "cpc"
+    wav2vec_type: str = "mms"
+    hubert_model: str = "hubert_jp"
+    freeze_encoder: int = 1
+    load_pretrained: int = 1
+    only_feature_extraction: int = 0
+    dim: int = 256
+    channel_layers: int = 1
+    cross_layers: int = 3
+    num_heads: int = 4
+    dropout: float = 0.1
+    context_limit: int = -1
+    context_limit_cpc_sec: float = -1
+    lid_classify: int = 0
+    lid_classify_num_class: int = 3
+    lid_classify_adversarial: int = 0
+    lang_cond: int = 0
+
+    @staticmethod
+    def add_argparse_args(parser, fields_added=[]):
+        for k, v in VapConfig.__dataclass_fields__.items():
+            if k == "bin_times":
+                parser.add_argument(f"--vap_{k}", nargs="+", type=float, default=v.default_factory())
+            else:
+                parser.add_argument(f"--vap_{k}", type=v.type if callable(v.type) else {"int": int, "float": float, "str": str}[v.type], default=v.default)
+            fields_added.append(k)
+        return parser, fields_added
+
+    @staticmethod
+    def args_to_conf(args):
+        return VapConfig(**{k.replace("vap_", ""): v for k, v in vars(args).items() if k.startswith("vap_")})
+
+
+_FIXED_CONF = {"sample_rate": 16000, "encoder_type": "cpc", "dim": 256, "channel_layers": 1, "cross_layers": 3, "num_heads": 4,
+               "context_limit": -1, "load_pretrained": 1}
+
+
+def _check_conf(conf):
+    """The HIP kernels are written for dim 256 / 4 heads / 1 + 3 layers / the CPC encoder / full causal attention: any other
+    value of those fields is refused here, at construction, instead of computing something else.  ``frame_hz``, ``dropout`` (inference),
+    ``freeze_encoder`` and the training-only multi-task switches do not touch the realtime path (the frame rate that counts is the one
+    of the loaded downsample kernel, vap_main.py:203-212)."""
+    for k, want in _FIXED_CONF.items():
+        got = getattr(conf, k, want)
+        if got != want:
+            raise _engine.VapxError(f"VapConfig.{k} = {got!r}: libvapx implements {k} = {want!r} only (the published Realtime-VAP architecture)")
+    if list(getattr(conf, "bin_times", BIN_TIMES)) != BIN_TIMES:
+        raise _engine.VapxError(f"VapConfig.bin_times = {conf.bin_times!r}: the 256-class codebook of libvapx is the one of {BIN_TIMES}")
+
+
+def _to_np(t) -> np.ndarray:
+    if hasattr(t, "detach"):
+        t = t.detach().cpu().float().numpy()
+    return np.ascontiguousarray(np.asarray(t, dtype=np.float32))
+
+
+class _Slot:
+    """A parameter holder (``.weight`` / ``.bias``) that takes whatever the reference assigns to it — ``nn.Parameter``, tensor, ndarray
+    (vap_main.py:204-212) — and tells the owning model that its device weights are stale."""
+
+    def __init__(self, owner, **children):
+        object.__setattr__(self, "_owner", owner)
+        object.__setattr__(self, "weight", None)
+        object.__setattr__(self, "bias", None)
+        for k, v in children.items():
+            object.__setattr__(self, k, v)
+
+    def __setattr__(self, name, value):
+        object.__setattr__(self, name, value)
+        self._owner._weights_changed()
+
+
+class _EncoderCPCProxy:
+    """``vap.encoder1`` / ``vap.encoder2``: what ``VAPRealTime.__init__`` touches of ``EncoderCPC`` (encoder.py:6-47) — the
+    ``downsample`` Sequential's entries ``[1]`` (Conv1d: ``.weight [256,256,K]``, ``.bias``) and ``[2].ln`` (``.weight``, ``.bias``)
+    (encoder_components.py:496-511) — plus ``eval() / freeze() / unfreeze()``.  The CPC tensors themselves (``gEncoder.*`` / ``gAR.*``)
+    sit in ``cpc_sd`` as loaded from the ``cpc_model`` file."""
+
+    def __init__(self, owner, cpc_sd):
+        self.sample_rate = 16000
+        self.output_dim = self.dim = 256
+        self.downsample_ratio = 320
+        self.cpc_sd = cpc_sd
+        self.downsample = [None, _Slot(owner), _Slot(owner, ln=_Slot(owner)), None, None]
 
     def eval(self):
         return self
+
+    def freeze(self):
+        pass
+
+    def unfreeze(self):
+        raise NotImplementedError("libvapx is an inference engine; there is nothing to train")
+
+    def _downsample_tensors(self):
+        d = self.downsample
+        return {"encoder.downsample.1.weight": d[1].weight, "encoder.downsample.1.bias": d[1].bias,
+                "encoder.downsample.2.ln.weight": d[2].ln.weight, "encoder.downsample.2.ln.bias": d[2].ln.bias}
+
+
+class _IncompatibleKeys(tuple):
+    """What ``nn.Module.load_state_dict`` returns: ``(missing_keys, unexpected_keys)``."""
+
+    def __new__(cls, missing, unexpected):
+        return super().__new__(cls, (missing, unexpected))
+
+    missing_keys = property(lambda self: self[0])
+    unexpected_keys = property(lambda self: self[1])
+
+
+_T_CAPACITIES = (64, 256, 512)      # window capacities a lazily built level-1 engine grows through (kernel families of DESIGN §4)
+
+
+class VapGPT:
+    """``self.vap`` replacement (SURVEY §8b level 1) with the reference's CONSTRUCTION surface, so that ``VAPRealTime.__init__``
+    (vap_main.py:194-215; library twin vap_realtime/model.py:25-49) runs textually unchanged with only the class names rebound:
+
+        self.vap = VapGPT(VapConfig())                                   # :194-195   (nothing touches the GPU yet)
+        self.vap.load_encoder(cpc_model=cpc_model)                       # :200       (CPC file -> encoder1 / encoder2 proxies)
+        self.vap.load_state_dict(sd, strict=False)                       # :201       (``encoder.*`` keys ignored like there)
+        self.vap.encoder1.downsample[1].weight = nn.Parameter(sd[...])   # :204-212   (eight assignments)
+        self.vap.to(self.device); self.vap = self.vap.eval()             # :214-215
+
+    The libvapx engine (device weights + LSTM state) is built at the first call that computes something: by then the downsample kernel
+    says the frame rate (K = n_cpc = 100 / rate) and the call says the window length.  ``VAPRealTime`` never tells the model its
+    ``context_len_sec``; the engine starts with room for 64 context rows and is rebuilt for 256 / 512 (carrying the LSTM state over) the
+    first time a longer window arrives — pass ``context_frames=`` to size it up front.  Assigning a weight after the engine exists
+    rebuilds it on the next call.  ``VapGPT.from_state_dicts(cpc_sd, vap_sd, ...)`` is the short form the tests and tools use.
+
+    Torch CUDA tensors in and out; every computation is a HIP kernel behind the C ABI (no rocBLAS, no CPU path)."""
+
+    _MODE = "vap"
+
+    def __init__(self, conf: Optional[VapConfig] = None, *, max_batch: int = 1, context_frames: Optional[int] = None, **engine_options):
+        if conf is None:
+            conf = VapConfig()
+        if not hasattr(conf, "dim"):
+            raise TypeError("VapGPT(conf): conf must be a VapConfig; the state-dict form is VapGPT.from_state_dicts(cpc_sd, vap_sd, ...)")
+        _check_conf(conf)
+        import torch
+        self._torch = torch
+        self.conf = conf
+        self.sample_rate = conf.sample_rate
+        self.frame_hz = conf.frame_hz
+        self.temp_elapse_time = []
+        self._lib = _engine.load_library()            # fails loudly here when libvapx.so is missing
+        self.objective = _Objective(self._lib)
+        self._sd: Dict[str, object] = {}
+        self._engine: Optional[_engine.Engine] = None
+        self._stale = False
+        self._max_batch = int(max_batch)
+        self._ctx_hint = context_frames
+        self._engine_options = engine_options
+        self._device_id = 0
+        self.device = None
+        self.training = False
+
+    # -- the reference's construction calls ------------------------------------------------------------------------------------
+    @classmethod
+    def from_state_dicts(cls, cpc_sd, vap_sd, frame_rate: Optional[int] = None, context_len_sec: float = 2.5, max_batch: int = 1,
+                         mode: Optional[str] = None, device_id: int = 0, **engine_options):
+        """Ready state dicts (reference key names) -> a model that is already on ``cuda:device_id`` with its engine built."""
+        from . import checkpoints
+        mode = mode or checkpoints.infer_mode(vap_sd)
+        klass = {"vap": VapGPT, "bc": VapGPT_bc, "nod": VapGPT_nod}[mode]
+        hz = frame_rate or checkpoints.infer_frame_rate(vap_sd)
+        m = klass(VapConfig(), max_batch=max_batch, context_frames=max(1, int(context_len_sec * hz)), **engine_options)
+        m.load_encoder(cpc_model=cpc_sd)
+        m.load_state_dict(vap_sd, strict=False)
+        for enc in (m.encoder1, m.encoder2):
+            enc.downsample[1].weight = vap_sd["encoder.downsample.1.weight"]
+            enc.downsample[1].bias = vap_sd["encoder.downsample.1.bias"]
+            enc.downsample[2].ln.weight = vap_sd["encoder.downsample.2.ln.weight"]
+            enc.downsample[2].ln.bias = vap_sd["encoder.downsample.2.ln.bias"]
+        m.to(f"cuda:{device_id}").eval()
+        m._build(max_batch, m._ctx_hint)
+        return m
+
+    def load_encoder(self, cpc_model):
+        """vap_main.py:144-169: both channels' ``EncoderCPC`` from ONE ``cpc_model`` file (path as ``load_CPC`` takes it,
+        encoder_components.py:372-399 — no download path here — or the loaded dict)."""
+        from . import checkpoints
+        if isinstance(cpc_model, (str, bytes)) or hasattr(cpc_model, "__fspath__"):
+            import os
+            if not os.path.isfile(cpc_model):
+                raise FileNotFoundError(f"CPC checkpoint {cpc_model!r} not found (the reference would download it; libvapx never does)")
+            cpc_model = checkpoints._torch_load(cpc_model)
+        cpc_sd = cpc_model["weights"] if "weights" in cpc_model else cpc_model
+        self.encoder1 = _EncoderCPCProxy(self, cpc_sd).eval()
+        self.encoder2 = _EncoderCPCProxy(self, cpc_sd).eval()
+        self._weights_changed()
+
+    def _model_keys(self):
+        """Parameter / buffer names the reference module owns (what ``load_state_dict`` matches against)."""
+        keys = [n for n, _, _ in _weights._vap_spec(5, self._MODE) if not n.startswith("encoder.")]
+        if hasattr(self, "encoder1"):
+            for e in ("encoder1", "encoder2"):
+                keys += [f"{e}.encoder.{n}" for n, _, _ in _weights._cpc_spec()]
+                keys += [f"{e}.downsample.1.weight", f"{e}.downsample.1.bias", f"{e}.downsample.2.ln.weight", f"{e}.downsample.2.ln.bias"]
+        return keys
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """``nn.Module.load_state_dict``: takes the tensors this module owns, reports the rest.  The reference calls it with
+        ``strict=False`` (vap_main.py:201) — the file's ``encoder.*`` keys match nothing (the module's encoders are ``encoder1`` /
+        ``encoder2``) and are dropped; that is why the four downsample tensors are assigned by hand afterwards."""
+        own = self._model_keys()
+        missing = [k for k in own if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in own]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for {type(self).__name__}: Missing key(s): {missing[:6]}..., "
+                               f"Unexpected key(s): {unexpected[:6]}...")
+        shapes = {n: s for n, s, _ in _weights._vap_spec(5, self._MODE)}
+        for k in own:
+            if k in state_dict and not k.startswith("encoder"):
+                if tuple(state_dict[k].shape) != tuple(shapes[k]):
+                    raise RuntimeError(f"size mismatch for {k}: copying a param with shape {tuple(state_dict[k].shape)}, the model has {tuple(shapes[k])}")
+                self._sd[k] = state_dict[k]
+        self._weights_changed()
+        return _IncompatibleKeys(missing, unexpected)
+
+    def state_dict(self):
+        sd = dict(self._sd)
+        if hasattr(self, "encoder1"):
+            for e, enc in (("encoder1", self.encoder1), ("encoder2", self.encoder2)):
+                sd.update({f"{e}.encoder.{k}": v for k, v in enc.cpc_sd.items()})
+                sd.update({k.replace("encoder.", e + ".", 1): v for k, v in enc._downsample_tensors().items() if v is not None})
+        return sd
+
+    def to(self, device=None, *args, **kwargs):
+        """``self.vap.to(self.device)`` (vap_main.py:214).  There is no CPU path: a cpu device raises."""
+        if device is None:
+            return self
+        dev = self._torch.device(device) if not isinstance(device, self._torch.device) else device
+        if dev.type != "cuda":
+            raise _engine.VapxError(f"vap-realtime_amd has no CPU path; .to({device!r}) needs a cuda device (MI355X)")
+        idx = 0 if dev.index is None else int(dev.index)
+        if self._engine is not None and idx != self._device_id:
+            self._stale = True
+        self._device_id = idx
+        self.device = self._torch.device("cuda", idx)
+        return self
+
+    def cuda(self, device=None):
+        return self.to(f"cuda:{device or 0}")
+
+    def eval(self):
+        return self
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError("libvapx is an inference engine; train() is not available")
+        return self
+
+    def _weights_changed(self):
+        self._stale = True
+
+    # -- the lazily built engine -------------------------------------------------------------------------------------------------
+    def _gather_state_dicts(self):
+        if not hasattr(self, "encoder1"):
+            raise _engine.VapxError("VapGPT: load_encoder(cpc_model=...) was never called (vap_main.py:200)")
+        d1, d2 = self.encoder1._downsample_tensors(), self.encoder2._downsample_tensors()
+        for k in d1:
+            if d1[k] is None or d2[k] is None:
+                raise _engine.VapxError(f"VapGPT: encoder1/encoder2.{k[len('encoder.'):]} was never assigned — load_state_dict does not load the "
+                                        f"downsample tensors, the caller assigns them (vap_main.py:203-212)")
+            if not np.array_equal(_to_np(d1[k]), _to_np(d2[k])):
+                raise _engine.VapxError(f"VapGPT: encoder1 and encoder2 differ in {k}; the engine serves both channels with one set "
+                                        f"(the reference assigns the same tensors to both, vap_main.py:204-212)")
+        if self.encoder1.cpc_sd is not self.encoder2.cpc_sd:
+            raise _engine.VapxError("VapGPT: encoder1 and encoder2 must come from the same cpc_model (vap_main.py:147-160)")
+        vap_sd = {k: _to_np(v) for k, v in self._sd.items()}
+        vap_sd.update({k: _to_np(v) for k, v in d1.items()})
+        cpc_sd = {k: _to_np(v) for k, v in self.encoder1.cpc_sd.items() if hasattr(v, "shape")}
+        return cpc_sd, vap_sd
+
+    def _build(self, batch: int, rows: Optional[int]):
+        from . import checkpoints
+        if self.device is None:
+            self.to("cuda:0")
+        cpc_sd, vap_sd = self._gather_state_dicts()
+        hz = checkpoints.infer_frame_rate(vap_sd)
+        checkpoints.validate(cpc_sd, vap_sd, hz, self._MODE)
+        want = max(int(rows or 1), int(self._ctx_hint or 1), self._engine.T if self._engine is not None else 1)
+        if self._ctx_hint and want == self._ctx_hint:
+            T = want
+        else:
+            fits = [c for c in _T_CAPACITIES if c >= want]
+            if not fits:
+                raise _engine.VapxError(f"a window of {want} frames exceeds the engine's maximum of {_T_CAPACITIES[-1]}")
+            T = fits[0]
+        mb = max(int(batch), self._max_batch)
+        old = self._engine
+        saved = []
+        if old is not None:
+            for sid in range(old.max_streams):
+                st = old.get_state(sid)
+                saved.append((st["lstm"], st["carry"]))
+            old.close()
+        eng = _engine.Engine(_weights.pack_blob(cpc_sd, vap_sd, self._MODE), hz, (T + 0.5) / hz, max_streams=mb, mode=self._MODE,
+                             device_id=self._device_id, **self._engine_options)
+        assert eng.T == T, (eng.T, T)
+        for sid, (lstm, carry) in enumerate(saved):          # the LSTM state is the model's only memory (encoder.py:27); the window is the caller's
+            eng.set_state(sid, {"ring": np.zeros((2, T, 256), np.float32), "n_frames": 0, "lstm": lstm, "carry": carry})
+        self._engine, self._max_batch, self._stale = eng, mb, False
+        self.frame_hz = hz
+        return eng
+
+    @property
+    def engine(self) -> "_engine.Engine":
+        if self._engine is None or self._stale:
+            self._build(self._max_batch, None)
+        return self._engine
+
+    def _engine_for(self, batch: int, rows: int = 1):
+        if self._engine is None or self._stale or batch > self._engine.max_batch or rows > self._engine.T:
+            self._build(batch, rows)
+        return self._engine
 
     def _stream(self):
         return self._torch.cuda.current_stream().cuda_stream
@@ -286,9 +598,13 @@ class VapGPT:
         """[B,1,L] x2 -> ([B,1,256], [B,1,256]); stateful LSTM like EncoderCPC (vap_main.py:175-180)."""
         torch = self._torch
         B = audio1.shape[0]
-        frames = torch.stack([audio1.reshape(B, -1), audio2.reshape(B, -1)], dim=1).float().contiguous()
+        eng = self._engine_for(B, 1)
+        frames = torch.stack([audio1.reshape(B, -1), audio2.reshape(B, -1)], dim=1).to(self.device).float().contiguous()
+        if frames.shape[2] != eng.L:
+            raise ValueError(f"encode_audio: {frames.shape[2]} samples per channel, the loaded {eng.frame_hz} Hz model takes "
+                             f"{eng.L} (= 16000 // rate + 320, vap_main.py:230)")
         e = torch.empty(B, 2, 256, device=self.device)
-        self.engine.encode_audio_device(B, frames.data_ptr(), e.data_ptr(), stream=self._stream())
+        eng.encode_audio_device(B, frames.data_ptr(), e.data_ptr(), stream=self._stream())
         return e[:, 0:1].contiguous(), e[:, 1:2].contiguous()
 
     def ar_channel(self, x, attention: bool = False):
@@ -296,24 +612,28 @@ class VapGPT:
         weights and layer 0 has no cross-channel term, so a batch of B inputs rides as ceil(B/2) (stream, channel) pairs:
         no input is computed twice."""
         torch = self._torch
+        if attention:
+            raise NotImplementedError("attention maps are never materialised by the fused attention block")
         B, n, _ = x.shape
-        x = x.float()
+        x = x.to(self.device).float()
         if B % 2:
             x = torch.cat([x, x[-1:]], dim=0)                         # odd batch: one padding row
         P = x.shape[0] // 2
         xin = x.reshape(P, 2, n, 256).contiguous()
         o = torch.empty(P, 2, n, 256, device=self.device)
-        self.engine.transformer_device(P, n, xin.data_ptr(), o_ptr=o.data_ptr(), stage=1, stream=self._stream())
+        self._engine_for(P, n).transformer_device(P, n, xin.data_ptr(), o_ptr=o.data_ptr(), stage=1, stream=self._stream())
         return {"x": o.reshape(2 * P, n, 256)[:B].contiguous()}
 
     def ar(self, x1, x2, attention: bool = False):
         """GPTStereo.forward (3 self+cross layers + Combinator) (vap_main.py:287)."""
         torch = self._torch
+        if attention:
+            raise NotImplementedError("attention maps are never materialised by the fused attention block")
         B, n, _ = x1.shape
-        xin = torch.stack([x1, x2], dim=1).float().contiguous()
+        xin = torch.stack([x1, x2], dim=1).to(self.device).float().contiguous()
         x12 = torch.empty(B, 2, n, 256, device=self.device)
         comb = torch.empty(B, n, 256, device=self.device)
-        self.engine.transformer_device(B, n, xin.data_ptr(), x12_ptr=x12.data_ptr(), comb_ptr=comb.data_ptr(), stage=2,
+        self._engine_for(B, n).transformer_device(B, n, xin.data_ptr(), x12_ptr=x12.data_ptr(), comb_ptr=comb.data_ptr(), stage=2,
                                        stream=self._stream())
         return {"x": comb, "x1": x12[:, 0].contiguous(), "x2": x12[:, 1].contiguous()}
 
@@ -329,9 +649,10 @@ class VapGPT:
         torch = self._torch
         B, two, N = waveform.shape
         assert two == 2
-        eng = self.engine
-        if B > eng.max_batch:
-            raise _engine.VapxError(f"batch {B} exceeds max_batch {eng.max_batch}")
+        if not self._ctx_hint:
+            raise _engine.VapxError("forward(waveform) slides the model's own window: construct with context_frames= "
+                                    "(VapGPT.from_state_dicts takes context_len_sec)")
+        eng = self._engine_for(B, self._ctx_hint)
         for b in range(B):
             eng.reset_stream(b)
         hop = eng.hop
@@ -352,20 +673,61 @@ class VapGPT:
     def vap_head(self, t):
         """Linear(256, 256) + bias on any [..., 256] tensor (vap_main.py:131,290): the engine's fp32-MFMA GEMM."""
         torch = self._torch
-        x = t.float().contiguous()
+        x = t.to(self.device).float().contiguous()
         y = torch.empty_like(x)
-        self.engine._check(self.engine.lib.vapx_vap_head(self.engine._h, x.numel() // 256, x.data_ptr(), y.data_ptr(), self._stream() or None),
-                           "vapx_vap_head")
+        eng = self.engine
+        eng._check(eng.lib.vapx_vap_head(eng._h, x.numel() // 256, x.data_ptr(), y.data_ptr(), self._stream() or None), "vapx_vap_head")
         return y.as_subclass(_logits_cls())
 
     def va_classifier(self, t):
         """Linear(256, 1) + bias -> [..., 1] (vap_main.py:142,292-293); the caller applies the sigmoid."""
         torch = self._torch
-        x = t.float().contiguous()
+        x = t.to(self.device).float().contiguous()
         y = torch.empty(*x.shape[:-1], 1, device=x.device)
-        self.engine._check(self.engine.lib.vapx_va_classifier(self.engine._h, x.numel() // 256, x.data_ptr(), y.data_ptr(), self._stream() or None),
-                           "vapx_va_classifier")
+        eng = self.engine
+        eng._check(eng.lib.vapx_va_classifier(eng._h, x.numel() // 256, x.data_ptr(), y.data_ptr(), self._stream() or None), "vapx_va_classifier")
         return y
+
+    def _aux_head(self, which: int, nout: int, t):
+        torch = self._torch
+        x = t.to(self.device).float().contiguous()
+        y = torch.empty(*x.shape[:-1], nout, device=x.device)
+        eng = self.engine
+        eng._check(eng.lib.vapx_aux_head(eng._h, which, x.numel() // 256, x.data_ptr(), y.data_ptr(), self._stream() or None), "vapx_aux_head")
+        return y
+
+
+class VapGPT_bc(VapGPT):
+    """``vap_realtime/vap_models.py:157-244`` (and rvap/vap_bc/vap_bc_main.py:88-137): VapGPT + ``bc_head = Linear(256, 3)``; the
+    caller takes ``bc_head(out["x"]).softmax(-1)[:, -1, 1 | 2]`` (vap_realtime/model.py:197-200)."""
+
+    _MODE = "bc"
+
+    def vap_head(self, t):
+        raise _engine.VapxError("the bc program never applies vap_head (vap_realtime/model.py:196-214); its weights are not on the device")
+
+    def bc_head(self, t):
+        """Linear(256, 3) + bias on any [..., 256] tensor -> [..., 3] (before the softmax)."""
+        return self._aux_head(0, 3, t)
+
+
+class VapGPT_nod(VapGPT):
+    """``vap_realtime/vap_models.py:246-334`` (and rvap/vap_nod/vap_nod_main.py:88-138): VapGPT + ``nod_head = Linear(256, 4)`` +
+    ``bc_head = Linear(256, 1)``; the caller takes ``bc_head(out["x"]).sigmoid()[-1]`` — every row of the window, the reference's
+    quirk — and ``nod_head(out["x"]).softmax(-1)[:, -1, 1..3]`` (vap_realtime/model.py:217-224)."""
+
+    _MODE = "nod"
+
+    def vap_head(self, t):
+        raise _engine.VapxError("the nod program never applies vap_head (vap_realtime/model.py:215-240); its weights are not on the device")
+
+    def bc_head(self, t):
+        """Linear(256, 1) + bias -> [..., 1] (before the sigmoid)."""
+        return self._aux_head(0, 1, t)
+
+    def nod_head(self, t):
+        """Linear(256, 4) + bias -> [..., 4] (before the softmax)."""
+        return self._aux_head(1, 4, t)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -386,7 +748,7 @@ class VAPRealTimeStatic:
         if device is not None and str(device).startswith("cpu"):
             raise _engine.VapxError("vap-realtime_amd has no CPU path; pass a cuda device (MI355X)")
         dev_id = int(device.index) if device is not None and getattr(device, "index", None) is not None else 0
-        self.vap_gpt = VapGPT(cpc_sd, vap_sd, frame_rate, context_len_sec, max_batch=max_batch, device_id=dev_id)
+        self.vap_gpt = VapGPT.from_state_dicts(cpc_sd, vap_sd, frame_rate, context_len_sec, max_batch=max_batch, mode="vap", device_id=dev_id)
         self.device = torch.device("cuda", dev_id)
         self.frame_rate = frame_rate
         self.audio_contenxt_lim_sec = context_len_sec

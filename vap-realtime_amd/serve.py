@@ -43,7 +43,7 @@ def build(args):
             engines.append(eng)
             passive = n > 1
             cores = None
-            if not args.no_pin:                  # tick / receive / sender threads next to their GPU, every shard on cores of its own
+            if args.pin:                  # tick / receive / sender threads next to their GPU, every shard on cores of its own
                 node_key = tuple(dist_util.gpu_node_cores(dev)[:1])
                 nthr = 1 + args.rx_threads + args.tx_threads
                 cores, _ = dist_util.front_end_placement(dev, nthr, skip=taken.get(node_key, 0))
@@ -91,7 +91,7 @@ def main(argv=None) -> int:
     ap.add_argument("--rx_threads", type=int, default=4)
     ap.add_argument("--tx_threads", type=int, default=4)
     ap.add_argument("--bind_any", action="store_true", help="listen on 0.0.0.0 instead of 127.0.0.1")
-    ap.add_argument("--pin", dest="no_pin", action="store_false", default=True,
+    ap.add_argument("--pin", dest="pin", action="store_true",
                     help="pin every shard's tick / receive / sender threads to consecutive cores at the top of its GPU's NUMA node (default: the "
                          "scheduler places them).  Worth it on a host you own — keep everything else off those cores; on a shared host it measured "
                          "no better than floating threads (profiles/r05_frontend/README.md)")
