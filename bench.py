@@ -59,69 +59,7 @@ KERNEL_NAMES = {"ffn_block": "ffn_block_kernel", "ffn_proj": "ffn_block_kernel<.
                 "last_row": "last_block_kernel", "lstm": "lstm_kernel", "head": "head_kernel", "conv0": "conv0_kernel"}
 
 
-def model_macs(hz: int, T: int, mode: str = "vap", leader: bool = True, qkv_in_attention: bool = False) -> dict:
-    """EXECUTED multiply-accumulates per stream-frame (both channels) by kernel class for ONE weight set of the default path.
-    vap / bc: exact last-layer pruning, absorbed last-layer K/V projections, cached layer-0 Q|K|V.  nod emits p_bc for every
-    window row (vap_nod_main.py:276), so it runs the FULL last layer and the Combinator on all rows.  leader = False: a trunk
-    follower (shares the leader's CPC CNN + LSTM, runs only its own downsample).  The attention classes count the DENSE T x T
-    products like SURVEY.md does (the kernels skip most of the causally masked tiles, see `attention_executed_fraction`).
-    qkv_in_attention (split path, long windows): the self-attention Q|K|V projections of the layers after layer 0 run inside the attention
-    kernel (csrc/attention_proj_f16x3.hip) instead of the previous layer's flat-row block — the same MACs, booked under "attention"."""
-    hop = 16000 // hz
-    L = hop + 320
-    P0 = L // 5; P1 = P0 // 4; P2 = P1 // 2; P3 = P2 // 2; P4 = P3 // 2; ncpc = P4 - 2
-    D = 256
-    rows = 2 * T
-    fused = T <= 64          # fused attention block (attention + projection + LN + cross-q) vs attention_long2_kernel + flat-row blocks
-    full = mode == "nod"
-    n_ffn = 4 if full else 3                       # FFN blocks executed on all rows
-    n_next = 3 if full else 2                      # next-layer Q|K|V + cross K|V emitted by an FFN block
-    n_attn = 7 if full else 5                      # attention blocks on all rows (l0 self, l1.. self + cross)
-    n_proj = n_attn + (3 if full else 2)           # attention output projections + cross-attention query projections
-    attn = n_attn * 2 * 4 * (T * T * 64 * 2)
-    moved = rows * D * n_next * 768 if (qkv_in_attention and not fused) else 0
-    m = {
-        "conv0": 2 * P0 * D * 10 if leader else 0,
-        "gemm_cn_relu": 2 * (P1 * 8 + P2 * 4 + P3 * 4 + ncpc * 4) * D * D if leader else 0,
-        "lstm": (2 * ncpc * D * 4 * D + 2 * ncpc * D * D) if leader else 0,    # recurrence (K=256) + fused downsample
-        # follower: its own downsample GEMM; nod: Combinator on all rows (two [T x 256 x 256] per stream)
-        "gemm_bias_ln_gelu": (0 if leader else 2 * ncpc * D * D) + (2 * T * D * D if full else 0),
-        # LSTM input projection (leader) + layer-0 QKV of the NEW row (others cached)
-        "gemm_store": (2 * ncpc * D * 4 * D if leader else 0) + 2 * D * 768,
-        "gemm_resid_ln": 0,
-        # FFN + next layer's QKV / cross-KV (last pruned layer: absorbed); long windows: + the attention output projections and
-        # the cross-attention query projections, which ride in the same flat-row blocks (fused_blocks.hip, modes 1 / 2)
-        # (mode 1: one pre-projection per FFN block).  The mode-2 launches — attention output projection + LN_src + cross-attention query,
-        # two per stereo layer executed on all rows — are a class of their own ("ffn_proj": csrc/engine.hip CLS_FFN_PROJ)
-        "ffn_block": rows * D * (n_ffn * 2 * 768 + n_next * (768 + 512) + (0 if fused else n_ffn * D)) - moved,
-        "ffn_proj": 0 if fused else rows * D * (n_proj - n_ffn) * D,
-        # pruned layer 3 on one row per channel: 14 contractions (q, Wk^T q, Wv, proj, their cross twins, FFN) + two
-        # 4-head single-query attentions over T rows of 256 (score + weighted sum)
-        "last_row": 0 if full else 2 * (14 * D * D + 2 * 4 * T * D * 2),
-        "gemm_gelu": 0, "gemm_resid": 0,
-        # dense T x T attention (+ in the fused block: output projections, cross-q projections)
-        "attention": attn + (rows * n_proj * D * D if fused else 0) + moved,
-        "head": 3 * D * D + 2 * D,
-        "gather_ln": 0,
-    }
-    return m
-
-
-def macs_per_stream_frame(hz: int, T: int, mode: str = "vap", qkv_in_attention: bool = False) -> dict:
-    """Sum of `model_macs` over the weight sets of `mode` ("bc+nod": the first leads the shared CPC trunk)."""
-    tot = {}
-    for k, md in enumerate(mode.split("+")):
-        for c, v in model_macs(hz, T, md, leader=(k == 0), qkv_in_attention=qkv_in_attention).items():
-            tot[c] = tot.get(c, 0) + v
-    return tot
-
-
-def attention_executed_fraction(T: int) -> float:
-    """Share of the dense T x T score / PV products the attention kernels execute: 32-row tiles, causal tiles jt <= it only."""
-    nt = (T + 31) // 32
-    if T <= 64:
-        return 1.0 if nt == 1 else 0.75       # fused block: 64 x 64 scores, tile (0,1) skipped
-    return (nt * (nt + 1) / 2) / (nt * nt)
+from vap_realtime_amd.capacity import attention_executed_fraction, macs_per_stream_frame, model_macs  # noqa: E402  (the work model lives in the package: serve.py plans with it)
 
 
 def front_door_plumbing_check(n_shards: int, per_shard: int = 2) -> dict:
@@ -405,11 +343,23 @@ def load_traffic(key: str, dominant: str):
     run).  The class mean covers exactly the launches the class's HIP-event time covers."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            tick = json.load(f).get(key, {}).get("_tick")
+            entry = json.load(f).get(key, {})
+        tick = entry.get("_tick")
         c = tick["by_class"].get(dominant)
-        return (c["bytes_corrected"] / c["launches"] if c else None), tick["bytes_corrected"]
+        return (c["bytes_corrected"] / c["launches"] if c else None), tick["bytes_corrected"], traffic_source(entry)
     except Exception:
-        return None, None
+        return None, None, traffic_source(None)
+
+
+def traffic_source(entry):
+    """Provenance of `roofline.traffic` / `tick_traffic`: they are NOT measured by this run (counters cannot be collected inside a timed
+    run) but read from the committed PMC passes.  `stale` says whether the kernels timed here are the sources those passes ran on
+    (content hash of vap-realtime_amd/csrc: the GPU box has no .git); `git` is the commit the passes were taken at."""
+    from vap_realtime_amd import provenance
+    src = (entry or {}).get("_source") or {}
+    now = provenance.kernel_source_hash()
+    return {"file": "profiles/pmc_traffic.json", "git": src.get("git"), "csrc_sha": src.get("csrc_sha"), "csrc_sha_now": now,
+            "stale": (src.get("csrc_sha") != now) if entry else None}
 
 
 class BoardWatch:
@@ -517,16 +467,26 @@ def run_workload(name, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=0, split
     barrier()
     wl.profile_read()
     watch = BoardWatch(local_rank)
+    # one HIP event per tick boundary, recorded on the launch stream inside the timed region: the spread of the K ticks rides in the record
+    # (the driver times ONE number over 20 ticks; boards differ by 7 %: a +-2 % code change is invisible without it)
+    tick_ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    tstream = torch.cuda.current_stream()
     with watch:
         t0 = time.perf_counter()
+        tick_ev[0].record(tstream)
         for i in range(steps):
             wl.step(i, defer_join=defer_join)
+            tick_ev[i + 1].record(tstream)
         if defer_join:
             wl.eng.join(wl.stream)
         torch.cuda.synchronize()
         dt_own = time.perf_counter() - t0                          # this rank's own K steps (reported per rank; `value` uses the max below)
     barrier()
     dt = time.perf_counter() - t0
+    tick_ms = sorted(tick_ev[i].elapsed_time(tick_ev[i + 1]) for i in range(steps))
+    tick_stats = {"min": tick_ms[0], "median": tick_ms[len(tick_ms) // 2], "p95": tick_ms[min(len(tick_ms) - 1, int(round(0.95 * (len(tick_ms) - 1))))],
+                  "max": tick_ms[-1], "n": steps,
+                  "note": "this rank's ticks, HIP events on the launch stream between consecutive steps" + (" (deferred join: overlap groups free-run, a tick's event marks its leading group)" if defer_join else "")}
 
     dom_ms, dom_launches = wl.profile_read()[dominant]
     wl.profile_enable([])
@@ -561,11 +521,11 @@ def run_workload(name, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=0, split
         kernel = "attention_long_f16x3_kernel + attention_proj_f16x3_kernel" if split_f16 else "attention_long2_kernel"
     if dominant == "ffn_block" and split_f16:
         kernel = "ffn_block_f16x3_kernel"
-    class_traffic, tick_traffic = load_traffic(f"{S}x{hz}hz_T{T}" + ("" if mode == "vap" else "_" + mode) + ("_split_f16" if split_f16 else ""), dominant)
+    class_traffic, tick_traffic, traffic_src = load_traffic(f"{S}x{hz}hz_T{T}" + ("" if mode == "vap" else "_" + mode) + ("_split_f16" if split_f16 else ""), dominant)
     roof = {"bound": "mfma", "kernel": kernel, "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tf / peak,
             # achieved, avg_launch_us, gflop_per_launch and traffic all describe the SAME launches: the `launches_per_step` launches of the
             # dominant class per tick (long windows: the mode-1 flat-row blocks; the mode-2 blocks are the class "ffn_proj")
-            "traffic": class_traffic,
+            "traffic": class_traffic, "traffic_source": traffic_src,
             "avg_launch_us": avg_launch_s * 1e6, "launches_per_step": launches_per_step, "gflop_per_launch": flop_per_launch / 1e9,
             "flop_count": "algorithmic FLOPs of the launch (dense T x T for attention), MACs x 2"}
     ab = ALGO_BYTES_PER_STREAM_FRAME.get((hz, T))
@@ -587,7 +547,7 @@ def run_workload(name, S, hz, ctx_sec, mode, steps, warmup, ctx, groups=0, split
         roof["frac_at_sclk"] = roof["frac"] * NOMINAL_SCLK_MHZ / board["sclk_mhz_median"]
     rec = {
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
-        "timed_seconds": dt,
+        "timed_seconds": dt, "ms_per_step_spread": tick_stats,
         "config": {"workload": f"{name}: {S} concurrent synthetic stereo streams per GPU, {ctx_sec} s / {hz} Hz (T={T}), mode {mode}, 1 MI355X per rank",
                    "streams_per_gpu": S, "streams_total": S * world, "frame_hz": hz, "ctx_frames": T, "mode": mode,
                    "gemm_arithmetic": ("f16x3 split products, fp32 accumulate" if split_f16 else "fp32 MFMA"),
@@ -871,6 +831,10 @@ def compact_line(result: dict, full_path: str = "") -> str:
     line = {
         "metric": result["metric"], "value": _r(result["value"], 7), "unit": result["unit"], "n_gpus": result["n_gpus"], "steps": result["steps"],
         "warmup": result["warmup"], "ms_per_step": _r(result["ms_per_step"], 6), "timed_seconds": _r(result.get("timed_seconds"), 5),
+        # spread of the K timed ticks (HIP events between consecutive steps on the launch stream): the one driver-timed number's error bar
+        "ms_per_step_min": _r((result.get("ms_per_step_spread") or {}).get("min"), 5),
+        "ms_per_step_median": _r((result.get("ms_per_step_spread") or {}).get("median"), 5),
+        "ms_per_step_p95": _r((result.get("ms_per_step_spread") or {}).get("p95"), 5),
         "higher_is_better": True, "scaling": result.get("scaling", "weak"), "vs_baseline": result.get("vs_baseline"), "dtype": result["dtype"],
         "data": "synthetic (seeded dialogue audio + seeded random weights)",
         "config": {"workload": cfg["workload"], "streams_per_gpu": cfg["streams_per_gpu"], "streams_total": cfg["streams_total"],
@@ -880,7 +844,10 @@ def compact_line(result: dict, full_path: str = "") -> str:
         "roofline": {"bound": roof["bound"], "kernel": roof["kernel"], "achieved": _r(roof["achieved"]), "peak": _r(roof["peak"]),
                      "unit": roof["unit"], "frac": _r(roof["frac"], 4), "traffic": _r(roof.get("traffic")), "avg_launch_us": _r(roof["avg_launch_us"]),
                      "launches_per_step": _r(roof["launches_per_step"], 3), "traffic_ratio": _r(roof.get("traffic_ratio"), 3),
-                     "frac_at_sclk": _r(roof.get("frac_at_sclk"), 4)},
+                     "frac_at_sclk": _r(roof.get("frac_at_sclk"), 4),
+                     # traffic / traffic_ratio come from the committed PMC passes, not from this run: which tree they were taken at, and
+                     # whether the kernels timed here are that tree's (content hash of vap-realtime_amd/csrc)
+                     "traffic_source": {k: (roof.get("traffic_source") or {}).get(k) for k in ("file", "git", "csrc_sha", "stale")}},
     }
     if "executed_frac_of_fp32_mfma_peak" in result:
         line["executed_tflops"] = _r(result["executed_tflops"], 4)

@@ -448,13 +448,14 @@ def test_library_twin_vap_class_with_microphone_sources(tmp_path):
     vap._stop_worker = True
 
 
-@pytest.mark.parametrize("gpus,precision", [(1, "fp32"), (2, "fp32"), (1, "split")], ids=["1", "2", "1-split"])
+@pytest.mark.parametrize("gpus,precision", [(1, "fp32"), (2, "fp32"), (1, "split"), (1, "auto")], ids=["1", "2", "1-split", "1-auto"])
 def test_serve_program_end_to_end(gpus, precision):
     """``python -m vap_realtime_amd.serve`` — the twin of ``python vap_main.py --vap_model ... --port_num_in ... --gpu`` (vap_main.py:461-530)
     for many dialogues: started as a subprocess with the reference's argument names, fed the golden audio over TCP, answers compared
     with the golden of the imported reference; SIGTERM stops it.  gpus = 2: two engines (both on this box's one GPU, ``--share-gpu``)
     behind ONE port pair — the front door sends dialogue k to engine k mod 2, every dialogue still gets its own golden numbers.
-    ``--precision split``: the served engine runs the opt-in split-precision path (dedicated GPU), same golden, same tolerance."""
+    ``--precision split``: the served engine runs the opt-in split-precision path (dedicated GPU), same golden, same tolerance.
+    ``--precision auto`` (the default): 4 dialogues of the 20 Hz model are far below the fp32 path's capacity — it must pick fp32 and say so."""
     import os
     import re
     import signal
@@ -469,11 +470,15 @@ def test_serve_program_end_to_end(gpus, precision):
                             + (["--gpus", str(gpus), "--share-gpu"] if gpus > 1 else []) + ["--precision", precision],
                             cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     try:
-        line = ""
+        line, seen = "", []
         t0 = time.time()
         while "input :" not in line and time.time() - t0 < 180:
             line = proc.stdout.readline()
+            seen.append(line)
             assert line or proc.poll() is None, "serve exited early"
+        if precision == "auto":
+            assert any("--precision auto -> fp32" in l for l in seen), seen
+            assert "fp32 arithmetic" in line
         pin, pout = (int(x) for x in re.search(r"input :(\d+), output :(\d+)", line).groups())
         S = len(c.streams)
         ins, outs = [], []

@@ -104,8 +104,8 @@ def test_roofline_bookkeeping_describes_one_set_of_launches():
         assert m["ffn_block"] == 2 * T * D * (n_ffn * 2 * 768 + (n_ffn - 1) * (768 + 512) + n_ffn * D)
     assert bench.model_macs(20, 50, "vap")["ffn_proj"] == 0      # short windows: the projections ride in the fused attention block
     # the C3 tick of the committed PMC passes: class means and the tick total
-    cls, tick = bench.load_traffic("4096x50hz_T250", "ffn_block")
-    cls2, _ = bench.load_traffic("4096x50hz_T250", "ffn_proj")
+    cls, tick, _src = bench.load_traffic("4096x50hz_T250", "ffn_block")
+    cls2, _, _ = bench.load_traffic("4096x50hz_T250", "ffn_proj")
     assert 15e9 < cls < 25e9 and 6e9 < cls2 < 10e9 and 100e9 < tick < 160e9
     ratio = tick / (bench.ALGO_BYTES_PER_STREAM_FRAME[(50, 250)] * 4096)
     assert 40 < ratio < 80
@@ -127,6 +127,32 @@ def test_roofline_bookkeeping_describes_one_set_of_launches():
     if "split_f16" in line and "value" in line["split_f16"]:
         assert line["split_f16"]["watts"] == 1372.0 and line["split_f16"]["sclk_mhz"] == 1957.0
     assert len(json.dumps(line)) < 4096
+
+
+def test_the_timed_number_carries_its_spread_and_the_traffic_its_provenance():
+    """(a) `roofline.traffic*` are read from committed PMC passes — the line must say which tree those were taken at and
+    whether the kernels timed now are that tree's; (b) the one driver-timed number rests on K ticks — their min / median / p95 ride along."""
+    from vap_realtime_amd import provenance
+    now = provenance.kernel_source_hash()
+    assert len(now) == 16 and now == provenance.kernel_source_hash()
+    committed = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    for key, entry in committed.items():                         # every workload's passes name their tree
+        if not key.startswith("_"):
+            assert entry.get("_source", {}).get("csrc_sha") and entry["_source"].get("git"), f"{key}: PMC passes without provenance stamp"
+    _, _, src = bench.load_traffic("4096x50hz_T250", "ffn_block")
+    assert src["file"] == "profiles/pmc_traffic.json" and src["csrc_sha_now"] == now and src["git"]
+    assert src["stale"] == (src["csrc_sha"] != now) and isinstance(src["stale"], bool)
+    _, _, none = bench.load_traffic("no such workload", "ffn_block")
+    assert none["stale"] is None and none["csrc_sha"] is None    # no passes at all is not "fresh"
+    full = canned()
+    full["roofline"]["traffic_source"] = src
+    full["ms_per_step_spread"] = {"min": 93.1234567, "median": 94.5, "p95": 96.25, "max": 97.0, "n": 20}
+    line = strict(bench.compact_line(full))
+    assert line["roofline"]["traffic_source"] == {"file": src["file"], "git": src["git"], "csrc_sha": src["csrc_sha"], "stale": src["stale"]}
+    assert (line["ms_per_step_min"], line["ms_per_step_median"], line["ms_per_step_p95"]) == (93.123, 94.5, 96.25)
+    assert len(json.dumps(line)) < 4096
+    text = open(os.path.join(ROOT, "bench.py")).read()
+    assert "tick_ev[i + 1].record(tstream)" in text and '"traffic_source": traffic_src' in text     # measured inside the timed region / stamped per record
 
 
 def test_bench_main_prints_only_the_compact_line():

@@ -196,3 +196,33 @@ def test_bench_flop_accounting_matches_the_survey_counts():
         ex = 2.0 * sum(bench.macs_per_stream_frame(hz, T).values()) / 1e9
         assert 0.65 * dense < ex < 0.80 * dense, (hz, T, ex, dense)
     assert bench.attention_executed_fraction(250) == 36 / 64 and bench.attention_executed_fraction(50) == 0.75
+
+
+def test_serving_precision_plan_follows_the_measured_rates():
+    """``serve --precision auto`` = ``capacity.plan``.  Row (g) of the scope table at the benchmark's own loads: 4096 dialogues of
+    the 20 Hz / 2.5 s model fit the fp32 path; C5 (bc + nod on one trunk) needs the split path; C3 (50 Hz / 5 s) fits neither at 4096 and
+    the plan says what does fit."""
+    from vap_realtime_amd import capacity as C
+    p = C.plan(4096, 20, 2.5, "vap")
+    assert p["precision"] == "fp32" and p["ok"] and 0.4 < p["fp32"]["busy"] < 0.55
+    p = C.plan(4096, 20, 2.5, "bc+nod")
+    assert p["precision"] == "split" and p["ok"] and p["fp32"]["busy"] > 0.85 and p["split"]["busy"] < 0.6 and "fp32 path would be" in p["reason"]
+    assert 2800 <= p["fp32"]["max_streams"] <= 4000          # bench.py's paced search accepted 2856-3072 (p99 <= 9 ms AND <= 85 % busy)
+    p = C.plan(4096, 50, 5.0, "vap")
+    assert not p["ok"] and p["precision"] == "split" and "NEITHER" in p["reason"]
+    assert 500 <= p["fp32"]["max_streams"] <= 800 and 1200 <= p["split"]["max_streams"] <= 1800      # measured: 520-576 / 1216-1296
+    assert C.plan(500, 50, 5.0, "vap")["precision"] == "fp32" and C.plan(1200, 50, 5.0, "vap")["precision"] == "split"
+    # the work model is the one bench.py prices its roofline with (one definition)
+    import bench
+    assert bench.model_macs is C.model_macs and bench.macs_per_stream_frame is C.macs_per_stream_frame
+    assert C.executed_gflop_per_stream_frame(50, 250, "vap") == pytest.approx(2.763, rel=2e-3)      # VERDICT r5: 119.2 TF / 43 146 frames/s
+    assert C.executed_gflop_per_stream_frame(20, 50, "vap") == pytest.approx(0.671, rel=2e-2)       # DESIGN section 4
+
+
+def test_serve_auto_refuses_a_load_no_path_can_hold(capsys):
+    """No GPU is touched: the plan is made before any engine exists.  4096 dialogues of the 50 Hz / 5 s model per GPU: start-up fails loudly."""
+    from vap_realtime_amd import serve
+    rc = serve.main(["--synthetic-weights", "0", "--streams", "4096", "--vap_process_rate", "50", "--context_len_sec", "5.0", "--port_num_in", "0",
+                     "--port_num_out", "0"])
+    err = capsys.readouterr().err
+    assert rc == 1 and "NEITHER path holds" in err and "--allow-overload" in err

@@ -13,6 +13,7 @@ RAW=/tmp/prof_raw_$$
 mkdir -p $OUT $RAW
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --workload $WL --configs= --no-latency --no-cpu-baseline --paced-sec 0 --steps $STEPS --warmup 1 $EXTRA"
+python -c "import sys; sys.path.insert(0, '$REPO'); from vap_realtime_amd import provenance as p; import json; print(json.dumps({'csrc_sha': p.kernel_source_hash()}))" > $OUT/source.json
 $BENCH > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -f csv -d $RAW/stats -o run -- $BENCH > $OUT/stats.log 2>&1
 cp $(find $RAW/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null

@@ -80,6 +80,13 @@ for wl in wls:
         for sub, cls in CLASS:
             if sub in name and cls not in entry:
                 entry[cls] = rec
+    sj = os.path.join(src, "source.json")
+    if entry and os.path.exists(sj):       # the tree the passes ran on (hash taken ON the box) + the commit it belongs to, if HEAD still has those sources
+        sys.path.insert(0, ROOT)
+        from vap_realtime_amd import provenance
+        sha = json.load(open(sj))["csrc_sha"]
+        head = provenance.git_head(ROOT)
+        entry["_source"] = {"csrc_sha": sha, "git": (head if provenance.kernel_source_hash_at("HEAD", ROOT) == sha else f"{head}+uncommitted"), "tag": tag}
     if entry:
         traffic[KEY[wl.replace("_split", "")] + ("_split_f16" if wl.endswith("_split") else "")] = entry
 json.dump(traffic, open(traffic_path, "w"), indent=1)

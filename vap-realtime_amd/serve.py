@@ -4,8 +4,10 @@ MANY GPUs behind the reference's ONE port pair.  One process: one engine per GPU
 front-end per engine (its own receive / tick / send threads, ``vapx_ingest_*``), and one front door (``vapx_frontdoor_*``) that owns
 ``port_num_in`` / ``port_num_out`` and hands every accepted connection to a GPU.  Dialogue k lands on GPU ``k mod N`` (lowest free global slot) and
 stays there — its state lives there; there is no collective.  Same argument names as the reference plus ``--streams`` (slots per GPU), ``--gpus``,
-``--mode`` and ``--precision {fp32,split}`` (``split`` = the opt-in split-precision engine for a dedicated node: C5 at >= 4096 streams per GPU
-within 10 ms needs it).
+``--mode`` and ``--precision {auto,fp32,split}``.  ``auto`` (default) serves the arithmetic the load needs: fp32 — the reference's — while
+``streams x frame rate`` keeps one GPU's fp32 path <= 85 % busy, the fp32-accurate split-precision engine beyond that, and it says so; when
+NEITHER path holds the 10 ms bound at the requested ``--streams`` it refuses to start (``--allow-overload`` downgrades that to a warning).  The
+rule and its measured rates: ``capacity.plan`` / DESIGN.md §5.
 
     python -m vap_realtime_amd.serve --vap_model asset/vap/vap_state_dict_jp_20hz_2500msec.pt --cpc_model asset/cpc/60k_epoch4-d0f474de.pt \\
         --streams 4096 --gpus 8
@@ -31,6 +33,17 @@ def build(args):
     else:
         blob, hz, mode = checkpoints.import_checkpoints(args.vap_model, args.cpc_model, frame_rate=args.vap_process_rate, mode=args.mode)
     n = max(1, args.gpus)
+    args.precision_plan = None
+    if args.precision == "auto":                 # serve the arithmetic the load needs (capacity.plan: measured sustained rate per path)
+        from . import capacity
+        pl = capacity.plan(args.streams, args.vap_process_rate, args.context_len_sec, mode)
+        args.precision_plan = pl
+        print(f"[vapx] --precision auto -> {pl['precision']}: {pl['reason']}", file=sys.stderr, flush=True)
+        if not pl["ok"]:
+            if not args.allow_overload:
+                raise RuntimeError(pl["reason"] + " (start anyway with --allow-overload, or name a --precision)")
+            print("[vapx] WARNING: starting overloaded (--allow-overload): frames WILL be answered later than 10 ms at full occupancy", file=sys.stderr, flush=True)
+        args.precision = pl["precision"]
     engines, shards, door = [], [], None
     taken = {}                                   # cores of a NUMA node's run already given to an earlier shard's front-end
     try:
@@ -82,8 +95,11 @@ def main(argv=None) -> int:
     ap.add_argument("--streams", type=int, default=1, help="dialogue slots per GPU (the reference serves exactly one)")
     ap.add_argument("--max_batch", type=int, default=1024)
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--precision", choices=["fp32", "split"], default="fp32",
-                    help="fp32: every contraction on the fp32 MFMA (default; safe next to other tenants).  split: VAPX_FLAG_SPLIT_F16 — the same "
+    ap.add_argument("--allow-overload", dest="allow_overload", action="store_true",
+                    help="with --precision auto: start even when no arithmetic path holds <= 10 ms per frame at --streams dialogues per GPU")
+    ap.add_argument("--precision", choices=["auto", "fp32", "split"], default="auto",
+                    help="auto (default): fp32 while --streams x rate keeps the fp32 path <= 85 %% busy, else split, refusing loads neither path holds "
+                         "within 10 ms (capacity.plan; the choice is printed).  fp32: every contraction on the fp32 MFMA (safe next to other tenants).  split: VAPX_FLAG_SPLIT_F16 — the same "
                          "contractions as fp32-accurate 3-term f16 split products, ~2x the streams per GPU at the same <= 1e-4 parity; for a "
                          "DEDICATED GPU/node (a process that issues f16 MFMAs all day can disturb co-running tenants: DESIGN.md \"co-running f16 MFMA\")")
     ap.add_argument("--share-gpu", dest="share_gpu", action="store_true", help="plumbing check on a 1-GPU box: every shard's engine on device 0")
