@@ -355,6 +355,20 @@ void vapx_ingest_close(vapx_ingest_handle g);
 typedef struct vapx_frontdoor* vapx_frontdoor_handle;
 int vapx_frontdoor_open(vapx_ingest_handle* shards, int32_t n_shards, int32_t port_in, int32_t port_out, int32_t bind_any,
                         vapx_frontdoor_handle* out);
+/* The same door with every shard in a process OF ITS OWN (one process per GPU: the process that owns the engine also owns its front-end's
+ * threads and descriptors - a container's RLIMIT_NOFILE of 20 000 holds ~9 800 dialogues, BASELINE config 4 has 32 768).  Door and worker are
+ * joined by one AF_UNIX / SOCK_SEQPACKET socket pair (`link`), created by whoever starts the workers:
+ *   worker process:  vapx_create, vapx_ingest_open (passive: port_in = port_out = -1), vapx_ingest_attach_link(front_end, its end of the link)
+ *   door process:    vapx_frontdoor_open_links(the other ends, n, port_in, port_out, ...) - it waits for every worker's greeting (slots, frame
+ *                    rate, mode), then owns the reference's ONE port pair (vap_main.py:338-366,470-471)
+ * The door keeps a mirror of every shard's slot / listener occupancy and is the only allocator: it names the slot, passes the accepted socket to
+ * the worker (SCM_RIGHTS) and closes its own copy; workers report released slots and dropped listeners back over the link.  Placement is the
+ * in-process door's: lowest free global slot g = local_slot * N + shard for inputs, fewest listeners / lowest global slot for outputs.  A worker
+ * that dies takes its dialogues with it and receives no new ones; the others keep serving.  The link descriptors stay the caller's: close them
+ * after vapx_frontdoor_close / vapx_ingest_close. */
+int vapx_ingest_attach_link(vapx_ingest_handle g, int32_t link_fd);
+int vapx_frontdoor_open_links(const int32_t* link_fds, int32_t n_links, int32_t port_in, int32_t port_out, int32_t bind_any,
+                              vapx_frontdoor_handle* out);
 int vapx_frontdoor_ports(vapx_frontdoor_handle d, int32_t* port_in, int32_t* port_out);
 int vapx_frontdoor_counts(vapx_frontdoor_handle d, int64_t* accepted_in, int64_t* accepted_out, int64_t* refused);
 void vapx_frontdoor_close(vapx_frontdoor_handle d);

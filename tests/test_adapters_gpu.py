@@ -448,14 +448,19 @@ def test_library_twin_vap_class_with_microphone_sources(tmp_path):
     vap._stop_worker = True
 
 
-@pytest.mark.parametrize("gpus,precision", [(1, "fp32"), (2, "fp32"), (1, "split"), (1, "auto")], ids=["1", "2", "1-split", "1-auto"])
+@pytest.mark.parametrize("gpus,precision", [(1, "fp32"), (2, "fp32"), (1, "split"), (1, "auto"), (2, "procs")], ids=["1", "2", "1-split", "1-auto", "2-procs"])
 def test_serve_program_end_to_end(gpus, precision):
     """``python -m vap_realtime_amd.serve`` — the twin of ``python vap_main.py --vap_model ... --port_num_in ... --gpu`` (vap_main.py:461-530)
     for many dialogues: started as a subprocess with the reference's argument names, fed the golden audio over TCP, answers compared
     with the golden of the imported reference; SIGTERM stops it.  gpus = 2: two engines (both on this box's one GPU, ``--share-gpu``)
     behind ONE port pair — the front door sends dialogue k to engine k mod 2, every dialogue still gets its own golden numbers.
     ``--precision split``: the served engine runs the opt-in split-precision path (dedicated GPU), same golden, same tolerance.
-    ``--precision auto`` (the default): 4 dialogues of the 20 Hz model are far below the fp32 path's capacity — it must pick fp32 and say so."""
+    ``--precision auto`` (the default): 4 dialogues of the 20 Hz model are far below the fp32 path's capacity — it must pick fp32 and say so.
+    ``2-procs``: ``--worker-procs on`` — the front door is a process of its own, each "GPU" a worker process that receives its connections over
+    a unix-socket link (vapx_frontdoor_open_links); same ports, same placement, same golden numbers."""
+    worker_procs = precision == "procs"
+    if worker_procs:
+        precision = "fp32"
     import os
     import re
     import signal
@@ -467,7 +472,8 @@ def test_serve_program_end_to_end(gpus, precision):
     proc = subprocess.Popen([sys.executable, "-u", "-m", "vap_realtime_amd.serve", "--synthetic-weights", str(c.seed), "--streams", "4",
                              "--port_num_in", "0", "--port_num_out", "0", "--vap_process_rate", str(c.frame_hz),
                              "--context_len_sec", str(c.ctx_sec), "--gpu", "--stats_sec", "0"]
-                            + (["--gpus", str(gpus), "--share-gpu"] if gpus > 1 else []) + ["--precision", precision],
+                            + (["--gpus", str(gpus), "--share-gpu"] if gpus > 1 else []) + ["--precision", precision]
+                            + (["--worker-procs", "on"] if worker_procs else ["--worker-procs", "off"]),
                             cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     try:
         line, seen = "", []
@@ -479,6 +485,7 @@ def test_serve_program_end_to_end(gpus, precision):
         if precision == "auto":
             assert any("--precision auto -> fp32" in l for l in seen), seen
             assert "fp32 arithmetic" in line
+        assert ("worker processes" in line) == worker_procs
         pin, pout = (int(x) for x in re.search(r"input :(\d+), output :(\d+)", line).groups())
         S = len(c.streams)
         ins, outs = [], []

@@ -472,7 +472,29 @@ class TaggedModel(Model):
         return rc
 
 
-def test_one_front_door_routes_dialogues_over_two_back_ends_and_reconnects_stick():
+def _open_door(shards, kind):
+    """The in-process front door, or the multi-process one (vapx_frontdoor_open_links) with its shards linked over AF_UNIX socket pairs — here
+    inside one process: the protocol does not care where the two ends live (tests/test_server.py runs it across real processes)."""
+    if kind == "in-process":
+        return ingest.FrontDoor(shards, port_in=0, port_out=0), []
+    pairs = [ingest.link_pair() for _ in shards]
+    for s_, (_, w) in zip(shards, pairs):
+        s_.attach_link(w.fileno())
+    door = ingest.RemoteFrontDoor([d for d, _ in pairs], port_in=0, port_out=0)
+    return door, pairs
+
+
+def _close_door(door, shards, kind):
+    if kind == "in-process":
+        door.close()
+    else:
+        door.close()
+        for s_ in shards:
+            s_.close()
+
+
+@pytest.mark.parametrize("kind", ["in-process", "links"])
+def test_one_front_door_routes_dialogues_over_two_back_ends_and_reconnects_stick(kind):
     """vapx_frontdoor_*: ONE port pair (the reference's, vap_main.py:338-366) in front of two passive front-ends (= two GPUs).  Dialogue k
     takes the lowest free GLOBAL slot g = local * N + shard, i.e. shard k mod 2; the k-th output connection hears the k-th dialogue; a
     dialogue that drops and reconnects gets its old slot back (lowest free) — the shard that holds its state — and a full house refuses."""
@@ -480,7 +502,7 @@ def test_one_front_door_routes_dialogues_over_two_back_ends_and_reconnects_stick
     models = [TaggedModel(10.0), TaggedModel(20.0)]
     shards = [ingest.NativeServer.over_function(m.step, 2, 20, reset=m.reset, max_wait_s=0.05, port_in=-1, port_out=-1) for m in models]
     assert all(s.port_in == 0 and s.port_out == 0 for s in shards)         # passive: listening on nothing
-    door = ingest.FrontDoor(shards, port_in=0, port_out=0)
+    door, _pairs = _open_door(shards, kind)
     try:
         ins, outs = [], []
         for k in range(4):                                                  # connect one by one: arrival order = dialogue index
@@ -525,17 +547,64 @@ def test_one_front_door_routes_dialogues_over_two_back_ends_and_reconnects_stick
         assert sorted(models[1].resets) == [0, 0, 1] and sorted(models[0].resets) == [0, 1]     # reset_on_connect per (re)connection
         assert door.counts() == {"accepted_in": 5, "accepted_out": 4, "refused": 1}
     finally:
+        _close_door(door, shards, kind)
+
+
+def test_linked_door_follows_dropped_listeners_and_a_worker_that_goes_away():
+    """The multi-process door decides on MIRRORS of its shards: a listener the worker dropped must free its place in the mirror (the next
+    output connection goes to that dialogue), and a worker whose link closes gets no new dialogues while the others keep serving."""
+    hop = 800
+    models = [TaggedModel(10.0), TaggedModel(20.0)]
+    shards = [ingest.NativeServer.over_function(m.step, 2, 20, reset=m.reset, max_wait_s=0.02, port_in=-1, port_out=-1) for m in models]
+    door, pairs = _open_door(shards, "links")
+    try:
+        ins = []
+        for k in range(2):
+            ins.append(socket.create_connection(("127.0.0.1", door.port_in)))
+            _wait(lambda: door.counts()["accepted_in"] == k + 1)
+        outs = []
+        for k in range(2):
+            outs.append(socket.create_connection(("127.0.0.1", door.port_out)))
+            _wait(lambda: door.counts()["accepted_out"] == k + 1)
+        x = np.random.default_rng(5).standard_normal((2, 2, hop))
+        # dialogue 0's listener goes away; the worker notices when it cannot deliver (the socket is reset), and tells the door
+        outs[0].setsockopt(socket.SOL_SOCKET, socket.SO_LINGER, struct.pack("ii", 1, 0))
+        outs[0].close()
+        for _ in range(3):
+            ins[0].sendall(wire.encode_input(x[0, 0], x[0, 1]))
+            time.sleep(0.1)
+        _wait(lambda: shards[0].stats()["out_connections"] == 0)
+        time.sleep(0.1)
+        late = socket.create_connection(("127.0.0.1", door.port_out))       # fewest listeners, lowest global slot: dialogue 0 again
+        _wait(lambda: shards[0].stats()["out_connections"] == 1)
+        ins[0].sendall(wire.encode_input(x[0, 0], x[0, 1]))
+        _, r = _read_result(late)
+        np.testing.assert_array_equal(r["x1"], x[0, 0])
+        assert r["vad"][0] == 10.0
+        # worker 0 goes away (its process died): dialogue slots 0 / 2 are gone, new dialogues land on worker 1 only
+        shards[0].close()
+        pairs[0][1].close()
+        time.sleep(0.3)
+        newc = socket.create_connection(("127.0.0.1", door.port_in))
+        _wait(lambda: shards[1].stats()["in_connections"] == 2)
+        ins[1].sendall(wire.encode_input(x[1, 0], x[1, 1]))
+        _, r = _read_result(outs[1])
+        assert r["vad"][0] == 20.0
+        newc.close()
+    finally:
         door.close()
+        shards[1].close()
 
 
-def test_front_door_over_single_slot_shards_spreads_the_output_connections():
+@pytest.mark.parametrize("kind", ["in-process", "links"])
+def test_front_door_over_single_slot_shards_spreads_the_output_connections(kind):
     """serve.py's default is --streams 1: every per-GPU front-end is then in BROADCAST mode (all its output connections hear its one
     dialogue, as the reference's single-client server does).  Behind the front door the k-th output connection must still hear dialogue k,
     i.e. GPU k mod N — round 3 skipped broadcast shards in the routing loop and every listener landed on shard 0 (advisor finding)."""
     hop = 800
     models = [TaggedModel(10.0), TaggedModel(20.0)]
     shards = [ingest.NativeServer.over_function(m.step, 1, 20, reset=m.reset, max_wait_s=0.05, port_in=-1, port_out=-1) for m in models]
-    door = ingest.FrontDoor(shards, port_in=0, port_out=0)
+    door, _pairs = _open_door(shards, kind)
     try:
         ins, outs = [], []
         for k in range(2):
@@ -553,7 +622,7 @@ def test_front_door_over_single_slot_shards_spreads_the_output_connections():
             np.testing.assert_array_equal(r["x1"], x[j % 2, 0])
             assert r["vad"][0] == models[j % 2].tag
     finally:
-        door.close()
+        _close_door(door, shards, kind)
         for s_ in ins + outs:
             s_.close()
 

@@ -1,5 +1,6 @@
 """Host logic of the many-stream TCP front-end, with a test double in place of the GPU model
 (the real model has no CPU path).  Checks routing, frame assembly and packet framing."""
+import os
 import socket
 import struct
 import time
@@ -282,3 +283,26 @@ def test_process_contract_is_decided_once_and_an_inner_type_error_is_not_retried
         assert "dtype bug" in str(e)
     assert vap.calls == ["x"]                 # stepped once, not twice
     srv.lin.close(); srv.lout.close()
+
+
+def test_front_door_process_over_worker_processes_with_standin_engines():
+    """The host half of BASELINE config 4 in miniature, across REAL processes: a front-door process (vapx_frontdoor_open_links) passes every
+    accepted connection to one of two worker processes (vapx_ingest_attach_link), each a passive native front-end over the native stand-in for
+    the GPU tick; two load-generator processes play 64 real-time dialogues with in-band latency stamps.  Every frame must come back, every output
+    socket must keep hearing one dialogue, both workers must carry half the dialogues."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "server_load.py"), "--standin", "--shards", "2", "--worker-procs", "--streams", "64",
+                          "--seconds", "3", "--warm", "1.5", "--loadgen-procs", "2", "--client-threads", "2", "--rx-threads", "2", "--tx-threads", "2"],
+                         capture_output=True, text=True, timeout=180, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["streams"] == 64 and d["procs"] == 2 and d["inband"] == 1
+    assert d["frames_sent"] > 64 * 20 * 3 and d["frames_answered"] == d["frames_sent"]
+    assert d["route_changes"] == 0 and d["inband_unreadable"] == 0
+    assert d["server_stats"]["front_door"] == {"accepted_in": 64, "accepted_out": 64, "refused": 0}
+    per = d["server_stats"]["per_shard"]
+    assert len(per) == 2 and all(abs(p["frames_done"] - d["frames_answered"] / 2) <= 64 for p in per)      # dialogue k -> worker k mod 2
+    assert "worker processes" in d["server"]

@@ -6,6 +6,15 @@
 //   * receiver threads parse the result packets; latency of a frame = just before its last packet is sent -> complete
 //     result packet read.
 // Prints one JSON line: frames sent / answered, latency percentiles, late frames (> --late-ms).
+// Scale-out (BASELINE config 4: 32768 dialogues behind one port pair; a process here may hold ~20 k descriptors):
+//   --inband 1        the send time of a frame and the stream's id ride IN the audio (first sample pair of the frame's last packet, scaled to
+//                     ~1e-3 so a real engine is not disturbed); the server echoes the audio in f64, so the receiver reads them back from the
+//                     result packet: latency needs no shared state between sender and receiver — any output socket may hear any dialogue, and
+//                     several loadgen PROCESSES can drive one server.  Also checks that an output socket keeps hearing the same dialogue.
+//   --procs P --rank r --sync-dir D    P processes, rank r plays dialogues r, r + P, ... of --total-streams (phases spread over the GLOBAL
+//                     population); all dial their inputs, meet (files in D), dial their outputs, meet, and start at a common CLOCK_MONOTONIC time
+//   --src-ips N       dial from 127.0.0.2 .. 127.0.0.(1+N) in turn (one (src ip, dst ip, dst port) triple has ~28 k ephemeral ports)
+//   --hist-out F      latency histogram (50 us bins up to 400 ms) as JSON, for merging the processes' percentiles
 // Build: make -C vap-realtime_amd/csrc loadgen   (plain C++17, no dependencies)
 #include <arpa/inet.h>
 #include <errno.h>
@@ -36,14 +45,26 @@ static double now_s() {
   return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
 
+static int g_src_ips = 0, g_dial_seq = 0;
 static int dial(const char* host, int port) {
   int s = socket(AF_INET, SOCK_STREAM, 0);
+  if (g_src_ips > 0) {   // spread the source address over 127.0.0.2.. (the whole 127/8 is local): ports are chosen at connect() time per 4-tuple
+    int one = 1;
+#ifdef IP_BIND_ADDRESS_NO_PORT
+    setsockopt(s, IPPROTO_IP, IP_BIND_ADDRESS_NO_PORT, &one, sizeof one);
+#endif
+    sockaddr_in b;
+    memset(&b, 0, sizeof b);
+    b.sin_family = AF_INET;
+    b.sin_addr.s_addr = htonl(0x7f000002u + (uint32_t)(g_dial_seq++ % g_src_ips));
+    if (bind(s, (sockaddr*)&b, sizeof b) != 0) perror("bind source address");
+  }
   sockaddr_in a;
   memset(&a, 0, sizeof a);
   a.sin_family = AF_INET;
   a.sin_port = htons((uint16_t)port);
   inet_pton(AF_INET, host, &a.sin_addr);
-  for (int tries = 0; tries < 50; ++tries) {
+  for (int tries = 0; tries < 500; ++tries) {
     if (connect(s, (sockaddr*)&a, sizeof a) == 0) {
       int one = 1;
       setsockopt(s, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
@@ -61,6 +82,7 @@ struct Stream {
   std::deque<double> sent;          // send-completion time of each frame not yet answered
   std::vector<uint8_t> rbuf;
   long answered = 0, frames = 0;
+  int heard = -1;                   // --inband: the dialogue this output socket hears (must never change)
   double t_first_sent = 0, t_first_answer = 0;
 };
 
@@ -68,6 +90,9 @@ int main(int argc, char** argv) {
   const char* host = "127.0.0.1";
   int port_in = 50007, port_out = 50008, S = 256, hz = 20, packet_ms = 10, threads = 4;
   double seconds = 10.0, late_ms = 10.0, warm = 3.0;
+  int inband = 0, procs = 1, rank = 0, total_streams = 0;
+  const char* sync_dir = nullptr;
+  const char* hist_out = nullptr;
   for (int i = 1; i + 1 < argc; i += 2) {
     std::string k = argv[i];
     const char* v = argv[i + 1];
@@ -81,8 +106,28 @@ int main(int argc, char** argv) {
     else if (k == "--packet-ms") packet_ms = atoi(v);
     else if (k == "--threads") threads = atoi(v);
     else if (k == "--late-ms") late_ms = atof(v);
+    else if (k == "--inband") inband = atoi(v);
+    else if (k == "--procs") procs = atoi(v);
+    else if (k == "--rank") rank = atoi(v);
+    else if (k == "--total-streams") total_streams = atoi(v);
+    else if (k == "--sync-dir") sync_dir = v;
+    else if (k == "--src-ips") g_src_ips = atoi(v);
+    else if (k == "--hist-out") hist_out = v;
     else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
   }
+  if (total_streams <= 0) total_streams = S * procs;
+  if (procs > 1 && (!sync_dir || !inband)) { fprintf(stderr, "--procs > 1 needs --sync-dir and --inband 1\n"); return 2; }
+  // meet the other loadgen processes: touch <dir>/<tag>.<rank>, wait until every rank's file is there
+  auto meet = [&](const char* tag) {
+    if (procs <= 1) return;
+    char p[512];
+    snprintf(p, sizeof p, "%s/%s.%d", sync_dir, tag, rank);
+    FILE* f = fopen(p, "w"); if (f) fclose(f);
+    for (int r = 0; r < procs; ++r) {
+      snprintf(p, sizeof p, "%s/%s.%d", sync_dir, tag, r);
+      while (access(p, F_OK) != 0) usleep(2000);
+    }
+  };
   const int hop = 16000 / hz;
   const double period = 1.0 / hz;
   const int packets_per_frame = (int)lround(period * 1000.0 / packet_ms);
@@ -109,23 +154,38 @@ int main(int argc, char** argv) {
   for (int i = 0; i < S; ++i) st[i].fd_in = dial(host, port_in);
   const double td1 = now_s();
   usleep((useconds_t)(300000 + 100 * S));            // let the server adopt every connection before the next step
+  meet("inputs");
 
   const double td2 = now_s();
   for (int i = 0; i < S; ++i) st[i].fd_out = dial(host, port_out);
   const double td3 = now_s();
   usleep((useconds_t)(300000 + 100 * S));
+  meet("outputs");
   fprintf(stderr, "loadgen CLOCK_MONOTONIC: inputs dialled %.3f .. %.3f, outputs dialled %.3f .. %.3f\n", td0, td1, td2, td3);
 
   std::atomic<bool> stop{false};
   std::atomic<long> frames_sent{0}, frames_answered{0}, late{0}, slipped{0};
   std::atomic<long> max_send_lag_us{0}, max_recv_gap_us{0}, max_send_call_us{0};   // the load generator's own stalls (so they are not blamed on the server)
   auto amax = [](std::atomic<long>& a, long v) { long m = a.load(); while (v > m && !a.compare_exchange_weak(m, v)) {} };
+  std::atomic<long> route_changes{0}, inband_bad{0};
   std::mutex lat_mu;
   struct Stall { double t; int stream; float ms; };
   std::vector<Stall> stalls;                          // answers later than 50 ms: when (s after the measurement start), which stream, how late
   std::vector<float> lats;
   lats.reserve((size_t)(S * hz * seconds * 1.1));
-  const double t_start = now_s() + 0.2;
+  double t_start = now_s() + 0.2;
+  if (procs > 1) {                                   // rank 0 names the common start (CLOCK_MONOTONIC is system-wide), the others read it
+    char p[512], q[512];
+    snprintf(p, sizeof p, "%s/t_start", sync_dir);
+    if (rank == 0) {
+      snprintf(q, sizeof q, "%s/t_start.tmp", sync_dir);
+      FILE* f = fopen(q, "w"); fprintf(f, "%.6f\n", now_s() + 1.0); fclose(f); rename(q, p);
+    }
+    FILE* f = nullptr;
+    while (!(f = fopen(p, "r"))) usleep(2000);
+    if (fscanf(f, "%lf", &t_start) != 1) { fprintf(stderr, "bad t_start\n"); return 2; }
+    fclose(f);
+  }
   fprintf(stderr, "loadgen CLOCK_MONOTONIC: t_start %.3f\n", t_start);
   const double t_measure = t_start + warm;          // latencies before this are not recorded (window fill / ramp-up)
   const double t_end = t_measure + seconds;
@@ -137,7 +197,8 @@ int main(int argc, char** argv) {
     struct Ev { double t; int s; int pk; long frame; };
     auto later = [](const Ev& a, const Ev& b) { return a.t > b.t; };
     std::priority_queue<Ev, std::vector<Ev>, decltype(later)> q(later);
-    for (int i : mine) q.push({t_start + period * i / S + period / packets_per_frame, i, 0, 0});
+    for (int i : mine) q.push({t_start + period * ((long)i * procs + rank) / total_streams + period / packets_per_frame, i, 0, 0});
+    std::vector<double> pkt((size_t)pk_samples * 2);
     while (!stop.load() && !q.empty()) {
       Ev e = q.top();
       q.pop();
@@ -152,9 +213,18 @@ int main(int argc, char** argv) {
       const uint8_t* p = (const uint8_t*)(audio.data() + ((size_t)(e.frame % NF) * hop + (size_t)e.pk * pk_samples) * 2);
       size_t left = (size_t)pk_samples * 16;
       if (e.pk + 1 == packets_per_frame) {   // time stamp BEFORE the frame's last packet leaves: the answer may overtake us
-        std::lock_guard<std::mutex> lk(st[e.s].mu);
-        st[e.s].sent.push_back(now_s());
-        if (st[e.s].frames++ == 0) st[e.s].t_first_sent = st[e.s].sent.back();
+        const double ts = now_s();
+        if (inband) {                          // the stamp and the dialogue id travel in the first sample pair of this packet
+          memcpy(pkt.data(), p, left);
+          pkt[0] = fmod(ts, 1024.0) * (1.0 / 1048576.0);
+          pkt[1] = (double)((long)e.s * procs + rank + 1) * (1.0 / 1073741824.0);
+          p = (const uint8_t*)pkt.data();
+          if (st[e.s].frames++ == 0) st[e.s].t_first_sent = ts;
+        } else {
+          std::lock_guard<std::mutex> lk(st[e.s].mu);
+          st[e.s].sent.push_back(ts);
+          if (st[e.s].frames++ == 0) st[e.s].t_first_sent = st[e.s].sent.back();
+        }
       }
       const double t_call = now_s();
       while (left) {
@@ -199,12 +269,24 @@ int main(int argc, char** argv) {
           uint32_t len;
           memcpy(&len, s.rbuf.data() + off, 4);
           if (s.rbuf.size() - off < 4 + (size_t)len) break;
-          off += 4 + len;
           double t_sent = 0;
-          {
+          if (inband) {   // payload: f64 t | u32 n | x1[n] | u32 n | x2[n] | ...; the stamps sit at sample k0 = hop - pk_samples of x1 / x2
+            const size_t k0 = (size_t)(hop - pk_samples), o1 = off + 4 + 8 + 4 + 8 * k0, o2 = off + 4 + 8 + 4 + 8 * (size_t)hop + 4 + 8 * k0;
+            double v1 = 0, v2 = 0;
+            if (len >= 8 + 4 + 8 * (size_t)hop + 4 + 8 * (size_t)hop) { memcpy(&v1, s.rbuf.data() + o1, 8); memcpy(&v2, s.rbuf.data() + o2, 8); }
+            const long id = lround(v2 * 1073741824.0) - 1;
+            if (id < 0 || v1 <= 0) inband_bad.fetch_add(1);
+            else {
+              const double tm = fmod(t, 1024.0), ts = v1 * 1048576.0;
+              t_sent = t - fmod(tm - ts + 1024.0, 1024.0);
+              if (s.heard >= 0 && s.heard != (int)id) route_changes.fetch_add(1);
+              s.heard = (int)id;
+            }
+          } else {
             std::lock_guard<std::mutex> lk(s.mu);
             if (!s.sent.empty()) { t_sent = s.sent.front(); s.sent.pop_front(); }
           }
+          off += 4 + len;
           if (s.answered == 0) s.t_first_answer = t;
           ++s.answered;
           frames_answered.fetch_add(1);
@@ -235,6 +317,17 @@ int main(int argc, char** argv) {
   auto pct = [&](double q) { return lats.empty() ? 0.0 : (double)lats[std::min(lats.size() - 1, (size_t)(q * lats.size()))]; };
   long unanswered = 0;
   for (auto& s : st) unanswered += (long)s.sent.size();
+  if (inband) unanswered = frames_sent.load() - frames_answered.load();
+  if (hist_out) {                                    // 50 us bins up to 400 ms (the last bin takes everything above)
+    std::vector<long> hist(8001, 0);
+    for (float v : lats) hist[std::min<size_t>(8000, (size_t)(v * 20.0f))]++;
+    if (FILE* f = fopen(hist_out, "w")) {
+      fprintf(f, "{\"bin_ms\": 0.05, \"samples\": %zu, \"max_ms\": %.3f, \"hist\": [", lats.size(), lats.empty() ? 0.0 : (double)lats.back());
+      for (size_t i = 0; i < hist.size(); ++i) fprintf(f, "%s%ld", i ? "," : "", hist[i]);
+      fprintf(f, "]}\n");
+      fclose(f);
+    }
+  }
   // stall events: late answers clustered in time (a TCP retransmission timeout shows as one stream ~200 ms late, a host stall as many at once)
   std::sort(stalls.begin(), stalls.end(), [](const Stall& a, const Stall& b) { return a.t < b.t; });
   std::string stall_json = "[";
@@ -262,6 +355,7 @@ int main(int argc, char** argv) {
       }
     printf("\"streams_with_unanswered_frames\": %s], ", u.c_str());
   }
+  printf("\"inband\": %d, \"procs\": %d, \"rank\": %d, \"route_changes\": %ld, \"inband_unreadable\": %ld, ", inband, procs, rank, route_changes.load(), inband_bad.load());
   printf("\"streams\": %d, \"frame_hz\": %d, \"packet_ms\": %d, \"seconds_measured\": %.1f, \"frames_sent\": %ld, \"frames_answered\": %ld, "
          "\"unanswered_at_end\": %ld, \"latency_samples\": %zu, \"lat_p50_ms\": %.3f, \"lat_p99_ms\": %.3f, \"lat_p999_ms\": %.3f, \"lat_max_ms\": %.3f, "
          "\"late_over_%.0fms\": %ld, \"schedule_slips\": %ld, \"client_max_send_lag_ms\": %.2f, \"client_max_send_call_ms\": %.2f, \"client_max_recv_pass_ms\": %.2f, \"stream_frames_per_s\": %.1f}\n",

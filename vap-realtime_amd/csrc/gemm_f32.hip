@@ -50,7 +50,11 @@ __global__ __launch_bounds__(256, (WM == 4 ? 2 : 2)) void gemm_f32_kernel(const 
   const int m0 = mt * BM, n0 = nt * 256;
 
   // ---- staging coordinates: 8 threads cover one 128-byte k-row ----
-  const int srow = tid >> 3, skq = (tid & 7) * 4;
+  // SPLIT: a staged row is 32 halves at an 80-byte stride and leaves as 8-byte stores; a ds_write_b64 is served in groups of 16 lanes over
+  // 32 banks, i.e. TWO rows per group, and rows r, r + 1 overlap in four banks (20 dwords apart: 28 % of the LDS-active cycles of
+  // gemm_f32_kernel<4, 1, 4, true> were conflicts, profiles/r05_c3_split_pmc.txt).  Rows r and r + 4 are 80 dwords = 16 banks apart: the
+  // thread -> row map pairs those (which 8 threads fetch which 128-byte k-row from global is free).
+  const int srow = SPLIT ? ((tid >> 4) & 3) + 4 * ((tid >> 3) & 1) + 8 * (tid >> 6) : tid >> 3, skq = (tid & 7) * 4;
   const float* aptr[WM];
 #pragma unroll
   for (int i = 0; i < WM; ++i) {

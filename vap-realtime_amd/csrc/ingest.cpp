@@ -22,6 +22,8 @@
 #include <sys/resource.h>
 #include <sys/socket.h>
 #include <sys/uio.h>
+#include <sys/un.h>
+#include <poll.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -231,6 +233,11 @@ struct vapx_ingest {
   bool debug = false;                      // VAPX_INGEST_DEBUG set at open: per-call stall diagnostics (two clock reads per recv / sendmsg)
   std::string err;
   bool pinned_blocks = true;               // staging came from vapx_host_alloc (false: plain calloc, no HIP device)
+  // link to a front door in ANOTHER process (vapx_ingest_attach_link): accepted connections arrive as descriptors over a unix socket,
+  // slot releases / listener drops are reported back
+  int link_fd = -1;
+  std::mutex link_mu;                      // serialises the sends (rx / tx / link threads)
+  std::thread link_thread;
 
   float* f32buf(int slot, int buf) { return stage + ((size_t)slot * NBUF + buf) * 2 * hop; }
   double* f64buf(int slot, int buf) { return echo.data() + ((size_t)slot * NBUF + buf) * 2 * hop; }
@@ -300,6 +307,66 @@ void release_buf(vapx_ingest* g, int slot, int buf) {
   if (need) kick(g->wake[r]);
 }
 
+// ---- link protocol (front-door process <-> worker process), one SOCK_SEQPACKET unix socket per worker ----
+struct LinkMsg { int32_t kind, a, b, c; };
+enum { LK_HELLO = 1,      // worker -> door: a = dialogue slots, b = frame_hz, c = mode | broadcast << 8
+       LK_ADOPT_IN = 2,   // door -> worker: a = local slot, + the accepted input socket (SCM_RIGHTS)
+       LK_ADOPT_OUT = 3,  // door -> worker: a = local slot the listener attaches to (ignored by a broadcast shard), + the socket
+       LK_IN_CLOSED = 4,  // worker -> door: the input connection of slot a is gone (the slot is free again)
+       LK_OUT_CLOSED = 5  // worker -> door: a listener of slot a was dropped (broadcast shard: a = -1)
+};
+
+bool link_send(int link, std::mutex* mu, const LinkMsg& m, int pass_fd = -1) {
+  msghdr mh;
+  memset(&mh, 0, sizeof mh);
+  iovec iov{(void*)&m, sizeof m};
+  mh.msg_iov = &iov; mh.msg_iovlen = 1;
+  alignas(cmsghdr) char ctl[CMSG_SPACE(sizeof(int))];
+  if (pass_fd >= 0) {
+    memset(ctl, 0, sizeof ctl);
+    mh.msg_control = ctl; mh.msg_controllen = sizeof ctl;
+    cmsghdr* c = CMSG_FIRSTHDR(&mh);
+    c->cmsg_level = SOL_SOCKET; c->cmsg_type = SCM_RIGHTS; c->cmsg_len = CMSG_LEN(sizeof(int));
+    memcpy(CMSG_DATA(c), &pass_fd, sizeof(int));
+  }
+  std::unique_lock<std::mutex> lk;
+  if (mu) lk = std::unique_lock<std::mutex>(*mu);
+  for (;;) {
+    ssize_t w = sendmsg(link, &mh, MSG_NOSIGNAL);
+    if (w == (ssize_t)sizeof m) return true;
+    if (w < 0 && (errno == EINTR)) continue;
+    if (w < 0 && (errno == EAGAIN || errno == EWOULDBLOCK)) { pollfd p{link, POLLOUT, 0}; poll(&p, 1, 50); continue; }
+    return false;
+  }
+}
+
+// one message (and at most one descriptor); returns 1, 0 = nothing within `timeout_ms`, -1 = the peer is gone
+int link_recv(int link, LinkMsg* m, int* got_fd, int timeout_ms) {
+  pollfd p{link, POLLIN, 0};
+  const int pr = poll(&p, 1, timeout_ms);
+  if (pr == 0) return 0;
+  if (pr < 0) return errno == EINTR ? 0 : -1;
+  msghdr mh;
+  memset(&mh, 0, sizeof mh);
+  iovec iov{m, sizeof *m};
+  mh.msg_iov = &iov; mh.msg_iovlen = 1;
+  alignas(cmsghdr) char ctl[CMSG_SPACE(sizeof(int))];
+  mh.msg_control = ctl; mh.msg_controllen = sizeof ctl;
+  ssize_t r = recvmsg(link, &mh, MSG_CMSG_CLOEXEC | MSG_DONTWAIT);
+  if (r < 0) return (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR) ? 0 : -1;
+  if (r == 0) return -1;
+  if (got_fd) {
+    *got_fd = -1;
+    for (cmsghdr* c = CMSG_FIRSTHDR(&mh); c; c = CMSG_NXTHDR(&mh, c))
+      if (c->cmsg_level == SOL_SOCKET && c->cmsg_type == SCM_RIGHTS) memcpy(got_fd, CMSG_DATA(c), sizeof(int));
+  }
+  return r == (ssize_t)sizeof *m ? 1 : -1;
+}
+
+void link_event(vapx_ingest* g, int kind, int slot) {
+  if (g->link_fd >= 0) link_send(g->link_fd, &g->link_mu, LinkMsg{kind, slot, 0, 0});
+}
+
 void drop_input(vapx_ingest* g, int r, int slot) {
   Slot& s = g->slots[slot];
   if (s.fd_in < 0) return;
@@ -313,6 +380,7 @@ void drop_input(vapx_ingest* g, int r, int slot) {
     if (slot < g->free_hint) g->free_hint = slot;
     s.gen.fetch_add(1);                     // frames of this connection still queued are dropped by the tick thread
   }
+  link_event(g, LK_IN_CLOSED, slot);       // (before the counter: who sees the count drop finds the door's mirror told already)
   g->in_conns.fetch_sub(1);
 }
 
@@ -559,9 +627,64 @@ void accept_out(vapx_ingest* g) {
 
 // a dropped listener lowers its slot's count: the next output connection goes there first
 void listener_dropped(vapx_ingest* g, int slot) {
+  {
+    std::lock_guard<std::mutex> lk(g->slots_mu);
+    if (--g->lcount[slot] < g->lmin) { g->lmin = g->lcount[slot]; g->lcursor = slot; }
+    else if (g->lcount[slot] == g->lmin && slot < g->lcursor) g->lcursor = slot;
+  }
+  link_event(g, LK_OUT_CLOSED, slot);
+}
+
+// the same adoptions with the slot named by a front door in another process (its mirror of this shard is the allocator)
+bool adopt_in_at(vapx_ingest* g, int fd, int slot) {
+  if (slot < 0 || slot >= g->S) return false;
+  {
+    std::lock_guard<std::mutex> lk(g->slots_mu);
+    if (g->slots[slot].fd_in >= 0) return false;
+    g->slots[slot].fd_in = fd;
+  }
+  int one = 1;
+  setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+  const int fl = fcntl(fd, F_GETFL, 0);
+  if (fl >= 0) fcntl(fd, F_SETFL, fl | O_NONBLOCK);
+  Slot& s = g->slots[slot];
+  s.wbuf = -1; s.fill = 0; s.npartial = 0; s.backlog.clear(); s.paused = false; s.lowat = 0;
+  {
+    std::lock_guard<std::mutex> lk(g->ready_mu);
+    g->resets.push_back({slot, g->cfg.reset_on_connect ? 0 : 1});
+  }
+  g->in_conns.fetch_add(1);
+  ep_add(g->ep[slot % g->R], fd, K_DATA | (uint32_t)slot);
+  return true;
+}
+
+void adopt_out_at(vapx_ingest* g, int fd, int slot) {
+  int one = 1;
+  setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+  const int fl = fcntl(fd, F_GETFL, 0);
+  if (fl >= 0) fcntl(fd, F_SETFL, fl | O_NONBLOCK);
+  g->out_conns.fetch_add(1);
+  if (g->broadcast) { std::lock_guard<std::mutex> lk(g->slots_mu); g->out_all.push_back(fd); return; }
+  if (slot < 0 || slot >= g->S) slot = 0;
   std::lock_guard<std::mutex> lk(g->slots_mu);
-  if (--g->lcount[slot] < g->lmin) { g->lmin = g->lcount[slot]; g->lcursor = slot; }
-  else if (g->lcount[slot] == g->lmin && slot < g->lcursor) g->lcursor = slot;
+  ++g->lcount[slot];
+  std::lock_guard<std::mutex> l2(g->slots[slot].lmu);
+  g->slots[slot].listeners.push_back(fd);
+}
+
+void link_main(vapx_ingest* g) {
+  while (!g->stop.load()) {
+    LinkMsg m;
+    int fd = -1;
+    const int rc = link_recv(g->link_fd, &m, &fd, 100);
+    if (rc == 0) continue;
+    if (rc < 0) break;                       // the front door is gone: keep serving the dialogues we have, take no new ones
+    if (m.kind == LK_ADOPT_IN) {
+      if (fd >= 0 && !adopt_in_at(g, fd, m.a)) { close(fd); link_event(g, LK_IN_CLOSED, m.a); }   // (cannot happen while the door's mirror is right)
+    } else if (m.kind == LK_ADOPT_OUT) {
+      if (fd >= 0) adopt_out_at(g, fd, m.a);
+    } else if (fd >= 0) close(fd);
+  }
 }
 
 void accept_main(vapx_ingest* g) {
@@ -656,7 +779,7 @@ void tx_main(vapx_ingest* g, int x) {
             const bool sent = send_packet(fds[i], iov, 5, total);
             if (g->debug) atomic_max(g->dbg_send_us, (int64_t)((mono_now() - ts0) * 1e6));   // longest sendmsg() call (the socket is non-blocking)
             if (sent) { g->tx_bytes.fetch_add((int64_t)total, std::memory_order_relaxed); ++i; }
-            else { close(fds[i]); fds.erase(fds.begin() + i); g->dropped.fetch_add(1); g->out_conns.fetch_sub(1); }
+            else { close(fds[i]); fds.erase(fds.begin() + i); g->dropped.fetch_add(1); g->out_conns.fetch_sub(1); if (g->broadcast) link_event(g, LK_OUT_CLOSED, -1); }
           }
         };
         if (g->broadcast) { std::lock_guard<std::mutex> lk(g->slots_mu); send_to(g->out_all); }
@@ -1004,6 +1127,8 @@ void vapx_ingest_close(vapx_ingest_handle g) {
   g->job_done_cv.notify_all();
   for (int fd : g->wake) kick(fd);
   if (g->accept_thread.joinable()) g->accept_thread.join();
+  if (g->link_thread.joinable()) g->link_thread.join();
+  if (g->link_fd >= 0) { std::lock_guard<std::mutex> lk(g->link_mu); g->link_fd = -1; }   // (the descriptor stays the caller's: include/vapx.h)
   if (g->ep_accept >= 0) close(g->ep_accept);
   for (auto& t : g->rx_threads) if (t.joinable()) t.join();
   if (g->tick_thread.joinable()) g->tick_thread.join();
@@ -1062,8 +1187,31 @@ void vapx_ingest_close(vapx_ingest_handle g) {
 // A dialogue never moves between GPUs: its state lives there (vapx_get_state / vapx_set_state migrate one on purpose).
 }  // extern "C"
 
+struct RemoteShard {                        // the door's mirror of a shard that lives in another process
+  int link = -1, S = 0, hz = 0, mode = 0;
+  bool broadcast = false, dead = false;
+  std::vector<char> used;                   // input slot taken
+  int free_hint = 0;
+  std::vector<int> lcount;                  // listeners per slot
+  int lmin = 0, lcursor = 0, bcast = 0;
+  int lowest_free() {
+    for (int i = free_hint; i < S; ++i) if (!used[i]) { free_hint = i; return i; }
+    free_hint = S;
+    return -1;
+  }
+  std::pair<int, int> next_listener() {
+    if (broadcast) return {bcast, 0};
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int i = lcursor; i < S; ++i) if (lcount[i] == lmin) { lcursor = i; return {lmin, i}; }
+      ++lmin; lcursor = 0;
+    }
+    return {lmin, 0};
+  }
+};
+
 struct vapx_frontdoor {
   std::vector<vapx_ingest*> shards;
+  std::vector<RemoteShard> remote;          // vapx_frontdoor_open_links: shards in other processes
   int lin = -1, lout = -1, port_in = 0, port_out = 0, ep = -1;
   std::thread th;
   std::atomic<bool> stop{false};
@@ -1121,9 +1269,113 @@ void frontdoor_main(vapx_frontdoor* d) {
   }
 }
 
+constexpr uint64_t K_LINK = 4ull << 32;
+
+// The same door with the shards in OTHER processes (one per GPU): placement runs on the mirrors, the accepted socket travels to the worker
+// (SCM_RIGHTS) and is closed here - this process never holds more than the listen sockets, the links and the connection in hand.
+void frontdoor_remote_main(vapx_frontdoor* d) {
+  epoll_event evs[16];
+  const int N = (int)d->remote.size();
+  while (!d->stop.load()) {
+    int n = epoll_wait(d->ep, evs, 16, 100);
+    for (int i = 0; i < n; ++i) {
+      const uint64_t kind = evs[i].data.u64 & ~0xffffffffull;
+      if (kind == K_LINK) {                  // a worker reports a released slot / a dropped listener (or went away)
+        RemoteShard& r = d->remote[(int)(evs[i].data.u64 & 0xffffffffu)];
+        for (;;) {
+          LinkMsg m;
+          const int rc = link_recv(r.link, &m, nullptr, 0);
+          if (rc == 0) break;
+          if (rc < 0) { if (!r.dead) { r.dead = true; epoll_ctl(d->ep, EPOLL_CTL_DEL, r.link, nullptr); } break; }
+          if (m.kind == LK_IN_CLOSED && m.a >= 0 && m.a < r.S) { r.used[m.a] = 0; if (m.a < r.free_hint) r.free_hint = m.a; }
+          else if (m.kind == LK_OUT_CLOSED) {
+            if (r.broadcast || m.a < 0) { if (r.bcast > 0) --r.bcast; }
+            else if (m.a < r.S && r.lcount[m.a] > 0) {
+              if (--r.lcount[m.a] < r.lmin) { r.lmin = r.lcount[m.a]; r.lcursor = m.a; }
+              else if (r.lcount[m.a] == r.lmin && m.a < r.lcursor) r.lcursor = m.a;
+            }
+          }
+        }
+        continue;
+      }
+      for (;;) {
+        int fd = accept4(kind == K_LISTEN_IN ? d->lin : d->lout, nullptr, nullptr, SOCK_NONBLOCK);
+        if (fd < 0) {
+          if (errno == EMFILE || errno == ENFILE || errno == ENOBUFS || errno == ENOMEM) std::this_thread::sleep_for(std::chrono::milliseconds(20));
+          break;
+        }
+        if (kind == K_LISTEN_IN) {
+          long best = -1; int who = -1, ls_who = -1;
+          for (int k = 0; k < N; ++k) {
+            if (d->remote[k].dead) continue;
+            const int ls = d->remote[k].lowest_free();
+            if (ls < 0) continue;
+            const long gslot = (long)ls * N + k;
+            if (who < 0 || gslot < best) { best = gslot; who = k; ls_who = ls; }
+          }
+          if (who >= 0 && link_send(d->remote[who].link, nullptr, LinkMsg{LK_ADOPT_IN, ls_who, 0, 0}, fd)) {
+            d->remote[who].used[ls_who] = 1;
+            d->accepted_in.fetch_add(1);
+          } else d->refused.fetch_add(1);      // every dialogue slot of every GPU is taken (or that worker is gone)
+        } else {
+          int who = -1, slot = 0; long bestc = -1, bestg = -1;
+          for (int k = 0; k < N; ++k) {
+            if (d->remote[k].dead) continue;
+            const std::pair<int, int> c = d->remote[k].next_listener();
+            const long gslot = (long)c.second * N + k;
+            if (bestc < 0 || c.first < bestc || (c.first == bestc && gslot < bestg)) { bestc = c.first; bestg = gslot; who = k; slot = c.second; }
+          }
+          if (who >= 0 && link_send(d->remote[who].link, nullptr, LinkMsg{LK_ADOPT_OUT, slot, 0, 0}, fd)) {
+            RemoteShard& r = d->remote[who];
+            if (r.broadcast) ++r.bcast; else { ++r.lcount[slot]; r.lcursor = slot + 1; }
+            d->accepted_out.fetch_add(1);
+          } else d->refused.fetch_add(1);
+        }
+        close(fd);                           // the worker holds its own copy now
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int vapx_ingest_attach_link(vapx_ingest_handle g, int32_t link_fd) {
+  if (!g || link_fd < 0 || g->link_fd >= 0) return VAPX_E_INVAL;
+  if (g->lin >= 0 || g->lout >= 0) return VAPX_E_INVAL;           // only a passive shard takes its connections from a door
+  g->link_fd = link_fd;
+  if (!link_send(link_fd, &g->link_mu, LinkMsg{LK_HELLO, g->S, g->hz, g->mode | (g->broadcast ? 256 : 0)})) { g->link_fd = -1; return VAPX_E_INVAL; }
+  g->link_thread = std::thread(link_main, g);
+  return VAPX_OK;
+}
+
+int vapx_frontdoor_open_links(const int32_t* link_fds, int32_t n_links, int32_t port_in, int32_t port_out, int32_t bind_any, vapx_frontdoor_handle* out) {
+  if (!link_fds || n_links < 1 || !out || port_in < 0 || port_out < 0) return VAPX_E_INVAL;
+  vapx_frontdoor* d = new vapx_frontdoor();
+  d->remote.resize(n_links);
+  for (int k = 0; k < n_links; ++k) {        // every worker introduces itself (it may still be loading its weights: wait up to 5 minutes)
+    RemoteShard& r = d->remote[k];
+    r.link = link_fds[k];
+    LinkMsg m;
+    int rc = 0;
+    for (int waited = 0; waited < 3000 && rc == 0; ++waited) rc = link_recv(r.link, &m, nullptr, 100);
+    if (rc <= 0 || m.kind != LK_HELLO || m.a < 1) { delete d; return VAPX_E_INVAL; }
+    r.S = m.a; r.hz = m.b; r.mode = m.c & 255; r.broadcast = (m.c & 256) != 0;
+    r.used.assign(r.S, 0); r.lcount.assign(r.S, 0);
+    if (r.hz != d->remote[0].hz || r.mode != d->remote[0].mode) { delete d; return VAPX_E_INVAL; }
+  }
+  d->lin = listen_on(port_in, bind_any != 0, &d->port_in);
+  d->lout = listen_on(port_out, bind_any != 0, &d->port_out);
+  if (d->lin < 0 || d->lout < 0) { vapx_frontdoor_close(d); return VAPX_E_INVAL; }
+  d->ep = epoll_create1(0);
+  ep_add(d->ep, d->lin, K_LISTEN_IN);
+  ep_add(d->ep, d->lout, K_LISTEN_OUT);
+  for (int k = 0; k < n_links; ++k) ep_add(d->ep, d->remote[k].link, K_LINK | (uint32_t)k);
+  d->th = std::thread(frontdoor_remote_main, d);
+  *out = d;
+  return VAPX_OK;
+}
 
 int vapx_frontdoor_open(vapx_ingest_handle* shards, int32_t n_shards, int32_t port_in, int32_t port_out, int32_t bind_any,
                         vapx_frontdoor_handle* out) {

@@ -30,7 +30,7 @@ EXPORTS = ("vapx_abi_version", "vapx_blob_floats", "vapx_create", "vapx_destroy"
            "vapx_profile_read", "vapx_bad_slots", "vapx_host_alloc", "vapx_host_free", "vapx_reset_carry", "vapx_get_config",
            "vapx_ingest_open", "vapx_ingest_open_fn", "vapx_ingest_ports", "vapx_ingest_stats_read", "vapx_ingest_late_read", "vapx_ingest_close",
            "vapx_wire_decode_input", "vapx_wire_encode_result", "vapx_vap_head", "vapx_va_classifier", "vapx_softmax256",
-           "vapx_aggregate", "vapx_aux_head", "vapx_frontdoor_open", "vapx_frontdoor_ports", "vapx_frontdoor_counts", "vapx_frontdoor_close")
+           "vapx_aggregate", "vapx_aux_head", "vapx_frontdoor_open", "vapx_frontdoor_open_links", "vapx_ingest_attach_link", "vapx_frontdoor_ports", "vapx_frontdoor_counts", "vapx_frontdoor_close")
 PROF_CLASSES = {0: "gemm_store", 1: "gemm_gelu", 2: "gemm_resid", 3: "gemm_resid_ln", 4: "gemm_cn_relu",
                 5: "conv_tail", 6: "ffn_block", 7: "last_row", 8: "conv0", 9: "lstm", 10: "gather_ln", 11: "attention", 12: "head",
                 13: "gemm_bias_ln_gelu", 14: "ffn_proj"}
@@ -122,6 +122,10 @@ def load_library(path: Optional[str] = None):
     lib.vapx_ingest_close.argtypes = [vp]
     lib.vapx_frontdoor_open.restype = i32
     lib.vapx_frontdoor_open.argtypes = [vp, i32, i32, i32, i32, C.POINTER(vp)]
+    lib.vapx_frontdoor_open_links.restype = i32
+    lib.vapx_frontdoor_open_links.argtypes = [C.POINTER(i32), i32, i32, i32, i32, C.POINTER(vp)]
+    lib.vapx_ingest_attach_link.restype = i32
+    lib.vapx_ingest_attach_link.argtypes = [vp, i32]
     lib.vapx_frontdoor_ports.restype = i32
     lib.vapx_frontdoor_ports.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     lib.vapx_frontdoor_counts.restype = i32

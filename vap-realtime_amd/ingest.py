@@ -103,6 +103,33 @@ class NativeServer:
         self._ports()
         return self
 
+    @classmethod
+    def over_native_function(cls, step_ptr: int, user_ptr: int, n_streams: int, frame_hz: int = 20, mode: str = "vap", max_batch: Optional[int] = None,
+                             keep=(), port_in: int = 0, port_out: int = 0, gain: float = 1.0, max_wait_s: float = 0.002, min_batch: int = 0,
+                             rx_threads: int = 0, tx_threads: int = 0, target_util: float = 0.9, cores: Optional[tuple] = None):
+        """The same front-end over a C step function (address of a ``vapx_ingest_step_fn``, ``user_ptr`` handed to it): no Python on the tick
+        thread.  ``tools/server_load.py --standin`` puts a stand-in for the GPU engine here (tools/standin_step.cpp) to load-test the host side of
+        N x 4096 dialogues; ``port_in = port_out = -1`` makes it a passive shard of a ``FrontDoor``.  ``keep``: objects that must outlive it."""
+        self = cls.__new__(cls)
+        self.lib = _engine.load_library()
+        self._keep = list(keep)
+        cfg = cls._cfg(port_in, port_out, gain, max_wait_s, min_batch, True, None, rx_threads, tx_threads, False, target_util, cores)
+        h = C.c_void_p()
+        rc = self.lib.vapx_ingest_open_fn(C.c_void_p(step_ptr), None, C.c_void_p(user_ptr), n_streams, max_batch or n_streams, frame_hz, MODE[mode],
+                                          C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise _engine.VapxError(f"vapx_ingest_open_fn failed ({rc})")
+        self._h = h
+        self._ports()
+        return self
+
+    def attach_link(self, link_fd: int):
+        """Make this PASSIVE front-end a shard of a front door in another process (``RemoteFrontDoor``): ``link_fd`` is this process's end of an
+        ``AF_UNIX / SOCK_SEQPACKET`` socket pair; accepted connections arrive over it as descriptors (include/vapx.h)."""
+        rc = self.lib.vapx_ingest_attach_link(self._h, int(link_fd))
+        if rc != 0:
+            raise _engine.VapxError(f"vapx_ingest_attach_link failed ({rc}): the front-end must be passive (port_in = port_out = -1) and not linked yet")
+
     def _ports(self):
         a, b = C.c_int32(0), C.c_int32(0)
         self.lib.vapx_ingest_ports(self._h, C.byref(a), C.byref(b))
@@ -166,6 +193,51 @@ def encode_result(mode: str, t: float, x1: np.ndarray, x2: np.ndarray, out_row: 
     return dst.tobytes()
 
 
+def link_pair():
+    """(door end, worker end) of a front-door link: ``socket.socketpair(AF_UNIX, SOCK_SEQPACKET)``; hand the worker end to the process that owns
+    the GPU (``subprocess.Popen(..., pass_fds=[worker.fileno()])``), keep both objects alive as long as the link is used."""
+    import socket
+    a, b = socket.socketpair(socket.AF_UNIX, socket.SOCK_SEQPACKET)
+    a.set_inheritable(False)
+    b.set_inheritable(True)
+    return a, b
+
+
+class RemoteFrontDoor:
+    """The reference's ONE port pair in front of N per-GPU WORKER PROCESSES (``vapx_frontdoor_open_links``): this process only accepts, decides the
+    dialogue's GPU and slot (same placement as ``FrontDoor``) and passes the socket on; engines, audio and results never come here.  ``links`` are
+    the door ends of ``link_pair()``; every worker runs a passive ``NativeServer`` with ``attach_link(worker_end)``.  The constructor waits for the
+    workers' greetings (they may still be loading weights)."""
+
+    def __init__(self, links, port_in: int = 50007, port_out: int = 50008, bind_any: bool = False):
+        self.lib = _engine.load_library()
+        self._links = list(links)
+        fds = [l if isinstance(l, int) else l.fileno() for l in self._links]
+        arr = (C.c_int32 * len(fds))(*fds)
+        h = C.c_void_p()
+        rc = self.lib.vapx_frontdoor_open_links(arr, len(fds), port_in, port_out, int(bool(bind_any)), C.byref(h))
+        if rc != 0:
+            raise _engine.VapxError(f"vapx_frontdoor_open_links failed ({rc}): a worker did not greet (died while starting?), the workers disagree on "
+                                    f"frame rate / mode, or the ports are taken")
+        self._h = h
+        a, b = C.c_int32(0), C.c_int32(0)
+        self.lib.vapx_frontdoor_ports(self._h, C.byref(a), C.byref(b))
+        self.port_in, self.port_out = a.value, b.value
+
+    counts = None      # (bound below: same as FrontDoor.counts)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.vapx_frontdoor_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class FrontDoor:
     """ONE port pair in front of N per-GPU front-ends (``vapx_frontdoor_*``): the reference's single ``port_num_in`` / ``port_num_out``
     (vap_main.py:338-366,470-471) for a whole node.  ``shards`` are ``NativeServer`` objects opened PASSIVE (``port_in=-1, port_out=-1``),
@@ -214,3 +286,6 @@ class FrontDoor:
             self.close(close_shards=False)
         except Exception:
             pass
+
+
+RemoteFrontDoor.counts = FrontDoor.counts

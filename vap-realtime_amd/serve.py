@@ -12,6 +12,11 @@ rule and its measured rates: ``capacity.plan`` / DESIGN.md §5.
     python -m vap_realtime_amd.serve --vap_model asset/vap/vap_state_dict_jp_20hz_2500msec.pt --cpc_model asset/cpc/60k_epoch4-d0f474de.pt \\
         --streams 4096 --gpus 8
 
+``--worker-procs`` (``auto`` turns it on when one process could not hold the descriptors: two sockets per dialogue against RLIMIT_NOFILE): the
+front door becomes a process of its own that only accepts and routes, and every GPU gets a WORKER process — engine, front-end threads, sockets —
+to which accepted connections are passed (``vapx_frontdoor_open_links`` / ``vapx_ingest_attach_link``, include/vapx.h).  Same ports, same
+placement, same packets; 8 x 4096 dialogues need it in a container whose descriptor limit is 20 000.
+
 ``--synthetic-weights SEED`` serves seeded random weights (no checkpoint files: load tests, demos).  SIGTERM / SIGINT stop every GPU's
 front-end and engine in order; a failure while one GPU comes up tears the others down and exits non-zero.
 """
@@ -24,16 +29,16 @@ import sys
 import time
 
 
-def build(args):
-    """(engines, shards, front door or None): N = 1 listens directly (no extra hop), N > 1 goes through the front door."""
-    from . import checkpoints, dist_util, engine, ingest, weights as W
+def load_blob(args):
+    from . import checkpoints, weights as W
     if args.synthetic_weights is not None:
         cpc, vap = W.synthetic_weights(args.synthetic_weights, args.vap_process_rate, args.mode or "vap")
-        blob, mode = W.pack_blob(cpc, vap, args.mode or "vap"), args.mode or "vap"
-    else:
-        blob, hz, mode = checkpoints.import_checkpoints(args.vap_model, args.cpc_model, frame_rate=args.vap_process_rate, mode=args.mode)
-    n = max(1, args.gpus)
-    args.precision_plan = None
+        return W.pack_blob(cpc, vap, args.mode or "vap"), args.mode or "vap"
+    blob, hz, mode = checkpoints.import_checkpoints(args.vap_model, args.cpc_model, frame_rate=args.vap_process_rate, mode=args.mode)
+    return blob, mode
+
+
+def choose_precision(args, mode):
     if args.precision == "auto":                 # serve the arithmetic the load needs (capacity.plan: measured sustained rate per path)
         from . import capacity
         pl = capacity.plan(args.streams, args.vap_process_rate, args.context_len_sec, mode)
@@ -44,6 +49,25 @@ def build(args):
                 raise RuntimeError(pl["reason"] + " (start anyway with --allow-overload, or name a --precision)")
             print("[vapx] WARNING: starting overloaded (--allow-overload): frames WILL be answered later than 10 ms at full occupancy", file=sys.stderr, flush=True)
         args.precision = pl["precision"]
+
+
+def wants_worker_procs(args) -> bool:
+    """``--worker-procs auto``: a process per GPU when ONE process could not hold the sockets (2 per dialogue + slack) under RLIMIT_NOFILE."""
+    if args.worker_procs != "auto":
+        return args.worker_procs == "on"
+    import resource
+    hard = resource.getrlimit(resource.RLIMIT_NOFILE)[1]
+    need = 2 * max(1, args.gpus) * args.streams + 256
+    return args.gpus > 1 and hard != resource.RLIM_INFINITY and need > hard
+
+
+def build(args):
+    """(engines, shards, front door or None): N = 1 listens directly (no extra hop), N > 1 goes through the front door."""
+    from . import dist_util, engine, ingest
+    blob, mode = load_blob(args)
+    n = max(1, args.gpus)
+    args.precision_plan = None
+    choose_precision(args, mode)
     engines, shards, door = [], [], None
     taken = {}                                   # cores of a NUMA node's run already given to an earlier shard's front-end
     try:
@@ -70,6 +94,104 @@ def build(args):
         teardown(engines, shards, door)
         raise
     return engines, shards, door, mode
+
+
+def run_worker(args) -> int:
+    """One GPU's worker process behind a front-door process: engine + passive front-end, connections arrive over the link (``--worker-link``)."""
+    import os
+    from . import dist_util, engine, ingest
+    stop = {"now": False}
+    signal.signal(signal.SIGTERM, lambda *_: stop.__setitem__("now", True))
+    signal.signal(signal.SIGINT, signal.SIG_IGN)               # ^C goes to the whole foreground group: the door process stops us in order
+    r = args.worker_rank
+    try:
+        blob, mode = load_blob(args)
+        dev = 0 if args.share_gpu else r
+        eng = engine.Engine(blob, args.vap_process_rate, args.context_len_sec, max_streams=args.streams, max_batch=min(args.streams, args.max_batch),
+                            mode=mode, device_id=dev, groups=2, split_f16=(args.precision == "split"))
+        cores = None
+        if args.pin:
+            nthr = 1 + args.rx_threads + args.tx_threads
+            cores, _ = dist_util.front_end_placement(dev, nthr, skip=(r * nthr if args.share_gpu else 0))
+        shard = ingest.NativeServer(eng, port_in=-1, port_out=-1, gain=args.audio_gain, max_wait_s=args.max_wait_ms * 1e-3,
+                                    rx_threads=args.rx_threads, tx_threads=args.tx_threads, cores=cores)
+        shard.attach_link(args.worker_link)
+    except Exception as e:                                      # noqa: BLE001
+        print(f"[vapx] GPU {r}: worker start-up failed: {e}", file=sys.stderr, flush=True)
+        return 1
+    parent = os.getppid()
+    last = time.time()
+    while not stop["now"] and os.getppid() == parent:          # an orphaned worker (the door process died) stops too
+        time.sleep(0.2)
+        if args.stats_sec > 0 and time.time() - last >= args.stats_sec:
+            last = time.time()
+            st = shard.stats(reset_latency_window=True)
+            print(f"[vapx] GPU {r}: " + json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()}), flush=True)
+    shard.close()
+    eng.close()
+    return 0
+
+
+def run_door(args, argv) -> int:
+    """The front-door process of ``--worker-procs``: spawns one worker per GPU, owns the port pair, touches no GPU."""
+    import subprocess
+    from . import ingest
+    stop = {"now": False}
+    signal.signal(signal.SIGTERM, lambda *_: stop.__setitem__("now", True))
+    signal.signal(signal.SIGINT, lambda *_: stop.__setitem__("now", True))
+    n = max(1, args.gpus)
+    mode = args.mode
+    if args.precision == "auto":                                # plan once, here; the workers are told the result
+        if mode is None and args.synthetic_weights is None:
+            from . import checkpoints
+            mode = checkpoints.infer_mode(checkpoints.load_state_dicts(args.vap_model, args.cpc_model)[1])
+        try:
+            choose_precision(args, mode or "vap")
+        except Exception as e:                                  # noqa: BLE001
+            print(f"[vapx] start-up failed: {e}", file=sys.stderr, flush=True)
+            return 1
+    base = [a for a in (argv if argv is not None else sys.argv[1:])]
+    for flag in ("--precision", "--worker-procs"):              # the workers get the decided values
+        while flag in base:
+            k = base.index(flag)
+            del base[k:k + 2]
+    links, workers = [], []
+    door = None
+    try:
+        for r in range(n):
+            mine, theirs = ingest.link_pair()
+            workers.append(subprocess.Popen([sys.executable, "-u", "-m", "vap_realtime_amd.serve"] + base + ["--precision", args.precision, "--worker-link",
+                                             str(theirs.fileno()), "--worker-rank", str(r)], pass_fds=[theirs.fileno()]))
+            theirs.close()
+            links.append(mine)
+        door = ingest.RemoteFrontDoor(links, args.port_num_in, args.port_num_out, bind_any=args.bind_any)
+    except Exception as e:                                      # noqa: BLE001
+        print(f"[vapx] start-up failed: {e}", file=sys.stderr, flush=True)
+        for w in workers:
+            w.terminate()
+        return 1
+    print(f"[vapx] {n} GPU(s) x {args.streams} dialogue slots in {n} worker processes, mode {mode or 'from the state dict'}, {args.precision} arithmetic, "
+          f"{args.vap_process_rate} Hz / {args.context_len_sec} s — input :{door.port_in}, output :{door.port_out} (front-door process: dialogue k -> GPU k mod N)", flush=True)
+    rc = 0
+    while not stop["now"]:
+        time.sleep(0.2)
+        dead = [r for r, w in enumerate(workers) if w.poll() is not None]
+        if len(dead) == n:                                       # nobody left to serve
+            print("[vapx] every worker has exited", file=sys.stderr, flush=True)
+            rc = 1
+            break
+    door.close()
+    for w in workers:
+        if w.poll() is None:
+            w.terminate()
+    for w in workers:
+        try:
+            w.wait(timeout=30)
+        except Exception:                                        # noqa: BLE001
+            w.kill()
+    for l in links:
+        l.close()
+    return rc
 
 
 def teardown(engines, shards, door):
@@ -113,7 +235,16 @@ def main(argv=None) -> int:
                          "no better than floating threads (profiles/r05_frontend/README.md)")
     ap.add_argument("--stats_sec", type=float, default=10.0)
     ap.add_argument("--synthetic-weights", dest="synthetic_weights", type=int, default=None)
+    ap.add_argument("--worker-procs", dest="worker_procs", choices=["auto", "on", "off"], default="auto",
+                    help="one worker PROCESS per GPU behind a front-door process that passes accepted connections on (auto: when one process could not "
+                         "hold 2 sockets per dialogue under RLIMIT_NOFILE; --gpus 8 x --streams 4096 needs 65 792 descriptors)")
+    ap.add_argument("--worker-link", dest="worker_link", type=int, default=None, help=argparse.SUPPRESS)     # set by the door process
+    ap.add_argument("--worker-rank", dest="worker_rank", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
+    if args.worker_link is not None:
+        return run_worker(args)
+    if wants_worker_procs(args):
+        return run_door(args, argv)
     stop = {"now": False}
     signal.signal(signal.SIGTERM, lambda *_: stop.__setitem__("now", True))   # the normal service-stop signal: shut every GPU down in order
     signal.signal(signal.SIGINT, lambda *_: stop.__setitem__("now", True))
