@@ -16,7 +16,8 @@ SPLIT = "--split" in sys.argv
 if SPLIT:
     sys.argv.remove("--split")
 NAMES = ["item start", "Q loads issued", "barrier A (previous item done)", "convert + LDS stores", "barrier B", "Q converted",
-         "next loads issued, accumulators zeroed", "key tiles (wave 0: 1)", "next rows arrived, maxima", "l reduce + stores"] if (LONG and SPLIT) else ["entry", "V tile staged", "query tile w (wave 0: 1 key tile)", "query tile 7-w (wave 0: 8 key tiles)"] if LONG else ["entry", "V in LDS (1st latency)", "scores+softmax+PV", "resid/ring loads issued", "barrier (all heads)", "O -> LDS + barrier",
+         "next loads issued, accumulators zeroed", "key tiles (wave 0: 1)", "next rows arrived, maxima", "l reduce + stores"] if (LONG and SPLIT) else ["entry", "metadata (n, ring rotation) loaded", "Q + K tile 0 (+ the V loads ahead of them) arrived", "first score tile + softmax", "V -> LDS (this wave)", "barrier (all 4 waves)",
+         "query tile w (wave 0: 1 key tile)", "query tile 7-w (wave 0: 8 key tiles)"] if LONG else ["entry", "V in LDS (1st latency)", "scores+softmax+PV", "resid/ring loads issued", "barrier (all heads)", "O -> LDS + barrier",
          "proj mm", "LN + xmid stores", "cross-q mm", "qx stores"]
 t = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 32).astype(np.int64)
 nst = int(np.median(t[:, 30]))

@@ -64,6 +64,21 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
     for (int i = 0; i < 16; ++i) ring[i] = wf[i * 64 + lane];
   };
   fetch(MODE == 0 ? g.w0f : g.wprojf);   // the first weight fragments fly while the activation tile is loaded and normalised
+  // layer 0 on long windows (mode 1 with resid_rot): the residual rows come straight from the embedding ring.  A tile is no longer than a window
+  // (the launcher checks resid_T >= BM), so its rows lie in at most TWO (stream, channel) slabs: their ring slots and rotations are four
+  // SCALAR loads, issued here, long before the projection needs them.  (Until round 5 every one of a lane's 16 rows looked its stream's slot
+  // and rotation up by itself behind the projection: an integer division and two DEPENDENT vector loads per row, each waited for with
+  // vmcnt(0) - 32 serialised L2 round trips per tile that also drained the next contraction's weight prefetch; tools/isa_waits.py.)
+  int ring_bc0 = 0, ring_bc1 = 0, ring_slot0 = 0, ring_slot1 = 0, ring_rot0 = 0, ring_rot1 = 0;
+  if (MODE == 1 && g.resid_rot) {
+    ring_bc0 = __builtin_amdgcn_readfirstlane(m0 / g.resid_T);
+    const int last_bc = (g.M - 1) / g.resid_T;
+    ring_bc1 = ring_bc0 + 1 <= last_bc ? ring_bc0 + 1 : ring_bc0;
+    ring_slot0 = g.resid_ids ? uniform_load(g.resid_ids, ring_bc0 >> 1) : ring_bc0 >> 1;
+    ring_slot1 = g.resid_ids ? uniform_load(g.resid_ids, ring_bc1 >> 1) : ring_bc1 >> 1;
+    ring_rot0 = uniform_load(g.resid_rot, ring_bc0 >> 1);
+    ring_rot1 = uniform_load(g.resid_rot, ring_bc1 >> 1);
+  }
   if constexpr (MODE != 0) {   // raw attention rows -> sH (A operand of the output projection)
     f32x4 xr[BM / 4];
 #pragma unroll
@@ -230,19 +245,27 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void ffn_block_kernel(const F
     mm(out, sH, g.wprojf, MODE == 1 ? g.w0f : after_ffn);
     if (MODE == 1 && g.resid_rot) {   // layer 0: residual rows straight from the embedding ring
       const int T = g.resid_T;
+      const int bc0 = ring_bc0, bc1 = ring_bc1, slot0 = ring_slot0, slot1 = ring_slot1, rot0 = ring_rot0, rot1 = ring_rot1;   // (loaded at kernel entry)
+      const int split = (bc0 + 1) * T;                           // first row of the second slab
+      const float* rp[MT][16];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
           m = m < g.M ? m : g.M - 1;
-          const int bc = m / T, i = m - bc * T, b = bc >> 1;
-          const long slab = (long)(g.resid_ids ? g.resid_ids[b] : b) * 2 + (bc & 1);
-          int rr = i + g.resid_rot[b];
+          const bool second = m >= split;
+          const int bc = second ? bc1 : bc0, i = m - bc * T;
+          int rr = i + (second ? rot1 : rot0);
           rr = rr >= T ? rr - T : rr;
-          const float* rp = g.resid + (slab * T + rr) * 256 + ccol;
-          out[mt][0][r] += rp[0];
-          out[mt][1][r] += rp[32];
+          rp[mt][r] = g.resid + (((long)(second ? slot1 : slot0) * 2 + (bc & 1)) * T + rr) * 256 + ccol;
+        }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          out[mt][0][r] += rp[mt][r][0];
+          out[mt][1][r] += rp[mt][r][32];
         }
     } else
     add_rows(out, g.resid);
@@ -1202,6 +1225,7 @@ hipError_t launch_ffn_block(const FfnArgs& a, hipStream_t st) {
       (void)hipFuncSetAttribute((const void*)ffn_block_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     if (!a.att || !a.wprojf || !a.resid || !a.xmid_out) return hipErrorInvalidValue;
+    if (a.mode == 1 && a.resid_rot && a.resid_T < 32) return hipErrorInvalidValue;   // a 32-row tile spans at most two windows (the kernel's scalar slot / rotation loads)
     if (a.mode == 1) hipLaunchKernelGGL((ffn_block_kernel<1, 1>), dim3((a.M + 31) / 32), dim3(256), lds, st, a);
     else hipLaunchKernelGGL((ffn_block_kernel<1, 2>), dim3((a.M + 31) / 32), dim3(256), lds / 2, st, a);   // one tile: three workgroups per CU
     return hipGetLastError();

@@ -440,8 +440,12 @@ __global__ __launch_bounds__(256, 2) void attention_long2_kernel(AttnArgs a) {
   };
   STAMP();   // 0: entry
   if (a.trace && tid == 0 && blockIdx.x < 16384) a.trace[(long)blockIdx.x * 32 + 28] = __builtin_amdgcn_s_memrealtime();
+  // fine stamps of the start-up (round 6): the stamp is taken once `x` has ARRIVED (an empty asm that consumes it pins the s_waitcnt there)
+#define STAMP_WHEN(x) do { asm volatile("" ::"v"(x)); STAMP(); } while (0)
+  STAMP_WHEN(n + rot);   // 1: per-stream metadata (window fill, ring rotation) loaded
 #else
   auto STAMP = [] {};
+#define STAMP_WHEN(x) do { } while (0)
 #endif
   // The V tile (up to 256 keys x 64 features of this head) goes to LDS, but NOTHING waits for it before the first score tile is done:
   // all 16 loads of a lane are issued first, then this wave's Q and K fragments, then S = K.Q^T of key tile 0 and its softmax run while
@@ -594,9 +598,11 @@ __global__ __launch_bounds__(256, 2) void attention_long2_kernel(AttnArgs a) {
     load_k(kfa, 0);
     if (it0 >= 1) load_k(kfb, 1);
     begin();
+    STAMP_WHEN(qf[7][3] + kfa[7][3]);   // 2: this wave's Q fragments and K tile 0 arrived (in-order returns: the 16 V loads issued before them too)
     scores(kfa);
     if (it0 >= 2) load_k(kfa, 2);
     al0 = softmax(0, it0 * 32 + l31, needs_mask(0, it0));
+    STAMP_WHEN(al0);                    // 3: first score tile + softmax done
   }
   if (act1) load_q(qn, it1);                             // the second pass's Q fragments fly under the first pass
   // ---- V tile -> LDS (rows >= n: zeros; masked keys have P = 0 exactly, and 0 x garbage must stay 0) ----
@@ -605,8 +611,9 @@ __global__ __launch_bounds__(256, 2) void attention_long2_kernel(AttnArgs a) {
     const int idx = u * 256 + tid, j = idx >> 4, q = (idx & 15) * 4;
     if (j < nt_valid * 32) *(f32x4*)&Vs[j * 64 + q] = j < n ? vv[u] : f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  STAMP();   // 4: this wave's part of V written to LDS
   __syncthreads();
-  STAMP();   // 1: V tile staged (first score tile already done)
+  STAMP();   // 5: barrier passed (every wave's first score tile done, whole V tile staged)
   if (act0) {
     pv(0, al0);
     if (it0 >= 1) {   // kfb holds tile 1, kfa tile 2: continue with (kfb, kfa) swapped roles
@@ -620,7 +627,7 @@ __global__ __launch_bounds__(256, 2) void attention_long2_kernel(AttnArgs a) {
   } else if (it0 < n_tiles) {
     zero_tile(it0);
   }
-  STAMP();   // 2: query tile w done
+  STAMP();   // 6: query tile w done
   // ---- pass 1: query tile 7 - w ----
   if (act1) {
 #pragma unroll
@@ -633,7 +640,7 @@ __global__ __launch_bounds__(256, 2) void attention_long2_kernel(AttnArgs a) {
   } else if (it1 < n_tiles) {
     zero_tile(it1);
   }
-  STAMP();   // 3: query tile 7 - w done
+  STAMP();   // 7: query tile 7 - w done
 #ifdef VAPX_TRACE
   if (a.trace && tid == 0 && blockIdx.x < 16384) { a.trace[(long)blockIdx.x * 32 + 29] = __builtin_amdgcn_s_memrealtime(); a.trace[(long)blockIdx.x * 32 + 30] = (unsigned long long)stamp_k; }
 #endif
