@@ -21,6 +21,7 @@
 #include <netinet/in.h>
 #include <netinet/tcp.h>
 #include <sys/epoll.h>
+#include <sys/prctl.h>
 #include <sys/resource.h>
 #include <sys/socket.h>
 #include <time.h>
@@ -191,6 +192,7 @@ int main(int argc, char** argv) {
   const double t_end = t_measure + seconds;
 
   auto sender = [&](int tid) {
+    prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);   // 1 us instead of the default 50 us: the sleeps above wake on time
     // streams tid, tid + threads, ...; stream i's frame k ends at t_start + (k + 1) * period + phase_i
     std::vector<int> mine;
     for (int i = tid; i < S; i += threads) mine.push_back(i);
@@ -206,8 +208,13 @@ int main(int argc, char** argv) {
       double n = now_s();
       if (n > e.t) amax(max_send_lag_us, (long)((n - e.t) * 1e6));
       if (n - e.t > 0.5 * period / packets_per_frame + 2e-3) { e.t = n; slipped.fetch_add(1); }   // fell behind: re-base — a microphone cannot burst either
-      while (n < e.t) {
-        if (e.t - n > 2e-4) usleep((useconds_t)((e.t - n) * 5e5));
+      // Pace WITHOUT spinning: a packet may leave up to 150 us early (1.5 % of its 10 ms), anything further away is slept for (timer slack 1 us, set
+      // at thread start).  The spin-wait this replaces burned a whole core per sender thread whatever the load - under a 16-core cgroup quota that
+      // was cores taken from the server under test (round 6: 7 - 9 "load generator" cores at 8192 dialogues, most of it waiting).
+      while (e.t - n > 150e-6) {
+        const double until = e.t - 60e-6;
+        timespec ts{(time_t)until, (long)((until - (double)(time_t)until) * 1e9)};
+        clock_nanosleep(CLOCK_MONOTONIC, TIMER_ABSTIME, &ts, nullptr);
         n = now_s();
       }
       const uint8_t* p = (const uint8_t*)(audio.data() + ((size_t)(e.frame % NF) * hop + (size_t)e.pk * pk_samples) * 2);
