@@ -170,7 +170,7 @@ def run_door(args, argv) -> int:
         for w in workers:
             w.terminate()
         return 1
-    print(f"[vapx] {n} GPU(s) x {args.streams} dialogue slots in {n} worker processes, mode {mode or 'from the state dict'}, {args.precision} arithmetic, "
+    print(f"[vapx] {n} GPU(s) x {args.streams} dialogue slots in {n} worker processes, mode {mode or ('vap' if args.synthetic_weights is not None else 'from the state dict')}, {args.precision} arithmetic, "
           f"{args.vap_process_rate} Hz / {args.context_len_sec} s — input :{door.port_in}, output :{door.port_out} (front-door process: dialogue k -> GPU k mod N)", flush=True)
     rc = 0
     while not stop["now"]:
