@@ -22,7 +22,7 @@ if SPLIT and (t[:, 30] > 0).any() and int(np.median(t[t[:, 30] > 0, 30])) != NST
     NST = int(np.median(t[t[:, 30] > 0, 30]))
     head = ["entry", "attention rows staged (scaled, split)", "proj mm", "residual add", "barrier (rows read)", "park + barrier", "row stats (LDS reads, reductions)", "LN + split -> sX + barrier"]
     woven = ["ffn1.0 mm", "gelu.0 -> sH under ffn1.1 mm", "ffn2.0 mm", "gelu.1 -> sH under ffn1.2 mm", "ffn2.1 mm", "gelu.2 -> sH", "ffn2.2 mm"]
-    apart = ["ffn1.0 mm", "gelu.0 -> sH", "ffn2.0 mm", "ffn1.1 mm", "gelu.1 -> sH", "ffn2.1 mm", "ffn1.2 mm", "gelu.2 -> sH", "ffn2.2 mm"]      # VAPX_F16X3_WOVEN_GELU=0
+    apart = ["ffn1.0 mm", "gelu.0 -> sH", "ffn2.0 mm", "ffn1.1 mm", "gelu.1 -> sH", "ffn2.1 mm", "ffn1.2 mm", "gelu.2 -> sH", "ffn2.2 mm"]      # the un-woven variant (tools/microbench/patches/ffn_block_f16x3_knobs.patch)
     tail = ["resid (+ x_out store)", "row stats + x_out / xn_out rows", "kvx0 mm+store", "kvx1 mm", "kvx1 scale + stores issued"]
     m1 = head + (apart if NST >= len(head) + len(apart) + len(tail) else woven) + tail
     NAMES = (m1 + [f"stamp {k}" for k in range(len(m1), NST)])[:NST]

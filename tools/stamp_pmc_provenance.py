@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Stamp every workload of profiles/pmc_traffic.json with the tree its PMC passes were taken at: ``_source = {"git": commit, "csrc_sha": hash of
 vap-realtime_amd/csrc at that commit}``.  For entries that have no stamp yet the commit is the LAST one that changed the entry's per-kernel
-numbers (found by replaying the file's git history) — the passes were committed with the tree they ran on.  New passes are stamped by
-tools/pmc_traffic.py when they are merged (`--stamp-worktree`: the current sources, commit = HEAD + "+dirty" if the tree has changes).
+numbers (found by replaying the file's git history) — the passes were committed with the tree they ran on.  New passes are stamped when they are taken:
+tools/profile_configs.sh writes the content hash of the sources ON the GPU box (source.json), tools/summarize_profiles.py stores it with the commit.
 bench.py compares csrc_sha with the sources it runs (roofline.traffic_source.stale)."""
 import json
 import os
